@@ -1,0 +1,148 @@
+/*
+ * photonbend_hip.h - C ABI of the MI355X (gfx950) per-pixel lens remapper.
+ *
+ * This is the drop-in boundary for photonbend's core remap path.  Every entry
+ * point is extern "C", takes plain pointers and sizes, returns 0 on success or
+ * a negative pb_status (message via pb_last_error()), never throws, never
+ * allocates or synchronises inside a launch function (so a caller may capture
+ * launches into a hipGraph), and works on caller-owned DEVICE buffers on a
+ * caller-chosen HIP stream (passed as void*; NULL = the default stream).
+ *
+ * Reference interfaces replaced (all paths under /root/reference/photonbend):
+ *   pb_proj            the state of CameraImage (core/projection.py:86-121),
+ *                      DoubleCameraImage (:296-316) and PanoramaImage (:477-485)
+ *   pb_plan_create     dst.get_coordinate_map() -> Rotation.rotate_coordinate_map()*
+ *                      -> src.process_coordinate_map()  chained lazily
+ *                      (core/__init__.py:66-92)
+ *   pb_remap_u8        that chain, fused: one work-item per output pixel
+ *   pb_index_map_i32   the integer coordinate map inside process_coordinate_map
+ *                      (projection.py:254-259, :545)
+ *   pb_coordmap_f64    get_coordinate_map()  (projection.py:147, :341, :487)
+ *   pb_rotate_f64      Rotation.rotate_coordinate_map()  (core/rotation.py:102-176)
+ *   pb_sample_map_u8   process_coordinate_map(ndarray)  (projection.py:197, :408, :515)
+ *
+ * Images are uint8 (H, W, 3) RGB, row-major, tightly packed (core/__init__.py:31-36).
+ * Coordinate maps are float64 (H, W, 3) = (latitude, longitude, invalid flag)
+ * (core/__init__.py:42-49).  Angles are radians.
+ */
+#ifndef PHOTONBEND_HIP_H
+#define PHOTONBEND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define PB_ABI_VERSION 1
+#define PB_MAX_ROTATIONS 8
+
+typedef enum pb_status {
+    PB_OK = 0,
+    PB_ERR_INVALID = -1,   /* bad argument (null pointer, size, enum value) */
+    PB_ERR_HIP = -2,       /* a HIP runtime call failed */
+    PB_ERR_UNSUPPORTED = -3,
+    PB_ERR_NO_DEVICE = -4
+} pb_status;
+
+/* projection.py class -> kind */
+typedef enum pb_kind {
+    PB_KIND_CAMERA = 0, /* CameraImage        projection.py:69  */
+    PB_KIND_DOUBLE = 1, /* DoubleCameraImage  projection.py:277 */
+    PB_KIND_PANO = 2    /* PanoramaImage      projection.py:465 */
+} pb_kind;
+
+/* core/lens.py factories :341-401 */
+typedef enum pb_lens {
+    PB_LENS_EQUIDISTANT = 0,
+    PB_LENS_EQUISOLID = 1,
+    PB_LENS_RECTILINEAR = 2,
+    PB_LENS_STEREOGRAPHIC = 3,
+    PB_LENS_ORTHOGRAPHIC = 4,
+    PB_LENS_THOBY = 5
+} pb_lens;
+
+/* One end of a remap.  f_distance is computed by the HOST with the reference
+ * formula magnitude / forward_lens(fov / 2) (projection.py:141-144) so that its
+ * bits are the caller's; the kernels never recompute it. */
+typedef struct pb_proj {
+    int32_t kind;      /* pb_kind */
+    int32_t lens;      /* pb_lens (ignored for PB_KIND_PANO) */
+    int32_t height;
+    int32_t width;
+    double fov;        /* radians; the per-sensor fov for PB_KIND_DOUBLE */
+    double magnitude;  /* informational (already folded into f_distance) */
+    double f_distance; /* focal distance in pixels */
+} pb_proj;
+
+typedef struct pb_plan pb_plan; /* opaque, immutable after creation */
+
+/* ---- library / device ------------------------------------------------- */
+int pb_abi_version(void);
+const char* pb_last_error(void); /* thread-local, valid until the next failing call */
+int pb_init(int device);         /* hipSetDevice + sanity checks (gfx950 expected) */
+int pb_shutdown(void);
+int pb_device_name(char* buf, size_t buflen);
+
+/* ---- the fused hot path ------------------------------------------------ */
+/* rot3x3: n_rot row-major 3x3 float64 matrices = Rotation.rotation_matrix
+ * (core/rotation.py:100), applied in order; n_rot in [0, PB_MAX_ROTATIONS]. */
+int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, pb_plan** out);
+void pb_plan_destroy(pb_plan* plan);
+int pb_plan_dst_shape(const pb_plan* plan, int* height, int* width);
+int pb_plan_src_shape(const pb_plan* plan, int* height, int* width);
+
+/* Remap n_frames frames that share the plan's geometry.  Frame f is read at
+ * src_dev + f * src_frame_stride and written at dst_dev + f * dst_frame_stride
+ * (strides in bytes; pass 0 for tightly packed frames).  The per-pixel index
+ * math runs once per output pixel per launch and is reused across the frames. */
+int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames,
+                size_t src_frame_stride, size_t dst_frame_stride, void* stream);
+
+/* Integer coordinate map: for camera / pano sources idx_dev is int32 [H*W], the
+ * linear source pixel index (row * src_width + col) or -1 where the output is
+ * black.  For a double source idx_dev is int32 [2][H*W] (left-eye index, then
+ * right-eye index, both into the full side-by-side frame) and, when weights_dev
+ * is not NULL, float64 [2][H*W] receives the two blend factors
+ * (projection.py:439-457). */
+int pb_index_map_i32(const pb_plan* plan, int32_t* idx_dev, double* weights_dev, void* stream);
+
+/* ---- materialised coordinate-map API (protocol compatibility) --------- */
+int pb_coordmap_f64(const pb_proj* dst, double* map_dev, void* stream);
+/* Zeroes lat/lon of invalid pixels IN map_in_dev (rotation.py:119-125), like the
+ * reference; map_out_dev must not alias map_in_dev. */
+int pb_rotate_f64(const double* rot3x3, double* map_in_dev, double* map_out_dev, int height, int width,
+                  void* stream);
+/* map is (height, width, 3); PB_KIND_PANO zeroes invalid lat/lon in map_dev
+ * (projection.py:534-536). */
+int pb_sample_map_u8(const pb_proj* src, double* map_dev, int height, int width, const uint8_t* src_dev,
+                     uint8_t* dst_dev, void* stream);
+
+/* ---- deterministic synthetic frames (bench + tests) -------- */
+/* circle_mask: 0 none, 1 black outside the inscribed circle, 2 black outside
+ * the two side-by-side inscribed circles. */
+int pb_synth_frame_u8(uint8_t* frame_dev, int height, int width, uint32_t frame, uint32_t seed, int circle_mask,
+                      void* stream);
+
+/* ---- plumbing for hosts without their own device allocator ------------ */
+int pb_malloc(void** dev_ptr, size_t bytes);
+int pb_free(void* dev_ptr);
+int pb_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int pb_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int pb_memset(void* dst_dev, int value, size_t bytes, void* stream);
+int pb_stream_create(void** stream);
+int pb_stream_destroy(void* stream);
+int pb_stream_sync(void* stream);
+int pb_event_create(void** event);
+int pb_event_destroy(void* event);
+int pb_event_record(void* event, void* stream);
+int pb_event_sync(void* event);
+int pb_event_elapsed_ms(void* start, void* stop, float* ms);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHOTONBEND_HIP_H */

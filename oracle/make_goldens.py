@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY - golden-vector generator.
+
+Runs ONLY in the build container: it imports the real reference read-only from
+/root/reference (never copied, never shipped), pushes the shared case matrix
+(tests/cases.py) through the reference's public API and writes small fixtures
+under tests/golden/:
+
+  lens.npz        G1  forward/inverse of the six lenses on a fixed grid (f64 bits)
+  small.npz       G2-G6  per case: f_distance bits, rotation matrices, integer
+                  source-index map, uint8 output on the synthetic frame, fragile
+                  mask, and (for keep_map cases) the float64 coordinate maps
+  full.json       G7  full-size pins for the BASELINE configs: SHA-256 of the
+                  index map and of the uint8 output, 65 536 seeded samples,
+                  valid-pixel and distinct-texel counts
+
+Usage:  python oracle/make_goldens.py [--small] [--full] [--lens]
+(no flag = everything; --full needs ~10 GB of RAM and a few minutes).
+"""
+
+from __future__ import annotations
+
+import argparse
+import hashlib
+import json
+import os
+import sys
+import warnings
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+
+from oracle import reference_path as orc  # noqa: E402
+from oracle.synth import synth_frame  # noqa: E402
+from tests.cases import Case, full_cases, small_cases  # noqa: E402
+
+import photonbend.core.lens as ref_lens  # noqa: E402
+from photonbend.core.projection import CameraImage, DoubleCameraImage, PanoramaImage  # noqa: E402
+from photonbend.core.rotation import Rotation  # noqa: E402
+from photonbend.utils import to_radians  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+warnings.simplefilter("ignore")
+np.seterr(all="ignore")
+
+
+def ref_obj(p, image=None):
+    kind, h, w, lens, fov, mag = p
+    if image is None:
+        image = np.zeros((h, w, 3), np.uint8)
+    if kind == "pano":
+        return PanoramaImage(image)
+    L = getattr(ref_lens, lens)()
+    if kind == "camera":
+        return CameraImage(image, to_radians(fov), L, magnitude=mag)
+    return DoubleCameraImage(image, to_radians(fov), L)
+
+
+def orc_proj(p):
+    kind, h, w, lens, fov, mag = p
+    if kind == "pano":
+        return orc.Proj("pano", h, w)
+    return orc.Proj(kind, h, w, lens, to_radians(fov), mag)
+
+
+def ref_map(case: Case):
+    dst = ref_obj(case.dst)
+    m = dst.get_coordinate_map()
+    stages = [np.copy(m)]
+    mats = []
+    for rot in case.rotations:
+        r = Rotation(*map(to_radians, rot))
+        mats.append(np.copy(r.rotation_matrix))
+        m = r.rotate_coordinate_map(m)
+        stages.append(np.copy(m))
+    return dst, m, stages, mats
+
+
+def ref_index(case: Case, cmap):
+    """Integer source-index map straight from the reference: feed it an int32
+    'image' whose pixel value is its own linear index + 1 (the reference only
+    fancy-indexes and zeroes, so any dtype passes through)."""
+    kind, h, w, lens, fov, mag = case.src
+    ids = (np.arange(h * w, dtype=np.int32) + 1).reshape(h, w)
+    if kind != "double":
+        src = ref_obj(case.src, ids)
+        return (src.process_coordinate_map(np.copy(cmap)) - 1).astype(np.int32)
+    # the two CameraImage objects DoubleCameraImage builds internally, made here
+    # through the public constructor on the same halves
+    L = getattr(ref_lens, lens)()
+    w2 = w // 2
+    left = CameraImage(ids[:, :w2], to_radians(fov), L)
+    right = CameraImage(np.copy(ids[:, w2:])[:, ::-1], to_radians(fov), L)
+    rmap = np.copy(cmap)
+    rmap[:, :, 0] *= -1
+    rmap[:, :, 0] += np.pi
+    il = left.process_coordinate_map(np.copy(cmap)) - 1
+    ir = right.process_coordinate_map(rmap) - 1
+    return il.astype(np.int32), ir.astype(np.int32)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def gen_lens():
+    grid = np.array(
+        [0.0, 1e-300, 1e-12, 0.1, 0.5, 0.7071067811865476, 1.0, 1.2, 1.47, 1.5, 2.0, 2.0000000000000004, 2.5, 3.0, 7.0, 100.0]
+        + [to_radians(d) / 2 for d in (140, 178, 180, 195, 360)]
+        + list(np.linspace(0.01, 3.2, 40)),
+        dtype=np.float64,
+    )
+    out = {"grid": bits(grid)}
+    for name in orc.LENSES:
+        L = getattr(ref_lens, name)()
+        out[f"{name}_fwd"] = bits(L.forward_function(np.copy(grid)))
+        out[f"{name}_inv"] = bits(L.reverse_function(np.copy(grid)))
+    np.savez_compressed(os.path.join(GOLD, "lens.npz"), **out)
+    print("lens.npz written")
+
+
+def gen_small():
+    out = {}
+    for case in small_cases():
+        dst, cmap, stages, mats = ref_map(case)
+        kind, h, w, *_ = case.src
+        frame = synth_frame(h, w, frame=0, seed=0, circle_mask=case.mask)
+        src = ref_obj(case.src, frame)
+        n = case.name
+        if case.dst[0] != "pano":
+            out[f"{n}/dst_f"] = bits(np.array([dst.f_distance]))
+        if case.src[0] != "pano":
+            out[f"{n}/src_f"] = bits(np.array([src.f_distance]))
+        if mats:
+            out[f"{n}/R"] = bits(np.stack(mats))
+        idx = ref_index(case, cmap)
+        u8 = src.process_coordinate_map(np.copy(cmap))
+        # oracle restatement on the same case: must agree bit for bit, then it
+        # supplies what the reference keeps in local variables
+        od, os_ = orc_proj(case.dst), orc_proj(case.src)
+        rots = [tuple(map(to_radians, r)) for r in case.rotations]
+        oidx = orc.remap_index(od, os_, rots)
+        if kind == "double":
+            assert np.array_equal(oidx[0], idx[0]) and np.array_equal(oidx[1], idx[1]), n
+            out[f"{n}/idx_l"], out[f"{n}/idx_r"] = idx
+            out[f"{n}/w_l"], out[f"{n}/w_r"] = bits(oidx[2]), bits(oidx[3])
+        else:
+            assert np.array_equal(oidx, idx), n
+            out[f"{n}/idx"] = idx
+        assert np.array_equal(orc.remap(od, os_, frame, rots), u8), n
+        out[f"{n}/u8"] = u8
+        out[f"{n}/fragile"] = np.packbits(orc.fragile_mask(orc.pretrunc(od, os_, rots)))
+        if case.keep_map:
+            for k, st in enumerate(stages):
+                out[f"{n}/map{k}"] = bits(st)
+        print(f"  {n}: ok ({u8.shape[0]}x{u8.shape[1]})")
+    np.savez_compressed(os.path.join(GOLD, "small.npz"), **out)
+    print("small.npz written,", len(out), "arrays")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gen_full():
+    pins = {}
+    for case in full_cases():
+        dst, cmap, _, mats = ref_map(case)
+        kind, h, w, *_ = case.src
+        frame = synth_frame(h, w, frame=0, seed=0, circle_mask=case.mask)
+        src = ref_obj(case.src, frame)
+        idx = ref_index(case, cmap)
+        u8 = src.process_coordinate_map(np.copy(cmap))
+        H, W = u8.shape[:2]
+        rng = np.random.default_rng(12345)
+        pos = rng.integers(0, H * W, size=65536)
+        pin = {
+            "dst": list(case.dst),
+            "src": list(case.src),
+            "rotations": [list(r) for r in case.rotations],
+            "mask": case.mask,
+            "u8_sha256": sha(u8),
+            "frame_sha256": sha(frame),
+            "sample_seed": 12345,
+            "u8_samples_sha256": sha(u8.reshape(-1, 3)[pos]),
+        }
+        if case.dst[0] != "pano":
+            pin["dst_f_bits"] = int(bits(np.array([dst.f_distance]))[0])
+        if case.src[0] != "pano":
+            pin["src_f_bits"] = int(bits(np.array([src.f_distance]))[0])
+        if mats:
+            pin["R_bits"] = [int(v) for v in bits(np.stack(mats)).ravel()]
+        if kind == "double":
+            il, ir = idx
+            pin["idx_l_sha256"], pin["idx_r_sha256"] = sha(il), sha(ir)
+            pin["idx_l_samples"] = [int(v) for v in il.ravel()[pos[:2048]]]
+            pin["idx_r_samples"] = [int(v) for v in ir.ravel()[pos[:2048]]]
+            pin["valid_left"] = int((il >= 0).sum())
+            pin["valid_right"] = int((ir >= 0).sum())
+            pin["in_bounds_samples"] = pin["valid_left"] + pin["valid_right"]
+        else:
+            pin["idx_sha256"] = sha(idx)
+            pin["idx_samples"] = [int(v) for v in idx.ravel()[pos[:2048]]]
+            pin["in_bounds_samples"] = int((idx >= 0).sum())
+            pin["distinct_texels"] = int(np.unique(idx[idx >= 0]).size)
+        pin["algorithmic_bytes"] = 3 * H * W + 3 * pin["in_bounds_samples"]
+        pin["u8_samples"] = [int(v) for v in u8.reshape(-1, 3)[pos[:2048]].ravel()]
+        pins[case.name] = pin
+        print(f"  {case.name}: in-bounds {pin['in_bounds_samples']}, algorithmic bytes {pin['algorithmic_bytes']}")
+        del cmap, idx, u8, frame
+    with open(os.path.join(GOLD, "full.json"), "w") as f:
+        json.dump(pins, f, indent=1)
+    print("full.json written")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lens", action="store_true")
+    ap.add_argument("--small", action="store_true")
+    ap.add_argument("--full", action="store_true")
+    a = ap.parse_args()
+    everything = not (a.lens or a.small or a.full)
+    os.makedirs(GOLD, exist_ok=True)
+    if a.lens or everything:
+        gen_lens()
+    if a.small or everything:
+        gen_small()
+    if a.full or everything:
+        gen_full()

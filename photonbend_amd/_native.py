@@ -1,0 +1,229 @@
+"""ctypes binding of include/photonbend_hip.h (the C ABI of the HIP library).
+
+There is no fallback: if ``libphotonbend_hip.so`` is missing or a call fails,
+this module raises.  PyTorch is imported FIRST on purpose - it ships its own
+``libamdhip64.so`` (SONAME libamdhip64.so.7); loading it before our library
+makes both share one HIP runtime, so torch device pointers and streams can be
+handed straight to the kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import torch  # noqa: F401  (must precede the CDLL below - see module docstring)
+
+from .build import LIB_PATH
+
+PB_MAX_ROTATIONS = 8
+KIND_CAMERA, KIND_DOUBLE, KIND_PANO = 0, 1, 2
+LENS_IDS = {
+    "equidistant": 0,
+    "equisolid": 1,
+    "rectilinear": 2,
+    "stereographic": 3,
+    "orthographic": 4,
+    "thoby": 5,
+}
+
+
+class PbError(RuntimeError):
+    pass
+
+
+class pb_proj(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("lens", C.c_int32),
+        ("height", C.c_int32),
+        ("width", C.c_int32),
+        ("fov", C.c_double),
+        ("magnitude", C.c_double),
+        ("f_distance", C.c_double),
+    ]
+
+    def key(self):
+        return (self.kind, self.lens, self.height, self.width, self.fov, self.magnitude, self.f_distance)
+
+
+# name -> (restype, argtypes); every symbol of include/photonbend_hip.h
+_VP = C.c_void_p
+SIGNATURES = {
+    "pb_abi_version": (C.c_int, []),
+    "pb_last_error": (C.c_char_p, []),
+    "pb_init": (C.c_int, [C.c_int]),
+    "pb_shutdown": (C.c_int, []),
+    "pb_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "pb_plan_create": (C.c_int, [C.POINTER(pb_proj), C.POINTER(C.c_double), C.c_int, C.POINTER(pb_proj), C.POINTER(_VP)]),
+    "pb_plan_destroy": (None, [_VP]),
+    "pb_plan_dst_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pb_plan_src_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pb_remap_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
+    "pb_index_map_i32": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "pb_coordmap_f64": (C.c_int, [C.POINTER(pb_proj), _VP, _VP]),
+    "pb_rotate_f64": (C.c_int, [C.POINTER(C.c_double), _VP, _VP, C.c_int, C.c_int, _VP]),
+    "pb_sample_map_u8": (C.c_int, [C.POINTER(pb_proj), _VP, C.c_int, C.c_int, _VP, _VP, _VP]),
+    "pb_synth_frame_u8": (C.c_int, [_VP, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, _VP]),
+    "pb_malloc": (C.c_int, [C.POINTER(_VP), C.c_size_t]),
+    "pb_free": (C.c_int, [_VP]),
+    "pb_memcpy_h2d": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
+    "pb_memcpy_d2h": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
+    "pb_memset": (C.c_int, [_VP, C.c_int, C.c_size_t, _VP]),
+    "pb_stream_create": (C.c_int, [C.POINTER(_VP)]),
+    "pb_stream_destroy": (C.c_int, [_VP]),
+    "pb_stream_sync": (C.c_int, [_VP]),
+    "pb_event_create": (C.c_int, [C.POINTER(_VP)]),
+    "pb_event_destroy": (C.c_int, [_VP]),
+    "pb_event_record": (C.c_int, [_VP, _VP]),
+    "pb_event_sync": (C.c_int, [_VP]),
+    "pb_event_elapsed_ms": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree HIP library and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise PbError(
+                f"{LIB_PATH} is missing - build it with `python -m photonbend_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        if lib.pb_abi_version() != 1:
+            raise PbError(f"ABI version mismatch: library says {lib.pb_abi_version()}, binding expects 1")
+        _lib = lib
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = load().pb_last_error()
+        raise PbError(f"photonbend_hip error {status}: {msg.decode() if msg else '?'}")
+
+
+def current_stream() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise PbError("no HIP device is visible; photonbend_amd has no CPU path")
+
+
+class Plan:
+    """Owner of one pb_plan (dst projection, rotations, src projection)."""
+
+    def __init__(self, dst: pb_proj, rotations, src: pb_proj):
+        lib = load()
+        rots = np.ascontiguousarray(np.asarray(list(rotations), dtype=np.float64).reshape(-1, 9))
+        if rots.shape[0] > PB_MAX_ROTATIONS:
+            raise PbError(f"at most {PB_MAX_ROTATIONS} chained rotations are supported")
+        self._h = _VP()
+        rp = rots.ctypes.data_as(C.POINTER(C.c_double)) if rots.shape[0] else None
+        check(lib.pb_plan_create(C.byref(dst), rp, rots.shape[0], C.byref(src), C.byref(self._h)))
+        self.dst, self.src, self.n_rot = dst, src, rots.shape[0]
+        self.double_src = src.kind == KIND_DOUBLE
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.pb_plan_destroy(h)
+
+    # -- launches (torch tensors in, torch tensors out; all on the current stream)
+    def remap(self, src: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """src: uint8 cuda tensor (h, w, 3) or (N, h, w, 3) -> (H, W, 3) / (N, H, W, 3)."""
+        require_gpu()
+        batched = src.dim() == 4
+        s = src if batched else src.unsqueeze(0)
+        if s.dtype != torch.uint8 or not s.is_cuda or tuple(s.shape[1:]) != (self.src.height, self.src.width, 3):
+            raise PbError(f"source frames must be uint8 cuda (N, {self.src.height}, {self.src.width}, 3), got {tuple(src.shape)} {src.dtype}")
+        s = s.contiguous()
+        n = s.shape[0]
+        if out is None:
+            out = torch.empty((n, self.dst.height, self.dst.width, 3), dtype=torch.uint8, device=s.device)
+            o = out
+        else:
+            o = out if out.dim() == 4 else out.unsqueeze(0)
+            if o.dtype != torch.uint8 or not o.is_contiguous() or tuple(o.shape) != (n, self.dst.height, self.dst.width, 3):
+                raise PbError("out must be a contiguous uint8 cuda tensor of the destination shape")
+        with torch.cuda.device(s.device):
+            check(load().pb_remap_u8(self._h, s.data_ptr(), o.data_ptr(), n, 0, 0, current_stream()))
+        return o if batched else o[0]
+
+    def index_map(self, weights: bool = False, device=None):
+        """int32 (H, W) index map, or for a double source (2, H, W) [+ float64 (2, H, W) weights]."""
+        require_gpu()
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        H, W = self.dst.height, self.dst.width
+        shape = (2, H, W) if self.double_src else (H, W)
+        idx = torch.empty(shape, dtype=torch.int32, device=device)
+        w = torch.empty((2, H, W), dtype=torch.float64, device=device) if (weights and self.double_src) else None
+        with torch.cuda.device(device):
+            check(load().pb_index_map_i32(self._h, idx.data_ptr(), w.data_ptr() if w is not None else None, current_stream()))
+        return (idx, w) if weights else idx
+
+
+def make_proj(kind: int, height: int, width: int, lens: int = 0, fov: float = 0.0, magnitude: float = 0.0, f_distance: float = 0.0) -> pb_proj:
+    return pb_proj(int(kind), int(lens), int(height), int(width), float(fov), float(magnitude), float(f_distance))
+
+
+def coordmap(dst: pb_proj, device=None) -> torch.Tensor:
+    require_gpu()
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    out = torch.empty((dst.height, dst.width, 3), dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        check(load().pb_coordmap_f64(C.byref(dst), out.data_ptr(), current_stream()))
+    return out
+
+
+def rotate(matrix: np.ndarray, cmap: torch.Tensor) -> torch.Tensor:
+    """cmap (H, W, 3) float64 cuda, contiguous; invalid lat/lon are zeroed in it."""
+    require_gpu()
+    m = np.ascontiguousarray(matrix, dtype=np.float64).reshape(9)
+    out = torch.empty_like(cmap)
+    with torch.cuda.device(cmap.device):
+        check(load().pb_rotate_f64(m.ctypes.data_as(C.POINTER(C.c_double)), cmap.data_ptr(), out.data_ptr(), cmap.shape[0], cmap.shape[1], current_stream()))
+    return out
+
+
+def sample_map(src: pb_proj, cmap: torch.Tensor, image: torch.Tensor) -> torch.Tensor:
+    require_gpu()
+    out = torch.empty((cmap.shape[0], cmap.shape[1], 3), dtype=torch.uint8, device=cmap.device)
+    with torch.cuda.device(cmap.device):
+        check(load().pb_sample_map_u8(C.byref(src), cmap.data_ptr(), cmap.shape[0], cmap.shape[1], image.data_ptr(), out.data_ptr(), current_stream()))
+    return out
+
+
+def synth_frame(height: int, width: int, frame: int = 0, seed: int = 0, circle_mask: int = 0, device=None, out: torch.Tensor | None = None) -> torch.Tensor:
+    require_gpu()
+    if out is None:
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        out = torch.empty((height, width, 3), dtype=torch.uint8, device=device)
+    with torch.cuda.device(out.device):
+        check(load().pb_synth_frame_u8(out.data_ptr(), height, width, frame & 0xFFFFFFFF, seed & 0xFFFFFFFF, circle_mask, current_stream()))
+    return out
+
+
+def device_name() -> str:
+    buf = C.create_string_buffer(256)
+    check(load().pb_device_name(buf, 256))
+    return buf.value.decode()

@@ -1,0 +1,66 @@
+"""Builds the HIP shared library in-tree with hipcc for gfx950 (cross-compiles
+without a GPU).  ``python -m photonbend_amd.build`` or ``build_library()``."""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_NAME = "libphotonbend_hip.so"
+LIB_PATH = os.path.join(HERE, LIB_NAME)
+
+# -ffp-contract=off: the reference rounds every multiply and add separately; the
+# kernels fuse only where they say fma() (see csrc/pb_stages.hpp).
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-ffp-contract=off",
+    "-fPIC",
+    "-shared",
+    "-fvisibility=hidden",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH and /opt/rocm/bin/hipcc)")
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "photonbend_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB_PATH
+    cmd = [_hipcc(), *HIPCC_FLAGS, *sources(), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    if verbose and res.stderr:
+        print(res.stderr, file=sys.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

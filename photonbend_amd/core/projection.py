@@ -1,0 +1,191 @@
+"""Projection images - the drop-in for photonbend.core.projection
+(projection.py:40-547): ``CameraImage``, ``DoubleCameraImage``, ``PanoramaImage``
+behind the ``ProjectionImage`` protocol, same constructor signatures, same public
+attributes, same error behaviour.
+
+What differs is where the work happens.  ``get_coordinate_map()`` returns a lazy
+``CoordinateMap`` recipe; ``process_coordinate_map(recipe)`` runs ONE fused HIP
+kernel (pb_remap_u8) in which each output pixel's inverse projection, rotations,
+forward projection and sample happen in registers.  A real ndarray map (a recipe
+that was looked at or edited, or a hand-made map) is sampled by the
+materialised-map kernel (pb_sample_map_u8).  There is no NumPy path.
+
+``image`` may be a NumPy uint8 array (H, W, 3) - uploaded per call, result
+returned as a fresh ndarray like the reference - or a uint8 CUDA tensor, which
+stays on the device and yields a CUDA tensor.
+"""
+
+from __future__ import annotations
+
+from abc import abstractmethod
+from typing import Protocol, Union
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from ._coordmap import CoordinateMap
+from .lens import Lens, lens_id
+
+_PLAN_CACHE: dict = {}
+_PLAN_CACHE_MAX = 64
+
+
+def _plan_for(dst: nat.pb_proj, rotations, src: nat.pb_proj) -> nat.Plan:
+    key = (dst.key(), tuple(np.asarray(r, dtype=np.float64).tobytes() for r in rotations), src.key())
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+            _PLAN_CACHE.clear()
+        plan = _PLAN_CACHE[key] = nat.Plan(dst, rotations, src)
+    return plan
+
+
+def _shape_hw(image) -> tuple:
+    shp = tuple(image.shape)
+    if len(shp) < 2:
+        raise ValueError("an image needs at least (height, width)")
+    return int(shp[0]), int(shp[1])
+
+
+def _device_image(image, height: int, width: int) -> torch.Tensor:
+    """uint8 CUDA tensor (h, w, 3) of the pixels behind ``.image``."""
+    nat.require_gpu()
+    if isinstance(image, torch.Tensor):
+        t = image
+        if t.dtype != torch.uint8:
+            raise TypeError("image tensors must be uint8")
+        if not t.is_cuda:
+            t = t.cuda()
+    else:
+        a = np.asarray(image)
+        if a.dtype != np.uint8:
+            raise TypeError(f"images are uint8 (H, W, 3) RGB arrays (core/__init__.py:31-36), got {a.dtype}")
+        t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    if tuple(t.shape) != (height, width, 3):
+        raise ValueError(f"image must have shape ({height}, {width}, 3), got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class ProjectionImage(Protocol):
+    """The protocol every projection image follows (projection.py:40-66)."""
+
+    image: np.ndarray
+
+    @abstractmethod
+    def get_coordinate_map(self):
+        ...
+
+    @abstractmethod
+    def process_coordinate_map(self, coordinate_map):
+        ...
+
+
+class _GpuProjection:
+    """Shared GPU plumbing of the three projection classes."""
+
+    image: Union[np.ndarray, torch.Tensor]
+
+    def _proj(self) -> nat.pb_proj:  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    def get_coordinate_map(self) -> CoordinateMap:
+        """This image's coordinate map, as a lazy recipe (see ``CoordinateMap``)."""
+        return CoordinateMap(self._proj())
+
+    def process_coordinate_map(self, coordinate_map):
+        """Maps this image's pixels through ``coordinate_map`` and returns the new
+        uint8 image (projection.py:197-245, :408-462, :515-547)."""
+        src = self._proj()
+        on_device = isinstance(self.image, torch.Tensor)
+        img = _device_image(self.image, src.height, src.width)
+        if isinstance(coordinate_map, CoordinateMap) and coordinate_map.is_lazy:
+            plan = _plan_for(coordinate_map.dst_proj, coordinate_map.rotations, src)
+            out = plan.remap(img)
+            if src.kind == nat.KIND_PANO:
+                coordinate_map.note_invalid_zeroed()  # projection.py:534-536
+            return out if on_device else out.cpu().numpy()
+        if isinstance(coordinate_map, torch.Tensor):
+            if not (coordinate_map.is_cuda and coordinate_map.dtype == torch.float64 and coordinate_map.is_contiguous()):
+                raise TypeError("tensor coordinate maps must be contiguous float64 CUDA tensors")
+            out = nat.sample_map(src, coordinate_map, img)
+            return out if on_device else out.cpu().numpy()
+        host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
+        if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
+            raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
+        dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+        out = nat.sample_map(src, dev, img)
+        if src.kind == nat.KIND_PANO:
+            host[...] = dev.cpu().numpy()  # the in-place zeroing of invalid pixels
+        return out if on_device else out.cpu().numpy()
+
+
+def _builtin_lens_id(lens: Lens) -> int:
+    lid = lens_id(lens)
+    if lid is None:
+        raise NotImplementedError(
+            "the GPU remap path knows the built-in lenses only (equidistant, equisolid, rectilinear, "
+            "stereographic, orthographic, thoby); a Lens made of arbitrary Python callables cannot run in a HIP kernel"
+        )
+    return lid
+
+
+class CameraImage(_GpuProjection):
+    """A single-fisheye / rectilinear camera image (projection.py:69-274).
+
+    Attributes: image, fov, forward_lens, reverse_lens, magnitude, f_distance."""
+
+    def __init__(self, image_arr, fov: float, lens: Lens, magnitude: Union[None, float] = None):
+        self.image = image_arr
+        self.fov = fov
+        self.forward_lens = lens.forward_function
+        self.reverse_lens = lens.reverse_function
+        self._lens = lens
+        height, _ = _shape_hw(image_arr)
+        self.magnitude: float = (height / 2.0) if (magnitude is None) else magnitude
+        self.f_distance = self._compute_f_distance()
+
+    def _compute_f_distance(self) -> float:
+        """Pixels per focal length: magnitude / forward(fov / 2) (projection.py:123-144);
+        raises what the lens raises (rectilinear beyond 178 degrees)."""
+        return self.magnitude / self.forward_lens(self.fov / 2)
+
+    def _proj(self) -> nat.pb_proj:
+        h, w = _shape_hw(self.image)
+        return nat.make_proj(nat.KIND_CAMERA, h, w, _builtin_lens_id(self._lens), self.fov, self.magnitude, self.f_distance)
+
+
+class DoubleCameraImage(_GpuProjection):
+    """Two side-by-side fisheyes from a 360-degree camera (projection.py:277-462).
+
+    Attributes: image, sensor_fov, lens, forward_lens, reverse_lens, magnitude,
+    f_distance.  Extra keyword arguments (the CLI passes ``magnitude=``) are
+    accepted and ignored, like the reference (projection.py:296-316)."""
+
+    def __init__(self, image_arr, sensor_fov: float, lens: Lens, **kwargs):
+        self.image = image_arr
+        self.sensor_fov = sensor_fov
+        self.lens = lens
+        self.forward_lens = lens.forward_function
+        self.reverse_lens = lens.reverse_function
+        height, _ = _shape_hw(image_arr)
+        self.magnitude = height / 2.0
+        self.f_distance = self._compute_f_distance()
+
+    def _compute_f_distance(self) -> float:
+        return self.magnitude / self.forward_lens(self.sensor_fov / 2)
+
+    def _proj(self) -> nat.pb_proj:
+        h, w = _shape_hw(self.image)
+        return nat.make_proj(nat.KIND_DOUBLE, h, w, _builtin_lens_id(self.lens), self.sensor_fov, self.magnitude, self.f_distance)
+
+
+class PanoramaImage(_GpuProjection):
+    """An equirectangular panorama (projection.py:465-547)."""
+
+    def __init__(self, image_arr) -> None:
+        self.image = image_arr
+
+    def _proj(self) -> nat.pb_proj:
+        h, w = _shape_hw(self.image)
+        return nat.make_proj(nat.KIND_PANO, h, w)

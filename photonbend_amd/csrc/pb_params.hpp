@@ -1,0 +1,103 @@
+// pb_params.hpp - the parameter block one remap launch carries (kernel argument,
+// passed by value) and the host code that derives it.  Every derived constant is
+// computed on the host in IEEE double with the SAME operation order the reference
+// uses in Python (file:line cited per field), so that kernels only ever replay
+// per-pixel arithmetic.
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/photonbend_hip.h"
+
+#define PB_PI 3.141592653589793  // == numpy.pi == M_PI
+
+struct PbEnd {
+    int32_t kind, lens, height, width;
+    double fov, f_distance;
+};
+
+struct PbParams {
+    PbEnd dst, src;
+    int32_t n_rot;
+    int32_t pad0;
+    double R[PB_MAX_ROTATIONS][9];
+
+    // ---- destination side -------------------------------------------------
+    double dst_half_fov;   // fov / 2            projection.py:160, :357
+    double dst_right_min;  // pi - fov / 2.0     projection.py:358-360 (double)
+    double dst_x0, dst_y0; // first linspace samples, projection.py:177-180, :390-400
+    int32_t dst_half_w;    // W // 2 (double)    projection.py:355
+    int32_t pad1;
+    // pano destination: np.linspace(start, stop, num) = k*step + start, last = stop
+    double pano_lon_start, pano_lon_stop, pano_lon_step;  // projection.py:500-504
+    double pano_lat_step;                                 // projection.py:505
+
+    // ---- source side --------------------------------------------------------
+    double src_hseg, src_wseg, src_half_w;  // pi/h, pi/(w/2), w/2   projection.py:539-543
+    int64_t src_nan_row, src_nan_col;       // INT64_MIN floor-mod h / w  (NaN -> int quirk)
+    double src_cy, src_cx, src_cx_r;        // h/2-0.5, w/2-0.5  projection.py:274 (per eye for double)
+    int32_t src_eye_w;                      // width of one eye (w // 2)  projection.py:413
+    int32_t src_eye_w_right;                // w - w // 2
+    double rect_max;                        // to_radians(89)  lens.py:91,98
+    double mrg_min, mrg_max, mrg_range, mrg_max_safe;  // projection.py:414-418
+};
+
+static inline int64_t pb_floor_mod_i64(int64_t a, int64_t n) {
+    int64_t r = a % n;
+    return (r < 0) ? r + n : r;
+}
+
+// np.linspace(start, stop, num): step = (stop - start) / (num - 1)
+static inline double pb_linspace_step(double start, double stop, int num) {
+    return (num > 1) ? (stop - start) / (double)(num - 1) : 0.0;
+}
+
+static inline void pb_derive(PbParams& P) {
+    const double pi = PB_PI;
+    // destination
+    {
+        const PbEnd& d = P.dst;
+        const double W = (double)d.width, H = (double)d.height;
+        P.dst_half_fov = d.fov / 2;
+        P.dst_right_min = pi - (d.fov / 2.0);
+        P.dst_half_w = d.width / 2;
+        P.dst_y0 = H / 2 - 0.5;
+        if (d.kind == PB_KIND_DOUBLE) {
+            const double half = (double)P.dst_half_w;
+            P.dst_x0 = -half / 2 + 0.5;
+        } else {
+            P.dst_x0 = -W / 2 + 0.5;
+        }
+        const double q = pi / W / 2;
+        P.pano_lon_start = -pi + q;
+        P.pano_lon_stop = pi - q;
+        P.pano_lon_step = pb_linspace_step(P.pano_lon_start, P.pano_lon_stop, d.width);
+        P.pano_lat_step = pb_linspace_step(0.0, pi, d.height);
+    }
+    // source
+    {
+        const PbEnd& s = P.src;
+        const double w = (double)s.width, h = (double)s.height;
+        P.src_wseg = pi / (w / 2);
+        P.src_hseg = pi / h;
+        P.src_half_w = w / 2;
+        P.src_nan_row = pb_floor_mod_i64(INT64_MIN, s.height);
+        P.src_nan_col = pb_floor_mod_i64(INT64_MIN, s.width);
+        P.src_eye_w = s.width / 2;
+        P.src_eye_w_right = s.width - s.width / 2;
+        P.src_cy = h / 2 - 0.5;
+        if (s.kind == PB_KIND_DOUBLE) {
+            P.src_cx = (double)P.src_eye_w / 2 - 0.5;
+            P.src_cx_r = (double)P.src_eye_w_right / 2 - 0.5;
+        } else {
+            P.src_cx = w / 2 - 0.5;
+            P.src_cx_r = P.src_cx;
+        }
+        const double ref = (s.fov / 2) - (pi / 2);
+        P.mrg_min = pi / 2 - ref;
+        P.mrg_max = pi / 2 + ref;
+        P.mrg_range = 2.0 * ref;
+        P.mrg_max_safe = P.mrg_max + (0.5 / 180 * pi);
+    }
+    P.rect_max = 89.0 / 180 * pi;
+}

@@ -1,0 +1,206 @@
+// pb_stages.hpp - the three per-pixel stages of photonbend's remap, as device
+// functions for ONE output pixel, in "faithful" float64: every IEEE-exact
+// operation (add, mul, div, sqrt, fma) is replayed in the reference's order with
+// contraction disabled (-ffp-contract=off), transcendentals come from the device
+// libm, and the NumPy cast quirks are spelled out.
+//
+//   stage A  dst_coord()      pixel (i, j) -> (lat, lon, invalid)
+//            CameraImage._compute_latitude_longitude  projection.py:171-194
+//            DoubleCameraImage._compute_latitude_longitude  :370-406
+//            PanoramaImage.get_coordinate_map  :487-513
+//   stage B  rotate()         Rotation.rotate_coordinate_map  rotation.py:102-176
+//   stage C  src_*_index()    process_coordinate_map minus the gather
+//            projection.py:197-260 (camera), :408-462 (double), :515-547 (pano)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pb_params.hpp"
+
+struct PbCoord {
+    double lat, lon;
+    bool inv;
+};
+
+// ---- NumPy / x86 cast semantics ------------------------------------------------
+// float64 -> int64 as cvttsd2si does it: truncate toward zero; NaN, +-inf and
+// anything outside int64 give INT64_MIN (SURVEY 2 "to-pixel", probe).
+__device__ __forceinline__ long long pb_cvt_i64(double v) {
+    if (!(fabs(v) < 9223372036854775808.0)) return (long long)0x8000000000000000ull;
+    return (long long)v;
+}
+// float64 -> uint8 as NumPy's astype(np.uint8) does it on x86-64: truncate to a
+// 32-bit integer (invalid -> 0x80000000), keep the low 8 bits (SURVEY 8 a-6 probe:
+// 300.0 -> 44, -1.0 -> 255, NaN / +-inf -> 0).
+__device__ __forceinline__ unsigned pb_cvt_u8(double v) {
+    if (!(fabs(v) < 2147483648.0)) return 0u;
+    return ((unsigned)(int)v) & 0xFFu;
+}
+// Python floor-mod of an int64 by a small positive n, fast when 0 <= a < 2n.
+__device__ __forceinline__ int pb_floor_mod(long long a, int n) {
+    if (a >= 0 && a < n) return (int)a;
+    if (a >= n && a < 2ll * n) return (int)(a - n);
+    long long r = a % (long long)n;
+    return (int)((r < 0) ? r + n : r);
+}
+
+// ---- a-1 lens functions (array semantics of core/lens.py) --------------------
+__device__ __forceinline__ double pb_lens_forward(int lens, double theta, double rect_max) {
+    switch (lens) {
+        case PB_LENS_EQUIDISTANT: return theta;                          // lens.py:187
+        case PB_LENS_EQUISOLID: return 2.0 * sin(theta / 2.0);           // lens.py:240-243
+        case PB_LENS_STEREOGRAPHIC: return 2.0 * tan(theta / 2.0);       // lens.py:142-145
+        case PB_LENS_ORTHOGRAPHIC: return sin(theta);                    // lens.py:285
+        case PB_LENS_THOBY: return 1.47 * sin(0.713 * theta);            // lens.py:332-335
+        default: {                                                       // lens.py:97-103
+            double t = tan(theta);
+            return (theta < 0.0 || theta > rect_max) ? __builtin_nan("") : t;
+        }
+    }
+}
+__device__ __forceinline__ double pb_lens_inverse(int lens, double r) {
+    switch (lens) {
+        case PB_LENS_EQUIDISTANT: return r;                              // lens.py:165
+        case PB_LENS_EQUISOLID: {                                        // lens.py:206-220
+            double t = 2.0 * asin(r / 2.0);
+            return (t != t) ? 0.0 : t;
+        }
+        case PB_LENS_STEREOGRAPHIC: return 2.0 * atan(r / 2.0);          // lens.py:121-124
+        case PB_LENS_ORTHOGRAPHIC: return asin(r);                       // lens.py:261
+        case PB_LENS_THOBY: return asin(r / 1.47) / 0.713;               // lens.py:305
+        default: return atan(r);                                         // lens.py:71
+    }
+}
+
+// atan2 as np.log(complex).imag gives it (glibc atan2).  The octant
+// lines |x| == |y| and the axes must come out correctly rounded because there the
+// pre-truncation longitude coordinate of a pano source is an exact integer
+// (SURVEY 7 hard part 2); the device libm is used elsewhere.
+__device__ __forceinline__ double pb_atan2(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    if (ax == ay && ax != 0.0 && ax < __builtin_inf()) {
+        const double q = 0.7853981633974483;   // pi/4 rounded
+        const double q3 = 2.356194490192345;   // 3*pi/4 rounded
+        double r = (x > 0.0) ? q : q3;
+        return (y < 0.0) ? -r : r;
+    }
+    return atan2(y, x);
+}
+
+// ---- stage A ---------------------------------------------------------------------
+__device__ __forceinline__ PbCoord pb_dst_coord(const PbParams& P, int i, int j) {
+    PbCoord c;
+    const PbEnd& d = P.dst;
+    if (d.kind == PB_KIND_PANO) {
+        // linspace: k * step + start (two roundings), last sample = stop
+        c.lat = (i == d.height - 1 && d.height > 1) ? PB_PI : ((double)i * P.pano_lat_step + 0.0);
+        c.lon = (j == d.width - 1 && d.width > 1) ? P.pano_lon_stop : ((double)j * P.pano_lon_step + P.pano_lon_start);
+        c.inv = false;
+        return c;
+    }
+    double x, y;
+    y = P.dst_y0 - (double)i;  // exact: i * (-1.0) + (H/2 - 0.5)
+    bool right = false;
+    if (d.kind == PB_KIND_DOUBLE) {
+        right = j >= P.dst_half_w;
+        const int jj = right ? j - P.dst_half_w : j;
+        x = (double)jj + P.dst_x0;
+        if (right) x = -x;  // projection.py:394
+    } else {
+        x = (double)j + P.dst_x0;
+    }
+    const double dist = sqrt(x * x + y * y) / d.f_distance;  // projection.py:186, :375
+    double lat = pb_lens_inverse(d.lens, dist);
+    if (d.kind == PB_KIND_DOUBLE && right) {
+        lat = (lat * -1.0) + PB_PI;           // projection.py:381-382
+        c.inv = lat < P.dst_right_min;        // projection.py:358-360
+    } else {
+        c.inv = lat > P.dst_half_fov;         // projection.py:160, :357
+    }
+    c.lat = lat;
+    c.lon = pb_atan2(y, x);                  // projection.py:193, :383
+    return c;
+}
+
+// ---- stage B ---------------------------------------------------------------------
+__device__ __forceinline__ PbCoord pb_rotate(const double* __restrict__ R, PbCoord c) {
+    if (c.inv) {  // rotation.py:125, :168-175
+        c.lat = 0.0;
+        c.lon = 0.0;
+        return c;
+    }
+    const double yy = cos(c.lat);
+    const double s = sin(c.lat);
+    double sl, cl;
+    sincos(c.lon, &sl, &cl);
+    const double x = cl * s, z = sl * s;  // rotation.py:130-132
+    // accumulation order of the BLAS behind np.matmul (probe)
+    const double vx = fma(R[2], z, fma(R[0], x, R[1] * yy));
+    const double vy = fma(R[5], z, fma(R[3], x, R[4] * yy));
+    const double vz = fma(R[8], z, fma(R[6], x, R[7] * yy));
+    c.lat = acos(vy);         // rotation.py:158
+    c.lon = pb_atan2(vz, vx); // rotation.py:159-164
+    return c;
+}
+
+// ---- stage C ---------------------------------------------------------------------
+// pano source: linear index or -1   (projection.py:533-546)
+__device__ __forceinline__ int pb_src_pano_index(const PbParams& P, const PbCoord& c) {
+    if (c.inv) return -1;
+    const double tr = c.lat / P.src_hseg;
+    const double tc = c.lon / P.src_wseg + P.src_half_w;
+    const int r = pb_floor_mod(pb_cvt_i64(tr), P.src.height);
+    const int col = pb_floor_mod(pb_cvt_i64(tc), P.src.width);
+    return r * P.src.width + col;
+}
+
+// one fisheye of size h x w centred at (cy, cx): (py, px) or ok == false
+// (projection.py:247-260, :223-231)
+__device__ __forceinline__ bool pb_src_camera_pos(const PbParams& P, double lat, double lon, int h, int w, double cy,
+                                                  double cx, int& py, int& px) {
+    const double dist = pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
+    double sl, cl;
+    sincos(lon, &sl, &cl);
+    const double re = cl * dist, im = sl * dist;
+    const long long y = pb_cvt_i64((im * -1.0) + cy);
+    const long long x = pb_cvt_i64(re + cx);
+    if (y >= h || y < 0 || x >= w || x < 0) return false;
+    py = (int)y;
+    px = (int)x;
+    return true;
+}
+
+__device__ __forceinline__ int pb_src_camera_index(const PbParams& P, const PbCoord& c) {
+    int py, px;
+    const bool ok = pb_src_camera_pos(P, c.lat, c.lon, P.src.height, P.src.width, P.src_cy, P.src_cx, py, px);
+    return (ok && !c.inv) ? py * P.src.width + px : -1;
+}
+
+struct PbDoubleTap {
+    int il, ir;     // indices into the full side-by-side frame, or -1
+    double fl, fr;  // blend factors
+};
+
+__device__ __forceinline__ double pb_merge_factor(const PbParams& P, double lat) {
+    const bool band = (lat >= P.mrg_min) && (lat <= P.mrg_max_safe);  // projection.py:440-443
+    const double f = (lat - P.mrg_max) / P.mrg_range * -1.0;         // projection.py:444
+    return band ? f : 1.0;
+}
+
+__device__ __forceinline__ PbDoubleTap pb_src_double_taps(const PbParams& P, const PbCoord& c) {
+    PbDoubleTap t;
+    const double lat_r = (c.lat * -1.0) + PB_PI;  // projection.py:426-427
+    int py, px;
+    bool ok = pb_src_camera_pos(P, c.lat, c.lon, P.src.height, P.src_eye_w, P.src_cy, P.src_cx, py, px);
+    t.il = (ok && !c.inv) ? py * P.src.width + px : -1;
+    ok = pb_src_camera_pos(P, lat_r, c.lon, P.src.height, P.src_eye_w_right, P.src_cy, P.src_cx_r, py, px);
+    // the right eye is mirrored before it is sampled (projection.py:430-431)
+    t.ir = (ok && !c.inv) ? py * P.src.width + (P.src_eye_w + (P.src_eye_w_right - 1 - px)) : -1;
+    t.fl = pb_merge_factor(P, c.lat);
+    t.fr = pb_merge_factor(P, lat_r);
+    return t;
+}
+
+// (left * fl + right * fr).astype(uint8)   projection.py:447-459
+__device__ __forceinline__ unsigned pb_blend_u8(unsigned l, unsigned r, double fl, double fr) {
+    return pb_cvt_u8((double)l * fl + (double)r * fr);
+}

@@ -1,0 +1,116 @@
+"""The parity case matrix shared by the golden generator (oracle/make_goldens.py),
+the oracle-vs-golden tests and the HIP-vs-oracle tests.
+
+A case = destination projection, optional rotations (degrees, as the CLI's
+``-r pitch yaw roll``), source projection, and which synthetic frame feeds it.
+Projections are written as (kind, height, width, lens, fov_degrees, magnitude).
+``magnitude`` None means the class default (height / 2).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+P = Tuple[str, int, int, str, float, Optional[float]]
+
+
+@dataclass
+class Case:
+    name: str
+    dst: P
+    src: P
+    rotations: List[Tuple[float, float, float]] = field(default_factory=list)
+    mask: int = 0  # synthetic-frame circle mask (0 none, 1 single, 2 double)
+    keep_map: bool = False  # also pin the float64 coordinate map(s)
+
+
+def cam(h, w, lens, fov, magnitude=None) -> P:
+    return ("camera", h, w, lens, float(fov), magnitude)
+
+
+def dbl(h, w, lens, fov) -> P:
+    return ("double", h, w, lens, float(fov), None)
+
+
+def pano(h, w) -> P:
+    return ("pano", h, w, "equidistant", 0.0, None)
+
+
+def inscribed(n):  # CLI rule commands/__init__.py:98-99
+    return n / 2 - 0.5
+
+
+def full_frame(h, w):  # commands/__init__.py:102-105
+    return math.sqrt((w / 2.0 - 0.5) ** 2 + (h / 2.0 - 0.5) ** 2)
+
+
+LENS_FOVS = {
+    "equidistant": (140, 180, 195, 360),
+    "equisolid": (140, 180, 360),
+    "stereographic": (140, 180, 360),  # 360 degenerates (f_distance ~ 1e-15)
+    "orthographic": (140, 180, 360),  # 360 degenerates (f_distance ~ 2.6e17)
+    "rectilinear": (100, 140),  # > 178 raises at construction
+    "thoby": (140, 180),
+}
+
+
+def small_cases() -> List[Case]:
+    cs: List[Case] = []
+    # A. pano source <- fisheye destination (make-photo), every lens x fov
+    for lens, fovs in LENS_FOVS.items():
+        for fov in fovs:
+            cs.append(
+                Case(f"A_photo_{lens}_{fov}", cam(48, 48, lens, fov, inscribed(48)), pano(64, 128), keep_map=(fov == fovs[0]))
+            )
+    # odd / non-square / default magnitude / full-frame magnitude
+    cs.append(Case("A_photo_odd", cam(33, 35, "equidistant", 180), pano(50, 100), keep_map=True))
+    cs.append(Case("A_photo_full", cam(32, 48, "rectilinear", 120, full_frame(32, 48)), pano(64, 128)))
+    cs.append(Case("A_photo_pano1000", cam(40, 40, "equidistant", 360, inscribed(40)), pano(1000, 2000)))
+    # B. fisheye source <- pano destination (make-pano)
+    for lens, fovs in LENS_FOVS.items():
+        for fov in fovs:
+            cs.append(Case(f"B_pano_{lens}_{fov}", pano(40, 80), cam(48, 48, lens, fov, inscribed(48)), mask=1, keep_map=(lens == "equidistant" and fov == 140)))
+    cs.append(Case("B_pano_odd", pano(31, 63), cam(33, 35, "equisolid", 190), keep_map=True))
+    # C. fisheye <- fisheye (alter-photo), with and without rotation
+    cs.append(Case("C_alter_eqd_eqs_rot", cam(48, 48, "equisolid", 360, inscribed(48)), cam(48, 48, "equidistant", 360, inscribed(48)), [(30, 45, 10)], keep_map=True))
+    cs.append(Case("C_alter_ste_ort", cam(40, 40, "orthographic", 170, inscribed(40)), cam(44, 44, "stereographic", 200, inscribed(44)), [(-15, 100, 200)]))
+    cs.append(Case("C_alter_rect_thoby", cam(36, 54, "thoby", 160), cam(40, 60, "rectilinear", 150, full_frame(40, 60)), [(5, -20, 33)]))
+    cs.append(Case("C_alter_norot", cam(40, 40, "equisolid", 180, inscribed(40)), cam(56, 56, "equidistant", 200, inscribed(56))))
+    # D. rotations on the pano paths, docs/scripts.md angle triples, a chain
+    cs.append(Case("D_photo_rot", cam(48, 48, "equidistant", 360, inscribed(48)), pano(64, 128), [(30, 45, 10)], keep_map=True))
+    cs.append(Case("D_photo_rot_m90", cam(48, 48, "equidistant", 180, inscribed(48)), pano(64, 128), [(-90, 0, 0)]))
+    cs.append(Case("D_photo_rot_m90_195", cam(48, 48, "equisolid", 180, inscribed(48)), pano(64, 128), [(-90, 0, 195)]))
+    cs.append(Case("D_pano_rot_m90_90", pano(40, 80), cam(48, 48, "equidistant", 360, inscribed(48)), [(-90, 0, 90)]))
+    cs.append(Case("D_pano_chain", pano(40, 80), cam(48, 48, "equidistant", 360, inscribed(48)), [(10, 20, 30), (-40, 5, 77)], keep_map=True))
+    cs.append(Case("D_pano_pano_rot", pano(32, 64), pano(48, 96), [(12, 34, 56)]))
+    cs.append(Case("D_pano_pano_identity", pano(32, 64), pano(32, 64)))
+    # E. double fisheye as source (Gear-360 stitch) and as destination
+    for fov in (180, 195, 220):
+        cs.append(Case(f"E_stitch_{fov}_masked", pano(32, 64), dbl(40, 80, "equidistant", fov), mask=2))
+        cs.append(Case(f"E_stitch_{fov}_raw", pano(32, 64), dbl(40, 80, "equidistant", fov)))
+    cs.append(Case("E_stitch_eqs_rot", pano(33, 66), dbl(40, 80, "equisolid", 200), [(3, 90, -7)], mask=2))
+    cs.append(Case("E_double_dst", dbl(32, 64, "equidistant", 195), pano(48, 96), keep_map=True))
+    cs.append(Case("E_double_dst_rot", dbl(32, 64, "equisolid", 190), cam(48, 48, "equidistant", 360, inscribed(48)), [(20, 30, 40)]))
+    cs.append(Case("E_double_double", dbl(32, 64, "equidistant", 200), dbl(40, 80, "equidistant", 190), [(0, 15, 0)]))
+    return cs
+
+
+def full_cases() -> List[Case]:
+    """BASELINE.json configs restated as API calls.  c4 = c2 x 512
+    frames; c5 is additionally pinned at sensor fov 195 (docs/scripts.md:51)."""
+    return [
+        Case("c1", pano(2048, 4096), cam(3072, 3072, "equidistant", 360, inscribed(3072)), mask=1),
+        Case("c2", cam(4096, 4096, "equidistant", 360, inscribed(4096)), pano(4096, 8192)),
+        Case("c3", cam(4096, 4096, "equisolid", 360, inscribed(4096)), cam(4096, 4096, "equidistant", 360, inscribed(4096)), [(30, 45, 10)]),
+        Case("c5_180", pano(4096, 8192), dbl(3888, 7776, "equidistant", 180), mask=2),
+        Case("c5_195", pano(4096, 8192), dbl(3888, 7776, "equidistant", 195), mask=2),
+    ]
+
+
+def case_by_name(name: str) -> Case:
+    for c in small_cases() + full_cases():
+        if c.name == name:
+            return c
+    raise KeyError(name)

@@ -1,0 +1,77 @@
+"""Shared helpers: build oracle / product objects from the case tuples."""
+
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from oracle import reference_path as orc
+from oracle.synth import synth_frame
+from tests.cases import Case
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def load_small():
+    return np.load(os.path.join(GOLD, "small.npz"))
+
+
+def load_full():
+    with open(os.path.join(GOLD, "full.json")) as f:
+        return json.load(f)
+
+
+def orc_proj(p) -> orc.Proj:
+    kind, h, w, lens, fov, mag = p
+    if kind == "pano":
+        return orc.Proj("pano", h, w)
+    return orc.Proj(kind, h, w, lens, orc.to_radians(fov), mag)
+
+
+def orc_rots(case: Case):
+    return [tuple(map(orc.to_radians, r)) for r in case.rotations]
+
+
+def case_frame(case: Case, frame: int = 0) -> np.ndarray:
+    _, h, w, *_ = case.src
+    return synth_frame(h, w, frame=frame, seed=0, circle_mask=case.mask)
+
+
+def pb_obj(p, image=None):
+    """The product-side object for a case tuple (import deferred: needs torch)."""
+    import photonbend_amd as pb
+
+    kind, h, w, lens, fov, mag = p
+    if image is None:
+        image = np.zeros((h, w, 3), np.uint8)
+    if kind == "pano":
+        return pb.PanoramaImage(image)
+    L = getattr(pb, lens)()
+    if kind == "camera":
+        return pb.CameraImage(image, pb.utils.to_radians(fov), L, magnitude=mag)
+    return pb.DoubleCameraImage(image, pb.utils.to_radians(fov), L)
+
+
+def pb_chain(case: Case, image=None):
+    """dst.get_coordinate_map() -> rotations -> (src object, lazy map)."""
+    import photonbend_amd as pb
+
+    dst = pb_obj(case.dst)
+    cmap = dst.get_coordinate_map()
+    for rot in case.rotations:
+        cmap = pb.Rotation(*map(pb.utils.to_radians, rot)).rotate_coordinate_map(cmap)
+    src = pb_obj(case.src, image if image is not None else case_frame(case))
+    return src, cmap
+
+
+def pb_plan(case: Case):
+    from photonbend_amd.core.projection import _plan_for
+
+    src, cmap = pb_chain(case, image=np.zeros((case.src[1], case.src[2], 3), np.uint8))
+    return _plan_for(cmap.dst_proj, cmap.rotations, src._proj())

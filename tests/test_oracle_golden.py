@@ -1,0 +1,102 @@
+"""The oracle (oracle/reference_path.py) against fixtures captured from the real
+reference (oracle/make_goldens.py).  Bit-for-bit: this is what pins parity."""
+
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import reference_path as orc
+from oracle.synth import synth_frame
+from tests import helpers as H
+from tests.cases import full_cases, small_cases
+
+SMALL = H.load_small()
+FULL = H.load_full()
+
+
+def test_lens_grid_bits():
+    g = np.load(H.GOLD + "/lens.npz")
+    grid = g["grid"].view(np.float64)
+    with np.errstate(all="ignore"):
+        for name in orc.LENSES:
+            fwd = orc.lens_forward(name, np.copy(grid))
+            inv = orc.lens_inverse(name, np.copy(grid))
+            assert np.array_equal(H.bits(fwd), g[f"{name}_fwd"]), name
+            assert np.array_equal(H.bits(inv), g[f"{name}_inv"]), name
+
+
+@pytest.mark.parametrize("case", small_cases(), ids=lambda c: c.name)
+def test_small_case_bits(case):
+    n = case.name
+    od, os_ = H.orc_proj(case.dst), H.orc_proj(case.src)
+    rots = H.orc_rots(case)
+    if f"{n}/dst_f" in SMALL:
+        assert H.bits(np.array([od.f_distance]))[0] == SMALL[f"{n}/dst_f"][0]
+    if f"{n}/src_f" in SMALL:
+        assert H.bits(np.array([os_.f_distance]))[0] == SMALL[f"{n}/src_f"][0]
+    if rots:
+        R = np.stack([orc.rotation_matrix(*r) for r in rots])
+        assert np.array_equal(H.bits(R), SMALL[f"{n}/R"])
+    idx = orc.remap_index(od, os_, rots)
+    if case.src[0] == "double":
+        assert np.array_equal(idx[0], SMALL[f"{n}/idx_l"])
+        assert np.array_equal(idx[1], SMALL[f"{n}/idx_r"])
+    else:
+        assert np.array_equal(idx, SMALL[f"{n}/idx"])
+    out = orc.remap(od, os_, H.case_frame(case), rots)
+    assert out.dtype == np.uint8 and np.array_equal(out, SMALL[f"{n}/u8"])
+    if case.keep_map:
+        cmap = orc.coordinate_map(od)
+        assert np.array_equal(H.bits(cmap), SMALL[f"{n}/map0"])
+        for k, r in enumerate(rots):
+            cmap = orc.rotate_map(orc.rotation_matrix(*r), cmap)
+            assert np.array_equal(H.bits(cmap), SMALL[f"{n}/map{k + 1}"])
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _check_full(case):
+    pin = FULL[case.name]
+    od, os_ = H.orc_proj(case.dst), H.orc_proj(case.src)
+    rots = H.orc_rots(case)
+    frame = H.case_frame(case)
+    assert _sha(frame) == pin["frame_sha256"]
+    out = orc.remap(od, os_, frame, rots)
+    assert _sha(out) == pin["u8_sha256"]
+    idx = orc.remap_index(od, os_, rots)
+    if case.src[0] == "double":
+        assert _sha(idx[0]) == pin["idx_l_sha256"] and _sha(idx[1]) == pin["idx_r_sha256"]
+    else:
+        assert _sha(idx) == pin["idx_sha256"]
+        assert int((idx >= 0).sum()) == pin["in_bounds_samples"]
+
+
+def test_full_c2_pins():
+    """The headline config at full size (about 15 s of NumPy)."""
+    _check_full([c for c in full_cases() if c.name == "c2"][0])
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("case", [c for c in full_cases() if c.name != "c2"], ids=lambda c: c.name)
+def test_full_other_pins(case):
+    _check_full(case)
+
+
+def test_synth_formula_spot_values():
+    """The synthetic frame formula restated with Python ints."""
+    img = synth_frame(5, 7, frame=3, seed=9)
+
+    def mix(h):
+        h ^= h >> 16
+        h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+        h ^= h >> 13
+        h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+        h ^= h >> 16
+        return h
+
+    for r, c, ch in [(0, 0, 0), (4, 6, 2), (2, 3, 1)]:
+        key = ((3 * 0x9E3779B1) ^ (r * 0x85EBCA6B) ^ (c * 0xC2B2AE35) ^ (ch * 0x27D4EB2F) ^ 9) & 0xFFFFFFFF
+        assert img[r, c, ch] == mix(key) & 0xFF
