@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py - Mpixels/s of the fused remap on BASELINE.json's headline config.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one frame of config c2: an 8192x4096
+equirectangular panorama remapped to a 4096x4096 equidistant-360 inscribed
+fisheye (16.78 Mpx out).  Every rank owns a pool of distinct synthetic frames
+resident in HBM and cycles through them, so the timed launches stream from HBM
+rather than re-reading one frame out of the 256 MiB Infinity Cache.  Ranks are
+independent (frames shard, nothing pixel-sized crosses xGMI); the only
+collective is the RCCL broadcast of the ~200-byte parameter block from rank 0 and
+the barriers / max-reduce that bracket the timed region.  Rank 0 prints ONE JSON
+line.  `roofline` prices the remap kernel's ALGORITHMIC bytes (3 B written per
+output pixel + 3 B read per in-bounds source sample = 89 842 104 B per c2 frame,
+SURVEY 8d) against the 8 TB/s HBM3E peak, using per-launch HIP-event durations
+taken on the launch stream inside the timed region.  `cpu_baseline` times the
+NumPy oracle (the pinned restatement of the reference path) on this host.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import photonbend_amd as pb  # noqa: E402
+from photonbend_amd import _native as nat  # noqa: E402
+from photonbend_amd import parallel  # noqa: E402
+
+DST = 4096
+SRC_H, SRC_W = 4096, 8192
+MPX_PER_FRAME = DST * DST / 1e6
+ALGORITHMIC_BYTES = 89_842_104  # tests/golden/full.json c2.algorithmic_bytes (from the reference's own index map)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def c2_objects():
+    fov = pb.utils.to_radians(360)
+    dst = pb.CameraImage(np.zeros((DST, DST, 3), np.uint8), fov, pb.equidistant(), magnitude=DST / 2 - 0.5)
+    src = pb.PanoramaImage(np.zeros((1, 1, 3), np.uint8))
+    src_proj = nat.make_proj(nat.KIND_PANO, SRC_H, SRC_W)
+    return dst._proj(), src_proj
+
+
+def cpu_baseline(frames: int = 2):
+    """The oracle (kind 'port') on this host's cores: `frames` full c2 frames."""
+    from oracle import reference_path as orc  # CPU baseline leg only
+    from oracle.synth import synth_frame
+
+    fov = orc.to_radians(360)
+    d = orc.Proj("camera", DST, DST, "equidistant", fov, DST / 2 - 0.5)
+    s = orc.Proj("pano", SRC_H, SRC_W)
+    imgs = [synth_frame(SRC_H, SRC_W, frame=f) for f in range(frames)]
+    t0 = time.perf_counter()
+    for img in imgs:
+        out = orc.remap(d, s, img)
+    dt = time.perf_counter() - t0
+    assert out.shape == (DST, DST, 3)
+    return {
+        "value": round(frames * MPX_PER_FRAME / dt, 3),
+        "unit": "Mpx/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{frames} full c2 frames (8192x4096 -> 4096x4096) through oracle/reference_path.py, {dt:.1f} s; host has {os.cpu_count()} logical cores, NumPy runs this path on 1",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pool", type=int, default=6, help="distinct frames resident per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    # rank 0 owns the parameters; everyone else receives the block over RCCL
+    block = None
+    if rank == 0:
+        d, s = c2_objects()
+        block = parallel.pack_params(d, [], s)
+    block = parallel.broadcast_params(block, device=device, src=0)
+    d, rots, s = parallel.unpack_params(block)
+    plan = nat.Plan(d, rots, s)
+
+    # per-rank frame pool, generated on the device (frame ids disjoint across ranks)
+    pool = max(1, args.pool)
+    srcs = [nat.synth_frame(SRC_H, SRC_W, frame=rank * pool + f, seed=0, device=device) for f in range(pool)]
+    dsts = [torch.empty((DST, DST, 3), dtype=torch.uint8, device=device) for _ in range(pool)]
+    lib = nat.load()
+    stream = torch.cuda.Stream(device=device)
+    st = int(stream.cuda_stream)
+    sp = [t.data_ptr() for t in srcs]
+    dp = [t.data_ptr() for t in dsts]
+    h = plan.handle
+
+    def step(k):
+        i = k % pool
+        rc = lib.pb_remap_u8(h, sp[i], dp[i], 1, 0, 0, st)
+        if rc:
+            nat.check(rc)
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for k in range(args.warmup):
+        step(k)
+    K = args.steps
+    use_events = not args.no_events
+    ev = []
+    if use_events:
+        for _ in range(2 * K):
+            e = ctypes.c_void_p()
+            nat.check(lib.pb_event_create(ctypes.byref(e)))
+            ev.append(e)
+    sync_all()
+    t0 = time.perf_counter()
+    if use_events:
+        for k in range(K):
+            lib.pb_event_record(ev[2 * k], st)
+            step(k)
+            lib.pb_event_record(ev[2 * k + 1], st)
+    else:
+        for k in range(K):
+            step(k)
+    sync_all()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    kern_ms = None
+    if use_events:
+        ms = ctypes.c_float()
+        durs = []
+        for k in range(K):
+            nat.check(lib.pb_event_elapsed_ms(ev[2 * k], ev[2 * k + 1], ctypes.byref(ms)))
+            durs.append(ms.value)
+        for e in ev:
+            lib.pb_event_destroy(e)
+        kern_ms = float(np.mean(durs))
+        kern_med = float(np.median(durs))
+
+    if rank == 0:
+        value = world * K * MPX_PER_FRAME / dt_max
+        per_launch_s = (kern_ms / 1e3) if kern_ms else dt_max / K
+        achieved = ALGORITHMIC_BYTES / per_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mpixels/s remapped, 8K equirect->equidistant",
+            "value": round(value, 1),
+            "unit": "Mpx/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt_max / K * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "c2: one 8192x4096 equirectangular frame -> 4096x4096 equidistant-360 inscribed per step",
+                "frames_resident_per_gpu": pool,
+                "sampling": "nearest (truncating), the reference's",
+                "parallelism": f"frames sharded over {world} GPU(s); RCCL broadcast of the parameter block only",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES,
+                "kernel_ms_mean": round(kern_ms, 5) if kern_ms else None,
+                "kernel_ms_median": round(kern_med, 5) if kern_ms else None,
+                "timing": "per-launch hipEvent pairs on the launch stream" if use_events else "wall / steps",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,8 +96,12 @@ def test_materialised_maps_within_ulps(case):
             g, w = got[..., ch], want[..., ch]
             both_nan = np.isnan(g) & np.isnan(w)
             d = ulp_diff(np.where(both_nan, 0.0, g), np.where(both_nan, 0.0, w))
-            # near zero an absolute bound replaces the ulp bound (cos/acos cancellation)
-            ok = (d <= MAP_ULPS) | (np.abs(g - w) <= 1e-15)
+            # near zero an absolute bound replaces the ulp bound; after a rotation
+            # lat = acos(v_y) is ill-conditioned near the poles: a 1-ulp change of
+            # v_y moves lat by 2^-53 / sin(lat)
+            with np.errstate(all="ignore"):
+                cond = 4 * 2.0**-52 / np.maximum(np.abs(np.sin(w)), 1e-9) if (k > 0 and ch == 0) else 0.0
+                ok = (d <= MAP_ULPS) | (np.abs(g - w) <= np.maximum(1e-15, cond))
             assert ok.all(), f"stage {k} {name}: max {d.max()} ulp"
 
 
