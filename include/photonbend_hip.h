@@ -88,9 +88,25 @@ int pb_device_name(char* buf, size_t buflen);
 
 /* ---- the fused hot path ------------------------------------------------ */
 /* rot3x3: n_rot row-major 3x3 float64 matrices = Rotation.rotation_matrix
- * (core/rotation.py:100), applied in order; n_rot in [0, PB_MAX_ROTATIONS]. */
+ * (core/rotation.py:100), applied in order; n_rot in [0, PB_MAX_ROTATIONS].
+ * When a HIP device is visible, creation runs two short kernels on the current device
+ * (synchronously): the destination-validity thresholds and the fast-path certification. */
 int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, pb_plan** out);
 void pb_plan_destroy(pb_plan* plan);
+/* Execution mode of a plan.  AUTO (default): per-tile polynomial fast path when the plan was
+ * certified at creation (its integer index map equals the faithful path's for every pixel),
+ * else the faithful per-pixel float64 path.  FAITHFUL / FAST force one of them (tests). */
+#define PB_MODE_AUTO 0
+#define PB_MODE_FAITHFUL 1
+#define PB_MODE_FAST 2
+int pb_plan_set_mode(pb_plan* plan, int mode);
+/* fast_path_enabled: 0/1 under the current mode; certify_mismatches: pixels whose fast-path
+ * index differed from the faithful one at creation (0 = certified, -1 = no device at creation);
+ * thresholds4: {invalid_lo, invalid_hi} on (2x)^2+(2y)^2 for the left/single and the right eye
+ * of the destination; tile_stats3: {32x32 tiles, tiles whose polynomial model was accepted, pixels
+ * that went through the faithful chain} in the certification run (-1 = none).  Any pointer may be NULL. */
+int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* certify_mismatches, long long* thresholds4,
+                 long long* tile_stats3);
 int pb_plan_dst_shape(const pb_plan* plan, int* height, int* width);
 int pb_plan_src_shape(const pb_plan* plan, int* height, int* width);
 

@@ -19,6 +19,7 @@ import torch  # noqa: F401  (must precede the CDLL below - see module docstring)
 from .build import LIB_PATH
 
 PB_MAX_ROTATIONS = 8
+MODE_AUTO, MODE_FAITHFUL, MODE_FAST = 0, 1, 2
 KIND_CAMERA, KIND_DOUBLE, KIND_PANO = 0, 1, 2
 LENS_IDS = {
     "equidistant": 0,
@@ -59,6 +60,8 @@ SIGNATURES = {
     "pb_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
     "pb_plan_create": (C.c_int, [C.POINTER(pb_proj), C.POINTER(C.c_double), C.c_int, C.POINTER(pb_proj), C.POINTER(_VP)]),
     "pb_plan_destroy": (None, [_VP]),
+    "pb_plan_set_mode": (C.c_int, [_VP, C.c_int]),
+    "pb_plan_info": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "pb_plan_dst_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_plan_src_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_remap_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
@@ -142,6 +145,24 @@ class Plan:
     @property
     def handle(self):
         return self._h
+
+    def set_mode(self, mode: int) -> None:
+        """MODE_AUTO (certified fast tiles, else faithful), MODE_FAITHFUL, MODE_FAST."""
+        check(load().pb_plan_set_mode(self._h, int(mode)))
+
+    def info(self) -> dict:
+        fast, bad = C.c_int(), C.c_longlong()
+        thr = (C.c_longlong * 4)()
+        st = (C.c_longlong * 3)()
+        check(load().pb_plan_info(self._h, C.byref(fast), C.byref(bad), thr, st))
+        return {
+            "fast_path": bool(fast.value),
+            "certify_mismatches": int(bad.value),
+            "thresholds": [int(t) for t in thr],
+            "tiles": int(st[0]),
+            "modelled_tiles": int(st[1]),
+            "exact_pixels": int(st[2]),
+        }
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

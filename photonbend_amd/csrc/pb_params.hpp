@@ -39,6 +39,15 @@ struct PbParams {
     int32_t src_eye_w;                      // width of one eye (w // 2)  projection.py:413
     int32_t src_eye_w_right;                // w - w // 2
     double rect_max;                        // to_radians(89)  lens.py:91,98
+    // destination validity as integer thresholds on n4 = (2x)^2 + (2y)^2, found at plan
+    // creation by bisection with the exact predicate (pb_threshold_kernel):
+    // invalid  <=>  inv_lo[side] <= n4 < inv_hi[side]   (side 0 = left / single, 1 = right eye)
+    int64_t inv_lo[2], inv_hi[2];
+    // fixed point used by the tile fast path: coordinate * 2^fx_shift fits an int32
+    double fx_scale;
+    int32_t fx_shift, fx_mask;
+    int32_t thresholds_ready;               // 0: kernels must evaluate the predicate per pixel
+    int32_t fast_tiles;                     // 1: per-tile polynomial models allowed (certified plan)
     double mrg_min, mrg_max, mrg_range, mrg_max_safe;  // projection.py:414-418
 };
 
@@ -100,4 +109,14 @@ static inline void pb_derive(PbParams& P) {
         P.mrg_max_safe = P.mrg_max + (0.5 / 180 * pi);
     }
     P.rect_max = 89.0 / 180 * pi;
+    {
+        int maxdim = P.src.height > P.src.width ? P.src.height : P.src.width;
+        int bits = 1;
+        while ((1ll << bits) < (long long)maxdim + 1) ++bits;  // 2^bits >= maxdim + 1
+        int shift = 30 - bits;                                  // coordinate < 2 * maxdim stays below 2^31
+        if (shift > 20) shift = 20;
+        P.fx_shift = shift;
+        P.fx_mask = (1 << shift) - 1;
+        P.fx_scale = (double)(1ll << shift);
+    }
 }

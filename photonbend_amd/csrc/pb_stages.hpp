@@ -121,6 +121,78 @@ __device__ __forceinline__ PbCoord pb_dst_coord(const PbParams& P, int i, int j)
     return c;
 }
 
+
+// ---- smooth continuation of stages A..C at REAL pixel positions -------------------
+// Used only to build per-tile polynomial models (pb_tile.hpp): same formulas, but the
+// pixel position is a real number, the invalid flag is ignored and the linspace
+// "last sample = stop" override is dropped (a 1-ulp kink that a model accurate to
+// 1e-7 px cannot see).  Never used to produce an output value directly.
+__device__ __forceinline__ PbCoord pb_dst_coord_real(const PbParams& P, double fi, double fj) {
+    PbCoord c;
+    const PbEnd& d = P.dst;
+    c.inv = false;
+    if (d.kind == PB_KIND_PANO) {
+        c.lat = fi * P.pano_lat_step;
+        c.lon = fj * P.pano_lon_step + P.pano_lon_start;
+        return c;
+    }
+    double x;
+    const double y = P.dst_y0 - fi;
+    bool right = false;
+    if (d.kind == PB_KIND_DOUBLE) {
+        right = fj >= (double)P.dst_half_w;
+        x = (right ? fj - (double)P.dst_half_w : fj) + P.dst_x0;
+        if (right) x = -x;
+    } else {
+        x = fj + P.dst_x0;
+    }
+    const double dist = sqrt(x * x + y * y) / d.f_distance;
+    double lat = pb_lens_inverse(d.lens, dist);
+    if (right) lat = (lat * -1.0) + PB_PI;
+    c.lat = lat;
+    c.lon = atan2(y, x);
+    return c;
+}
+
+// pre-truncation source coordinates (row-like, column-like) of a pano / camera source
+template <int SRC_KIND>
+__device__ __forceinline__ void pb_src_pretrunc(const PbParams& P, const PbCoord& c, double& f0, double& f1) {
+    if (SRC_KIND == PB_KIND_PANO) {
+        f0 = c.lat / P.src_hseg;
+        f1 = c.lon / P.src_wseg + P.src_half_w;
+    } else {
+        const double dist = pb_lens_forward(P.src.lens, c.lat, P.rect_max) * P.src.f_distance;
+        double sl, cl;
+        sincos(c.lon, &sl, &cl);
+        f0 = ((sl * dist) * -1.0) + P.src_cy;
+        f1 = (cl * dist) + P.src_cx;
+    }
+}
+
+// exact invalid predicate of a camera / double destination pixel as a function of the
+// integer n4 = (2x)^2 + (2y)^2 (x*x + y*y == n4 / 4 exactly), projection.py:160, :357-360
+__device__ __forceinline__ bool pb_dst_inv_pred(const PbParams& P, long long n4, bool right, bool* outside_domain) {
+    const double dist = sqrt((double)n4 * 0.25) / P.dst.f_distance;
+    double lat;
+    bool nan_region = false;
+    switch (P.dst.lens) {
+        case PB_LENS_EQUISOLID: {
+            const double t = 2.0 * asin(dist / 2.0);
+            nan_region = (t != t);
+            lat = nan_region ? 0.0 : t;
+        } break;
+        case PB_LENS_ORTHOGRAPHIC: lat = asin(dist); nan_region = (lat != lat); break;
+        case PB_LENS_THOBY: lat = asin(dist / 1.47) / 0.713; nan_region = (lat != lat); break;
+        default: lat = pb_lens_inverse(P.dst.lens, dist);
+    }
+    if (outside_domain) *outside_domain = nan_region;
+    if (right) {
+        lat = (lat * -1.0) + PB_PI;
+        return lat < P.dst_right_min;
+    }
+    return lat > P.dst_half_fov;
+}
+
 // ---- stage B ---------------------------------------------------------------------
 __device__ __forceinline__ PbCoord pb_rotate(const double* __restrict__ R, PbCoord c) {
     if (c.inv) {  // rotation.py:125, :168-175

@@ -15,12 +15,17 @@
 
 #include "pb_params.hpp"
 #include "pb_stages.hpp"
+#include "pb_tile.hpp"
 
 #define PB_BLOCK 256
 #define PB_PX 4  // output pixels per work-item: 12 contiguous bytes = 3 dword stores
 
 struct pb_plan {
     PbParams P;
+    int mode;                     // PB_MODE_AUTO / PB_MODE_FAITHFUL / PB_MODE_FAST
+    long long certify_mismatches; // -1 = not certified (no device at creation)
+    long long exact_pixels = -1;  // pixels the fast path sent through the faithful chain (certification run)
+    long long modelled_tiles = -1;
 };
 
 static thread_local std::string g_err;
@@ -271,6 +276,143 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_synth_kernel(uint8_t* __restrict_
     for (uint32_t ch = 0; ch < 3; ++ch) o[ch] = (uint8_t)(keep * (pb_mix32(base ^ (ch * 0x27D4EB2Fu)) & 0xFFu));
 }
 
+
+// ----------------------------------------------------------------------------------
+// tile kernels (pano / camera sources): one wave per 32x32 tile, 4 tiles per block
+// ----------------------------------------------------------------------------------
+#define PB_TILE_WAVES 4
+typedef unsigned pb_u32x3 __attribute__((ext_vector_type(3)));
+
+__device__ __forceinline__ unsigned pb_load_px32(const uint8_t* __restrict__ src, int idx) {
+    if (idx < 0) return 0u;
+    unsigned v;
+    __builtin_memcpy(&v, src + 3ull * (unsigned)idx, 4);  // unaligned dword; the source carries >= 1 byte of tail slack
+    return v & 0xFFFFFFu;
+}
+
+// tile id -> (tile x, tile y); a block of 4 waves takes a 2x2 group of tiles (64x64 px)
+__device__ __forceinline__ bool pb_tile_origin(const PbParams& P, int wave, int& X0, int& Y0) {
+    const int gx = (P.dst.width + 2 * PB_TILE - 1) / (2 * PB_TILE);
+    const int by = blockIdx.x / gx, bx = blockIdx.x - by * gx;
+    X0 = (2 * bx + (wave & 1)) * PB_TILE;
+    Y0 = (2 * by + (wave >> 1)) * PB_TILE;
+    return X0 < P.dst.width && Y0 < P.dst.height;
+}
+
+// OUT 0: gather + store frames; OUT 1: write the int32 index map; OUT 2: certify (count pixels
+// whose fast-path index differs from the faithful one)
+template <int SRC_KIND, int OUT>
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_tile_kernel(const PbParams P, const uint8_t* __restrict__ src,
+                                                                      uint8_t* __restrict__ dst, int n_frames,
+                                                                      unsigned long long src_stride,
+                                                                      unsigned long long dst_stride, int tail_slack,
+                                                                      int32_t* __restrict__ idx_out,
+                                                                      unsigned long long* __restrict__ counter) {
+    __shared__ PbWaveLds lds[PB_TILE_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int X0, Y0;
+    if (!pb_tile_origin(P, wave, X0, Y0)) return;  // wave-uniform; no workgroup barriers below
+    PbWaveLds& L = lds[wave];
+    unsigned n_exact = 0;
+    const bool modelled = pb_tile_indices<SRC_KIND>(P, L, lane, X0, Y0, P.fast_tiles != 0, OUT == 2 ? &n_exact : nullptr);
+
+    // gather-phase ownership: lane -> 4 consecutive px (x = 4*xg..) in rows yb + 8*jr
+    const int xg = lane & 7, yb = lane >> 3;
+    const int W = P.dst.width, H = P.dst.height;
+    int id[4][4];
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) id[jr][k] = L.idx[(yb + 8 * jr) * PB_TILE_PITCH + 4 * xg + k];
+    const int x = X0 + 4 * xg;
+    if (OUT == 1) {
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const int y = Y0 + yb + 8 * jr;
+            if (y < H)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (x + k < W) idx_out[(size_t)y * W + x + k] = id[jr][k];
+        }
+        return;
+    }
+    if (OUT == 2) {
+        unsigned bad = 0;
+#pragma unroll 1
+        for (int jr = 0; jr < 4; ++jr) {
+            const int y = Y0 + yb + 8 * jr;
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k)
+                if (y < H && x + k < W) bad += (pb_exact_index<SRC_KIND>(P, y, x + k) != id[jr][k]);
+        }
+        if (bad) atomicAdd(counter, (unsigned long long)bad);
+        if (n_exact) atomicAdd(counter + 1, (unsigned long long)n_exact);  // pixels that took the faithful chain
+        if (lane == 0) atomicAdd(counter + 2, modelled ? 1ull : 0ull);      // tiles with an accepted model
+        return;
+    }
+    const unsigned last_px = (unsigned)P.src.height * (unsigned)P.src.width - 1u;
+    for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* s = src + (unsigned long long)f * src_stride;
+        uint8_t* d = dst + (unsigned long long)f * dst_stride;
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const int y = Y0 + yb + 8 * jr;
+            unsigned a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = id[jr][k];
+                // the 4-byte read of the very last source pixel would touch one byte past the
+                // frame: only allowed when the caller's buffer has slack
+                a[k] = (!tail_slack && (unsigned)v == last_px) ? pb_load_px(s, v) : pb_load_px32(s, v);
+            }
+            if (y < H) {
+                const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+                if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
+                    pb_u32x3 o;
+                    o.x = a[0] | (a[1] << 24);
+                    o.y = (a[1] >> 8) | (a[2] << 16);
+                    o.z = (a[2] >> 16) | (a[3] << 8);
+                    *reinterpret_cast<pb_u32x3*>(d + off) = o;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (x + k < W) {
+                            d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+                            d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+                            d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+                        }
+                }
+            }
+        }
+    }
+}
+
+// plan creation: bisection for the validity thresholds with the exact predicate
+__global__ void pb_threshold_kernel(const PbParams P, long long* __restrict__ out) {
+    const int side = threadIdx.x;  // 0: left / single, 1: right eye of a double destination
+    if (side > 1) return;
+    const long long wc = (P.dst.kind == PB_KIND_DOUBLE) ? P.dst_half_w : P.dst.width;
+    const long long nmax = (wc - 1) * (wc - 1) + (long long)(P.dst.height - 1) * (P.dst.height - 1);
+    // first n4 where the lens inverse leaves its domain (asin argument > 1); nmax + 1 if never
+    long long lo = 0, hi = nmax + 1;
+    while (lo < hi) {
+        const long long mid = lo + (hi - lo) / 2;
+        bool outside;
+        pb_dst_inv_pred(P, mid, side != 0, &outside);
+        if (outside) hi = mid; else lo = mid + 1;
+    }
+    const long long n_dom = lo;
+    // first n4 in [0, n_dom) where the pixel is invalid (monotone inside the domain)
+    lo = 0;
+    hi = n_dom;
+    while (lo < hi) {
+        const long long mid = lo + (hi - lo) / 2;
+        if (pb_dst_inv_pred(P, mid, side != 0, nullptr)) hi = mid; else lo = mid + 1;
+    }
+    out[2 * side + 0] = lo;      // invalid  <=>  lo <= n4 < n_dom
+    out[2 * side + 1] = n_dom;
+}
+
 // ----------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------
@@ -310,6 +452,70 @@ static PbEnd pb_to_end(const pb_proj* p) {
 }
 
 static inline unsigned pb_blocks(unsigned long long items) { return (unsigned)((items + PB_BLOCK - 1) / PB_BLOCK); }
+
+
+static inline unsigned pb_tile_blocks(const PbParams& P) {
+    const unsigned gx = (P.dst.width + 2 * PB_TILE - 1) / (2 * PB_TILE), gy = (P.dst.height + 2 * PB_TILE - 1) / (2 * PB_TILE);
+    return gx * gy;
+}
+
+template <int OUT>
+static void pb_launch_tiles(const PbParams& P, const uint8_t* src, uint8_t* dst, int n_frames, unsigned long long ss,
+                            unsigned long long ds, int32_t* idx_out, unsigned long long* counter, hipStream_t st) {
+    const dim3 grid(pb_tile_blocks(P)), block(64 * PB_TILE_WAVES);
+    if (P.src.kind == PB_KIND_PANO)
+        hipLaunchKernelGGL((pb_tile_kernel<PB_KIND_PANO, OUT>), grid, block, 0, st, P, src, dst, n_frames, ss, ds, 0, idx_out, counter);
+    else
+        hipLaunchKernelGGL((pb_tile_kernel<PB_KIND_CAMERA, OUT>), grid, block, 0, st, P, src, dst, n_frames, ss, ds, 0, idx_out, counter);
+}
+
+// Runs once per plan on the current device (synchronously, default stream):
+//  1. validity thresholds of a camera / double destination by bisection with the exact predicate;
+//  2. certification: the fast tile path's index map is compared with the faithful one for every
+//     pixel; one differing pixel disables the fast path for this plan.
+static int pb_plan_prepare_on_device(pb_plan* pl) {
+    PbParams& P = pl->P;
+    long long* scratch = nullptr;
+    PB_HIP(hipMalloc((void**)&scratch, 8 * sizeof(long long)));
+    int rc = PB_OK;
+    do {
+        if (P.dst.kind != PB_KIND_PANO) {
+            hipLaunchKernelGGL(pb_threshold_kernel, dim3(1), dim3(2), 0, 0, P, scratch);
+            long long thr[4];
+            if (hipMemcpy(thr, scratch, sizeof(thr), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            P.inv_lo[0] = thr[0]; P.inv_hi[0] = thr[1];
+            P.inv_lo[1] = thr[2]; P.inv_hi[1] = thr[3];
+        }
+        P.thresholds_ready = 1;
+        if (P.src.kind != PB_KIND_DOUBLE) {
+            unsigned long long* counter = reinterpret_cast<unsigned long long*>(scratch + 4);
+            if (hipMemset(counter, 0, 3 * sizeof(unsigned long long)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            // the fast path needs 32-bit squares of the doubled pixel offsets and >= 14 fraction bits
+            const int maxd = P.dst.width > P.dst.height ? P.dst.width : P.dst.height;
+            if (maxd > 16384 || P.fx_shift < 14) break;
+            P.fast_tiles = 1;
+            pb_launch_tiles<2>(P, nullptr, nullptr, 0, 0, 0, nullptr, counter, 0);
+            unsigned long long res[3] = {0, 0, 0};
+            if (hipMemcpy(res, counter, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            pl->certify_mismatches = (long long)res[0];
+            pl->exact_pixels = (long long)res[1];
+            pl->modelled_tiles = (long long)res[2];
+            if (res[0]) P.fast_tiles = 0;
+        }
+    } while (0);
+    if (rc != PB_OK) g_err = std::string("plan preparation on device failed: ") + hipGetErrorString(hipGetLastError());
+    (void)hipFree(scratch);
+    return rc;
+}
+
+static PbParams pb_effective_params(const pb_plan* plan) {
+    PbParams P = plan->P;
+    if (plan->mode == PB_MODE_FAITHFUL) P.fast_tiles = 0;
+    if (plan->mode == PB_MODE_FAST && P.src.kind != PB_KIND_DOUBLE && P.thresholds_ready && P.fx_shift >= 14 &&
+        P.dst.width <= 16384 && P.dst.height <= 16384)
+        P.fast_tiles = 1;
+    return P;
+}
 
 extern "C" {
 
@@ -351,6 +557,18 @@ int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb
     for (int k = 0; k < n_rot; ++k)
         for (int e = 0; e < 9; ++e) pl->P.R[k][e] = rot3x3[9 * k + e];
     pb_derive(pl->P);
+    pl->mode = PB_MODE_AUTO;
+    pl->certify_mismatches = -1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    (void)hipGetLastError();
+    if (ndev > 0) {
+        const int rc = pb_plan_prepare_on_device(pl);
+        if (rc != PB_OK) {
+            delete pl;
+            return rc;
+        }
+    }
     *out = pl;
     return PB_OK;
 }
@@ -380,21 +598,15 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
     if (!src_frame_stride) src_frame_stride = 3ull * P.src.height * P.src.width;
     if (!dst_frame_stride) dst_frame_stride = 3ull * npx;
     if (dst_frame_stride < 3ull * npx) return pb_fail(PB_ERR_INVALID, "dst_frame_stride smaller than a frame");
-    const int aligned = (((uintptr_t)dst_dev | dst_frame_stride) & 3u) == 0;
-    const unsigned blocks = pb_blocks((npx + PB_PX - 1) / PB_PX);
     hipStream_t st = (hipStream_t)stream;
-    switch (P.src.kind) {
-        case PB_KIND_PANO:
-            hipLaunchKernelGGL(pb_remap_kernel<PB_KIND_PANO>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, src_dev, dst_dev,
-                               n_frames, src_frame_stride, dst_frame_stride, aligned);
-            break;
-        case PB_KIND_CAMERA:
-            hipLaunchKernelGGL(pb_remap_kernel<PB_KIND_CAMERA>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, src_dev,
-                               dst_dev, n_frames, src_frame_stride, dst_frame_stride, aligned);
-            break;
-        default:
-            hipLaunchKernelGGL(pb_remap_kernel<PB_KIND_DOUBLE>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, src_dev,
-                               dst_dev, n_frames, src_frame_stride, dst_frame_stride, aligned);
+    if (P.src.kind != PB_KIND_DOUBLE) {
+        pb_launch_tiles<0>(pb_effective_params(plan), src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride, nullptr,
+                           nullptr, st);
+    } else {
+        const int aligned = (((uintptr_t)dst_dev | dst_frame_stride) & 3u) == 0;
+        const unsigned blocks = pb_blocks((npx + PB_PX - 1) / PB_PX);
+        hipLaunchKernelGGL(pb_remap_kernel<PB_KIND_DOUBLE>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, src_dev, dst_dev,
+                           n_frames, src_frame_stride, dst_frame_stride, aligned);
     }
     PB_HIP(hipGetLastError());
     return PB_OK;
@@ -403,22 +615,41 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
 int pb_index_map_i32(const pb_plan* plan, int32_t* idx_dev, double* weights_dev, void* stream) {
     if (!plan || !idx_dev) return pb_fail(PB_ERR_INVALID, "null argument");
     const PbParams& P = plan->P;
-    const unsigned blocks = pb_blocks((unsigned long long)P.dst.height * P.dst.width);
     hipStream_t st = (hipStream_t)stream;
-    switch (P.src.kind) {
-        case PB_KIND_PANO:
-            hipLaunchKernelGGL(pb_index_kernel<PB_KIND_PANO>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, idx_dev,
-                               weights_dev);
-            break;
-        case PB_KIND_CAMERA:
-            hipLaunchKernelGGL(pb_index_kernel<PB_KIND_CAMERA>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, idx_dev,
-                               weights_dev);
-            break;
-        default:
-            hipLaunchKernelGGL(pb_index_kernel<PB_KIND_DOUBLE>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, idx_dev,
-                               weights_dev);
+    if (P.src.kind != PB_KIND_DOUBLE) {
+        pb_launch_tiles<1>(pb_effective_params(plan), nullptr, nullptr, 0, 0, 0, idx_dev, nullptr, st);
+    } else {
+        const unsigned blocks = pb_blocks((unsigned long long)P.dst.height * P.dst.width);
+        hipLaunchKernelGGL(pb_index_kernel<PB_KIND_DOUBLE>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, idx_dev, weights_dev);
     }
     PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+int pb_plan_set_mode(pb_plan* plan, int mode) {
+    if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (mode < PB_MODE_AUTO || mode > PB_MODE_FAST) return pb_fail(PB_ERR_INVALID, "mode out of range");
+    plan->mode = mode;
+    return PB_OK;
+}
+
+int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* certify_mismatches, long long* thresholds4,
+                 long long* tile_stats3) {
+    if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (fast_path_enabled) *fast_path_enabled = pb_effective_params(plan).fast_tiles;
+    if (certify_mismatches) *certify_mismatches = plan->certify_mismatches;
+    if (tile_stats3) {
+        const PbParams& P = plan->P;
+        tile_stats3[0] = (long long)((P.dst.width + PB_TILE - 1) / PB_TILE) * ((P.dst.height + PB_TILE - 1) / PB_TILE);
+        tile_stats3[1] = plan->modelled_tiles;
+        tile_stats3[2] = plan->exact_pixels;
+    }
+    if (thresholds4) {
+        thresholds4[0] = plan->P.inv_lo[0];
+        thresholds4[1] = plan->P.inv_hi[0];
+        thresholds4[2] = plan->P.inv_lo[1];
+        thresholds4[3] = plan->P.inv_hi[1];
+    }
     return PB_OK;
 }
 

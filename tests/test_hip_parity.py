@@ -96,11 +96,11 @@ def test_materialised_maps_within_ulps(case):
             g, w = got[..., ch], want[..., ch]
             both_nan = np.isnan(g) & np.isnan(w)
             d = ulp_diff(np.where(both_nan, 0.0, g), np.where(both_nan, 0.0, w))
-            # near zero an absolute bound replaces the ulp bound; after a rotation
-            # lat = acos(v_y) is ill-conditioned near the poles: a 1-ulp change of
-            # v_y moves lat by 2^-53 / sin(lat)
+            # near zero an absolute bound replaces the ulp bound; after k rotations
+            # lat = acos(v_y) and lon = atan2(v_z, v_x) are ill-conditioned near the
+            # poles: a 1-ulp change of v moves them by 2^-53 / sin(lat)
             with np.errstate(all="ignore"):
-                cond = 4 * 2.0**-52 / np.maximum(np.abs(np.sin(w)), 1e-9) if (k > 0 and ch == 0) else 0.0
+                cond = k * 8 * 2.0**-52 / np.maximum(np.abs(np.sin(want[..., 0])), 1e-9)
                 ok = (d <= MAP_ULPS) | (np.abs(g - w) <= np.maximum(1e-15, cond))
             assert ok.all(), f"stage {k} {name}: max {d.max()} ulp"
 
