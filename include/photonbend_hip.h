@@ -89,24 +89,27 @@ int pb_device_name(char* buf, size_t buflen);
 /* ---- the fused hot path ------------------------------------------------ */
 /* rot3x3: n_rot row-major 3x3 float64 matrices = Rotation.rotation_matrix
  * (core/rotation.py:100), applied in order; n_rot in [0, PB_MAX_ROTATIONS].
- * When a HIP device is visible, creation runs two short kernels on the current device
- * (synchronously): the destination-validity thresholds and the fast-path certification. */
+ * When a HIP device is visible, creation prepares the plan on the CURRENT device (synchronously,
+ * about the cost of two faithful frames): destination-validity thresholds, per-tile models, and the
+ * exhaustive comparison that yields the fix list.  The plan then owns device memory on that device
+ * (256 B per 32x32 output tile + the fix list) until pb_plan_destroy. */
 int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, pb_plan** out);
 void pb_plan_destroy(pb_plan* plan);
-/* Execution mode of a plan.  AUTO (default): per-tile polynomial fast path when the plan was
- * certified at creation (its integer index map equals the faithful path's for every pixel),
- * else the faithful per-pixel float64 path.  FAITHFUL / FAST force one of them (tests). */
+/* Execution mode of a plan.  AUTO (default) and FAST: the hot kernel (per-tile float32 polynomial
+ * models of the coordinate field) followed by the fix kernel (faithful float64 chain on the plan's
+ * fix list), when the plan was prepared on a device; otherwise, and under FAITHFUL, the per-pixel
+ * float64 chain for every pixel.  Both produce identical bytes: the fix list is, by construction at
+ * plan creation, every pixel whose model index differs from the faithful one. */
 #define PB_MODE_AUTO 0
 #define PB_MODE_FAITHFUL 1
 #define PB_MODE_FAST 2
 int pb_plan_set_mode(pb_plan* plan, int mode);
-/* fast_path_enabled: 0/1 under the current mode; certify_mismatches: pixels whose fast-path
- * index differed from the faithful one at creation (0 = certified, -1 = no device at creation);
- * thresholds4: {invalid_lo, invalid_hi} on (2x)^2+(2y)^2 for the left/single and the right eye
- * of the destination; tile_stats3: {32x32 tiles, tiles whose polynomial model was accepted, pixels
- * that went through the faithful chain} in the certification run (-1 = none).  Any pointer may be NULL. */
-int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* certify_mismatches, long long* thresholds4,
-                 long long* tile_stats3);
+/* fast_path_enabled: 0/1 under the current mode; stats5: {32x32 tiles, tiles handled whole by the
+ * fix kernel, single pixels on the fix list, pixels where model and faithful index differed,
+ * bytes of the per-tile model table} (-1 when the plan has no device state); thresholds4:
+ * {invalid_lo, invalid_hi} on (2x)^2+(2y)^2 for the left/single and the right eye of the
+ * destination.  Any pointer may be NULL. */
+int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats5, long long* thresholds4);
 int pb_plan_dst_shape(const pb_plan* plan, int* height, int* width);
 int pb_plan_src_shape(const pb_plan* plan, int* height, int* width);
 

@@ -61,7 +61,7 @@ SIGNATURES = {
     "pb_plan_create": (C.c_int, [C.POINTER(pb_proj), C.POINTER(C.c_double), C.c_int, C.POINTER(pb_proj), C.POINTER(_VP)]),
     "pb_plan_destroy": (None, [_VP]),
     "pb_plan_set_mode": (C.c_int, [_VP, C.c_int]),
-    "pb_plan_info": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "pb_plan_info": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "pb_plan_dst_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_plan_src_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_remap_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
@@ -151,17 +151,18 @@ class Plan:
         check(load().pb_plan_set_mode(self._h, int(mode)))
 
     def info(self) -> dict:
-        fast, bad = C.c_int(), C.c_longlong()
+        fast = C.c_int()
+        st = (C.c_longlong * 5)()
         thr = (C.c_longlong * 4)()
-        st = (C.c_longlong * 3)()
-        check(load().pb_plan_info(self._h, C.byref(fast), C.byref(bad), thr, st))
+        check(load().pb_plan_info(self._h, C.byref(fast), st, thr))
         return {
             "fast_path": bool(fast.value),
-            "certify_mismatches": int(bad.value),
-            "thresholds": [int(t) for t in thr],
             "tiles": int(st[0]),
-            "modelled_tiles": int(st[1]),
-            "exact_pixels": int(st[2]),
+            "fix_tiles": int(st[1]),
+            "fix_pixels": int(st[2]),
+            "model_diff_pixels": int(st[3]),
+            "table_bytes": int(st[4]),
+            "thresholds": [int(t) for t in thr],
         }
 
     def __del__(self):

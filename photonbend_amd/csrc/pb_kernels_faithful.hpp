@@ -1,0 +1,250 @@
+// pb_kernels_faithful.hpp - the per-pixel FAITHFUL kernels: every output pixel runs the
+// float64 chain of pb_stages.hpp.  They are (a) the reference the plan builder certifies the
+// tile models against, (b) the path of double-fisheye sources, (c) the materialised-map API
+// (pb_coordmap_f64 / pb_rotate_f64 / pb_sample_map_u8) and (d) PB_MODE_FAITHFUL.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pb_params.hpp"
+#include "pb_stages.hpp"
+
+#define PB_BLOCK 256
+#define PB_PX 4  // output pixels per work-item: 12 contiguous bytes = 3 dword stores
+
+// ----------------------------------------------------------------------------------
+// kernels
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ PbCoord pb_chain(const PbParams& P, int i, int j) {
+    PbCoord c = pb_dst_coord(P, i, j);
+    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    return c;
+}
+
+__device__ __forceinline__ unsigned pb_load_px(const uint8_t* __restrict__ src, int idx) {
+    if (idx < 0) return 0u;
+    const uint8_t* p = src + 3ull * (unsigned)idx;
+    return (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16);
+}
+
+// Packs 4 RGB pixels (24-bit each, in the low bits of a[0..3]) into 3 dwords and
+// stores them; `full` = all four pixels exist and the address is 4-byte aligned.
+__device__ __forceinline__ void pb_store_px4(uint8_t* __restrict__ out, unsigned long long p0, const unsigned a[PB_PX],
+                                             int count, bool aligned) {
+    uint8_t* o = out + 3ull * p0;
+    if (count == PB_PX && aligned) {
+        uint3 v;
+        v.x = a[0] | (a[1] << 24);
+        v.y = (a[1] >> 8) | (a[2] << 16);
+        v.z = (a[2] >> 16) | (a[3] << 8);
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(o);
+        o32[0] = v.x;
+        o32[1] = v.y;
+        o32[2] = v.z;
+    } else {
+        for (int k = 0; k < count; ++k) {
+            o[3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+            o[3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+            o[3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+        }
+    }
+}
+
+template <int SRC_KIND>
+__global__ __launch_bounds__(PB_BLOCK) void pb_remap_kernel(const PbParams P, const uint8_t* __restrict__ src,
+                                                            uint8_t* __restrict__ dst, int n_frames,
+                                                            unsigned long long src_stride,
+                                                            unsigned long long dst_stride, int aligned) {
+    const unsigned total = (unsigned)P.dst.height * (unsigned)P.dst.width;
+    const unsigned g = blockIdx.x * PB_BLOCK + threadIdx.x;
+    const unsigned p0 = g * PB_PX;
+    if (p0 >= total) return;
+    const int count = (total - p0 >= PB_PX) ? PB_PX : (int)(total - p0);
+    const unsigned W = (unsigned)P.dst.width;
+    unsigned i = p0 / W, j = p0 - i * W;
+
+    int idx[PB_PX];
+    int idx2[PB_PX];
+    double fl[PB_PX], fr[PB_PX];
+    bool inv[PB_PX];
+#pragma unroll
+    for (int k = 0; k < PB_PX; ++k) {
+        idx[k] = -1;
+        idx2[k] = -1;
+        fl[k] = fr[k] = 1.0;
+        inv[k] = true;
+        if (k < count) {
+            const PbCoord c = pb_chain(P, (int)i, (int)j);
+            if (SRC_KIND == PB_KIND_PANO) {
+                idx[k] = pb_src_pano_index(P, c);
+            } else if (SRC_KIND == PB_KIND_CAMERA) {
+                idx[k] = pb_src_camera_index(P, c);
+            } else {
+                const PbDoubleTap t = pb_src_double_taps(P, c);
+                idx[k] = t.il;
+                idx2[k] = t.ir;
+                fl[k] = t.fl;
+                fr[k] = t.fr;
+                inv[k] = c.inv;
+            }
+            if (++j == W) {
+                j = 0;
+                ++i;
+            }
+        }
+    }
+    for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* s = src + (unsigned long long)f * src_stride;
+        uint8_t* d = dst + (unsigned long long)f * dst_stride;
+        unsigned a[PB_PX];
+#pragma unroll
+        for (int k = 0; k < PB_PX; ++k) {
+            if (SRC_KIND == PB_KIND_DOUBLE) {
+                const unsigned l = pb_load_px(s, idx[k]);
+                const unsigned r = pb_load_px(s, idx2[k]);
+                unsigned v = 0;
+                if (!inv[k]) {  // final_image[invalid_map] = 0, projection.py:460
+                    v = pb_blend_u8(l & 0xFF, r & 0xFF, fl[k], fr[k]) |
+                        (pb_blend_u8((l >> 8) & 0xFF, (r >> 8) & 0xFF, fl[k], fr[k]) << 8) |
+                        (pb_blend_u8((l >> 16) & 0xFF, (r >> 16) & 0xFF, fl[k], fr[k]) << 16);
+                }
+                a[k] = v;
+            } else {
+                a[k] = pb_load_px(s, idx[k]);
+            }
+        }
+        pb_store_px4(d, p0, a, count, aligned != 0);
+    }
+}
+
+template <int SRC_KIND>
+__global__ __launch_bounds__(PB_BLOCK) void pb_index_kernel(const PbParams P, int32_t* __restrict__ out,
+                                                            double* __restrict__ wout) {
+    const unsigned total = (unsigned)P.dst.height * (unsigned)P.dst.width;
+    const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    const unsigned W = (unsigned)P.dst.width;
+    const unsigned i = p / W, j = p - i * W;
+    const PbCoord c = pb_chain(P, (int)i, (int)j);
+    if (SRC_KIND == PB_KIND_PANO) {
+        out[p] = pb_src_pano_index(P, c);
+    } else if (SRC_KIND == PB_KIND_CAMERA) {
+        out[p] = pb_src_camera_index(P, c);
+    } else {
+        const PbDoubleTap t = pb_src_double_taps(P, c);
+        out[p] = t.il;
+        out[(size_t)total + p] = t.ir;
+        if (wout) {
+            wout[p] = t.fl;
+            wout[(size_t)total + p] = t.fr;
+        }
+    }
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void pb_coordmap_kernel(const PbParams P, double* __restrict__ out) {
+    const unsigned total = (unsigned)P.dst.height * (unsigned)P.dst.width;
+    const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    const unsigned W = (unsigned)P.dst.width;
+    const unsigned i = p / W, j = p - i * W;
+    const PbCoord c = pb_dst_coord(P, (int)i, (int)j);
+    double* o = out + 3ull * p;
+    o[0] = c.lat;
+    o[1] = c.lon;
+    o[2] = c.inv ? 1.0 : 0.0;
+}
+
+struct PbMat {
+    double m[9];
+};
+
+__global__ __launch_bounds__(PB_BLOCK) void pb_rotate_kernel(const PbMat R, double* __restrict__ in,
+                                                             double* __restrict__ out, unsigned total) {
+    const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    double* a = in + 3ull * p;
+    PbCoord c;
+    c.inv = a[2] != 0.0;  // NaN counts as invalid, rotation.py:118
+    if (c.inv) {
+        a[0] = 0.0;  // the reference zeroes the CALLER's map, rotation.py:119-125
+        a[1] = 0.0;
+    }
+    c.lat = a[0];
+    c.lon = a[1];
+    c = pb_rotate(R.m, c);
+    double* o = out + 3ull * p;
+    o[0] = c.lat;
+    o[1] = c.lon;
+    o[2] = c.inv ? 1.0 : 0.0;
+}
+
+template <int SRC_KIND>
+__global__ __launch_bounds__(PB_BLOCK) void pb_sample_map_kernel(const PbParams P, double* __restrict__ map,
+                                                                 unsigned total, const uint8_t* __restrict__ src,
+                                                                 uint8_t* __restrict__ dst) {
+    const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    double* a = map + 3ull * p;
+    PbCoord c;
+    c.inv = a[2] != 0.0;
+    if (SRC_KIND == PB_KIND_PANO && c.inv) {
+        a[0] = 0.0;  // polar_map[invalid_map] = 0 writes through the view, projection.py:534-536
+        a[1] = 0.0;
+    }
+    c.lat = a[0];
+    c.lon = a[1];
+    unsigned v;
+    if (SRC_KIND == PB_KIND_PANO) {
+        v = pb_load_px(src, pb_src_pano_index(P, c));
+    } else if (SRC_KIND == PB_KIND_CAMERA) {
+        v = pb_load_px(src, pb_src_camera_index(P, c));
+    } else {
+        const PbDoubleTap t = pb_src_double_taps(P, c);
+        const unsigned l = pb_load_px(src, t.il), r = pb_load_px(src, t.ir);
+        v = 0;
+        if (!c.inv)
+            v = pb_blend_u8(l & 0xFF, r & 0xFF, t.fl, t.fr) |
+                (pb_blend_u8((l >> 8) & 0xFF, (r >> 8) & 0xFF, t.fl, t.fr) << 8) |
+                (pb_blend_u8((l >> 16) & 0xFF, (r >> 16) & 0xFF, t.fl, t.fr) << 16);
+    }
+    uint8_t* o = dst + 3ull * p;
+    o[0] = (uint8_t)(v & 0xFF);
+    o[1] = (uint8_t)((v >> 8) & 0xFF);
+    o[2] = (uint8_t)((v >> 16) & 0xFF);
+}
+
+__device__ __forceinline__ uint32_t pb_mix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void pb_synth_kernel(uint8_t* __restrict__ out, int height, int width,
+                                                            uint32_t fkey, int circle_mask) {
+    const unsigned total = (unsigned)height * (unsigned)width;
+    const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    const unsigned r = p / (unsigned)width, c = p - r * (unsigned)width;
+    unsigned keep = 1;
+    if (circle_mask) {
+        const long long ys = 2ll * r + 1 - height;
+        long long xs, d;
+        if (circle_mask == 1) {
+            xs = 2ll * c + 1 - width;
+            d = height < width ? height : width;
+        } else {
+            const int half = width / 2;
+            xs = 2ll * (c % (unsigned)half) + 1 - half;
+            d = height < half ? height : half;
+        }
+        keep = (ys * ys + xs * xs <= d * d) ? 1u : 0u;
+    }
+    const uint32_t base = (r * 0x85EBCA6Bu) ^ (c * 0xC2B2AE35u) ^ fkey;
+    uint8_t* o = out + 3ull * p;
+#pragma unroll
+    for (uint32_t ch = 0; ch < 3; ++ch) o[ch] = (uint8_t)(keep * (pb_mix32(base ^ (ch * 0x27D4EB2Fu)) & 0xFFu));
+}
+
+
