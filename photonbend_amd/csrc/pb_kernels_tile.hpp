@@ -85,18 +85,377 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_kernel(const PbPara
         return;
     }
     const unsigned last_px = (unsigned)P.src.height * (unsigned)P.src.width - 1u;
+    const int variant = P.pad0;  // experiment switch
     for (int f = 0; f < n_frames; ++f) {
         const uint8_t* s = src + (unsigned long long)f * src_stride;
         uint8_t* d = dst + (unsigned long long)f * dst_stride;
+        unsigned a[4][4];
+        if (variant == 1) {
+            // A: first pixel of every row group, wait, then the rest (they should hit L1 now)
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) a[jr][0] = ((unsigned)id[jr][0] == last_px) ? pb_load_px(s, id[jr][0]) : pb_load_px32(s, id[jr][0]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+                for (int k = 1; k < 4; ++k) a[jr][k] = ((unsigned)id[jr][k] == last_px) ? pb_load_px(s, id[jr][k]) : pb_load_px32(s, id[jr][k]);
+        } else if (variant == 2) {
+            // B: one 16-byte load at the lowest texel of the 4; pixels it covers are extracted, others loaded separately
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                int lo = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (id[jr][k] >= 0) lo = min(lo, id[jr][k]);
+                uint4 q = make_uint4(0, 0, 0, 0);
+                const bool have = lo != 0x7fffffff && (unsigned)lo + 6u <= last_px;
+                if (have) __builtin_memcpy(&q, s + 3ull * (unsigned)lo, 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int v = id[jr][k];
+                    const unsigned dlt = (unsigned)(v - lo);
+                    if (v < 0) a[jr][k] = 0;
+                    else if (have && dlt <= 4u) {
+                        const unsigned sh = 3u * dlt;  // byte offset 0..12
+                        const unsigned w0 = sh < 4 ? q.x : (sh < 8 ? q.y : (sh < 12 ? q.z : q.w));
+                        const unsigned w1 = sh < 4 ? q.y : (sh < 8 ? q.z : (sh < 12 ? q.w : 0u));
+                        a[jr][k] = __builtin_amdgcn_alignbyte(w1, w0, sh & 3u) & 0xFFFFFFu;
+                    } else a[jr][k] = ((unsigned)v == last_px) ? pb_load_px(s, v) : pb_load_px32(s, v);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int v = id[jr][k];
+                    // a 4-byte read of the frame's very last pixel would touch one byte past the buffer
+                    a[jr][k] = ((unsigned)v == last_px) ? pb_load_px(s, v) : pb_load_px32(s, v);
+                }
+        }
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const int y = Y0 + yb + 8 * jr;
+            if (y < H) {
+                const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+                if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
+                    pb_u32x3 o;
+                    o.x = a[jr][0] | (a[jr][1] << 24);
+                    o.y = (a[jr][1] >> 8) | (a[jr][2] << 16);
+                    o.z = (a[jr][2] >> 16) | (a[jr][3] << 8);
+                    *reinterpret_cast<pb_u32x3*>(d + off) = o;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (x + k < W) {
+                            d[off + 3 * k + 0] = (uint8_t)(a[jr][k] & 0xFF);
+                            d[off + 3 * k + 1] = (uint8_t)((a[jr][k] >> 8) & 0xFF);
+                            d[off + 3 * k + 2] = (uint8_t)((a[jr][k] >> 16) & 0xFF);
+                        }
+                }
+            }
+        }
+    }
+}
+
+// ---- LDS-staged variant of the hot kernel ---------------------------------------------------------
+// Same math phase; the gather goes through a wave-private LDS window.  The tile is processed as two
+// 32x16 halves; for each half the wave reduces the bounding box of its source samples, loads the box
+// with coalesced 16-byte loads (one row segment = `n16` consecutive lanes), and every pixel whose
+// sample lies inside the loaded box reads LDS (one aligned dword pair + alignbyte).  Samples outside
+// (seams, poles, boxes larger than the window) fall back to the unaligned global load.
+#define PB_WIN_BYTES 8192
+
+struct PbWaveLdsStaged {
+    int idx[PB_TILE * PB_TILE_PITCH];
+    __attribute__((aligned(16))) unsigned win[PB_WIN_BYTES / 4 + 4];
+};
+
+__device__ __forceinline__ int pb_wave_min(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int pb_wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <int SRC_KIND>
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_staged_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
+                                                                            const uint8_t* __restrict__ src,
+                                                                            uint8_t* __restrict__ dst, int n_frames,
+                                                                            unsigned long long src_stride,
+                                                                            unsigned long long dst_stride) {
+    __shared__ PbWaveLdsStaged lds[PB_TILE_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tx, ty;
+    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
+    const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
+    if (e->flags & PB_TILE_FAILED) return;
+    const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
+    PbWaveLdsStaged& L = lds[wave];
+    {
+        const int y = lane & 31, xh = (lane >> 5) * 16;
+        PbRowModel R;
+        pb_model_row(P, e, X0, Y0, y, xh, R);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) L.idx[y * PB_TILE_PITCH + xh + k] = pb_model_px_rc<SRC_KIND>(P, R, xh, k);
+    }
+    pb_wave_sync();
+    const int xg = lane & 7, yb = lane >> 3;
+    const int W = P.dst.width, H = P.dst.height;
+    const unsigned rowbytes = 3u * (unsigned)P.src.width;
+    const unsigned long long frame_bytes = (unsigned long long)rowbytes * P.src.height;
+    const int x = X0 + 4 * xg;
+    for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* s = src + (unsigned long long)f * src_stride;
+        uint8_t* d = dst + (unsigned long long)f * dst_stride;
+#pragma unroll 1
+        for (int half_t = 0; half_t < 2; ++half_t) {
+            int rc[2][4];
+            int rmin = 0x7fffffff, rmax = -1, cmin = 0x7fffffff, cmax = -1;
+#pragma unroll
+            for (int jr = 0; jr < 2; ++jr)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int v = L.idx[(16 * half_t + yb + 8 * jr) * PB_TILE_PITCH + 4 * xg + k];
+                    rc[jr][k] = v;
+                    if (v >= 0) {
+                        const int r = v >> 16, c = v & 0xFFFF;
+                        rmin = min(rmin, r); rmax = max(rmax, r);
+                        cmin = min(cmin, c); cmax = max(cmax, c);
+                    }
+                }
+            rmin = pb_wave_min(rmin); rmax = pb_wave_max(rmax);
+            cmin = pb_wave_min(cmin); cmax = pb_wave_max(cmax);
+            // window geometry (wave-uniform)
+            int n16 = 0, nrows = 0;
+            if (rmax >= 0) {
+                n16 = (3 * (cmax - cmin + 1) + 16 + 15) >> 4;   // 16-byte chunks per row incl. alignment slack + 1 byte
+                if (n16 > 16) n16 = 16;
+                nrows = rmax - rmin + 1;
+                const int cap = PB_WIN_BYTES / (16 * n16);
+                if (nrows > cap) nrows = cap;
+            }
+            const unsigned pitch = 16u * n16;
+            if (nrows > 0) {
+                const unsigned inv = (65536u + n16 - 1) / n16;          // lane / n16 for lane < 64
+                const unsigned lrow = (lane * inv) >> 16, chunk = lane - lrow * n16;
+                const unsigned rpp = 64u / n16;
+                if (lrow < rpp)
+                    for (unsigned row = lrow; row < (unsigned)nrows; row += rpp) {
+                        const unsigned long long g = (unsigned long long)(rmin + row) * rowbytes + 3u * cmin;
+                        const uintptr_t abs0 = (uintptr_t)s + g;
+                        const uintptr_t ga = (abs0 & ~(uintptr_t)15) + 16u * chunk;
+                        uint4 v4 = make_uint4(0, 0, 0, 0);
+                        if (ga >= (uintptr_t)s && ga + 16 <= (uintptr_t)s + frame_bytes) {
+                            v4 = *reinterpret_cast<const uint4*>(ga);
+                        } else {
+                            unsigned char tmp[16];
+                            for (int b = 0; b < 16; ++b) {
+                                const uintptr_t a = ga + b;
+                                tmp[b] = (a >= (uintptr_t)s && a < (uintptr_t)s + frame_bytes) ? *reinterpret_cast<const uint8_t*>(a) : 0;
+                            }
+                            __builtin_memcpy(&v4, tmp, 16);
+                        }
+                        *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(L.win) + row * pitch + 16u * chunk) = v4;
+                    }
+            }
+            pb_wave_sync();
+#pragma unroll
+            for (int jr = 0; jr < 2; ++jr) {
+                const int y = Y0 + 16 * half_t + yb + 8 * jr;
+                unsigned a[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int v = rc[jr][k];
+                    unsigned px = 0;
+                    if (v >= 0) {
+                        const unsigned r = (unsigned)v >> 16, c = (unsigned)v & 0xFFFFu;
+                        const unsigned row = r - (unsigned)rmin;
+                        const unsigned long long g = (unsigned long long)r * rowbytes + 3u * c;
+                        const unsigned a0 = (unsigned)(((uintptr_t)s + (unsigned long long)r * rowbytes + 3u * cmin) & 15u);
+                        const unsigned off = 3u * (c - (unsigned)cmin) + a0;
+                        if (row < (unsigned)nrows && off + 4u <= pitch) {
+                            const unsigned la = row * pitch + off;
+                            const unsigned lo = L.win[la >> 2], hi = L.win[(la >> 2) + 1];
+                            px = __builtin_amdgcn_alignbyte(hi, lo, la & 3u) & 0xFFFFFFu;
+                        } else if (g + 4 <= frame_bytes) {
+                            unsigned t;
+                            __builtin_memcpy(&t, s + g, 4);
+                            px = t & 0xFFFFFFu;
+                        } else {
+                            px = (unsigned)s[g] | ((unsigned)s[g + 1] << 8) | ((unsigned)s[g + 2] << 16);
+                        }
+                    }
+                    a[k] = px;
+                }
+                if (y < H) {
+                    const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+                    if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
+                        pb_u32x3 o;
+                        o.x = a[0] | (a[1] << 24);
+                        o.y = (a[1] >> 8) | (a[2] << 16);
+                        o.z = (a[2] >> 16) | (a[3] << 8);
+                        *reinterpret_cast<pb_u32x3*>(d + off) = o;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (x + k < W) {
+                                d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+                                d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+                                d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+                            }
+                    }
+                }
+            }
+            pb_wave_sync();  // the window is reused by the next half
+        }
+    }
+}
+
+
+// ---- hot kernel with prefetched LDS windows ---------------------------------------------------------
+// The plan entry carries the exact bounding box of the tile's source samples.  The wave first issues
+// the whole box as LDS-DMA loads (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, one row
+// segment = n16 consecutive lanes, no VGPRs), then evaluates the tile model while the loads fly, then
+// gathers every pixel from LDS (aligned dword pair + alignbyte).  Samples outside the loaded window
+// (boxes taller than the LDS budget, the last bytes of a frame) use the unaligned global load.
+// Requires frame pointers and strides that are multiples of 16 bytes (else pb_hot_kernel is used).
+#define PB_WINLDS_BYTES 16384
+#ifdef PB_STAMPS
+__device__ unsigned long long pb_stamp_acc[65536 * 8];
+#define PB_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) pb_stamp_acc[(size_t)(ty * pb_tiles_x(P) + tx) * 8 + i] += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define PB_STAMP(i)
+#endif
+
+template <int SRC_KIND>
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
+                                                                         const uint8_t* __restrict__ src,
+                                                                         uint8_t* __restrict__ dst, int n_frames,
+                                                                         unsigned long long src_stride,
+                                                                         unsigned long long dst_stride) {
+    __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tx, ty;
+    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
+    const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
+    if (e->flags & PB_TILE_FAILED) return;
+    const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
+    unsigned* win = win_all[wave];
+    const unsigned rowbytes = 3u * (unsigned)P.src.width;
+    const unsigned frame_bytes = rowbytes * (unsigned)P.src.height;   // < 2^31 (host check)
+    const unsigned safe_len = frame_bytes & ~15u;                     // every 16-byte chunk below this is loadable
+
+    // window geometry (wave-uniform)
+    const int r0 = e->win_r0, c0 = e->win_c0;
+    int nrows = e->win_rows;
+    const unsigned gbase = (unsigned)r0 * rowbytes + 3u * (unsigned)c0;   // byte offset of the box's first sample
+    const unsigned a0 = gbase & 15u;                                      // frames are 16-byte aligned, rows may not be
+    int n16 = 0;
+    if (nrows > 0) {
+        n16 = (3 * e->win_cols + 15 + 1 + 15) >> 4;  // + worst-case alignment slack + 1 byte for the dword reads
+        if (n16 > 16) n16 = 16;
+        const int cap = PB_WINLDS_BYTES / (16 * n16);
+        if (nrows > cap) nrows = cap;
+    }
+    const unsigned pitch = 16u * (unsigned)n16;
+    const unsigned rb16 = rowbytes & 15u;  // row-to-row change of the alignment offset
+
+    const int xg = lane & 7, yb = lane >> 3;
+    const int W = P.dst.width, H = P.dst.height;
+    const int x = X0 + 4 * xg;
+#ifdef PB_STAMPS
+    unsigned long long t_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev) :: "memory");
+#endif
+    for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* s = src + (unsigned long long)f * src_stride;
+        uint8_t* d = dst + (unsigned long long)f * dst_stride;
+        if (nrows > 0) {
+            const unsigned inv = (65536u + n16 - 1) / n16;
+            const unsigned lrow = ((unsigned)lane * inv) >> 16, chunk = (unsigned)lane - lrow * n16;
+            const unsigned rpp = 64u / n16;
+            const bool lane_on = lrow < rpp;
+            for (unsigned rowb = 0; rowb < (unsigned)nrows; rowb += rpp) {
+                const unsigned row = rowb + lrow;
+                // row segment starts at the 16-byte boundary at or below its first sample
+                const unsigned g = gbase + row * rowbytes;
+                const unsigned ga = (g & ~15u) + 16u * chunk;
+                if (lane_on && row < (unsigned)nrows && ga + 16u <= safe_len)
+                    __builtin_amdgcn_global_load_lds(s + ga, (__attribute__((address_space(3))) void*)(win + (rowb * pitch >> 2)), 16, 0, 0);
+            }
+        }
+        PB_STAMP(0);
+        // model evaluation overlaps the loads: lane owns 4 consecutive pixels in rows yb + 8 * jr
+        int rc[4][4];
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            PbRowModel R;
+            pb_model_row(P, e, X0, Y0, yb + 8 * jr, 4 * xg, R);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rc[jr][k] = pb_model_px_rc<SRC_KIND>(P, R, 4 * xg, k);
+        }
+        // LDS addresses + "inside the loaded window" predicate for all 16 pixels (no memory access yet)
+        unsigned la[4][4];
+        bool all_in = true;
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = rc[jr][k];
+                const unsigned r = (unsigned)v >> 16, c = (unsigned)v & 0xFFFFu;
+                const unsigned row = r - (unsigned)r0;
+                const unsigned off = __umul24(c - (unsigned)c0, 3u) + ((a0 + row * rb16) & 15u);
+                la[jr][k] = __umul24(row, pitch) + off;
+                const bool in = row < (unsigned)nrows && off + 4u <= pitch && __umul24(r, rowbytes) + __umul24(c, 3u) + 4u <= safe_len;
+                all_in = all_in && (in || v < 0);
+            }
+        PB_STAMP(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pb_wave_sync();
+        PB_STAMP(2);
+        const bool fast_gather = __builtin_amdgcn_ballot_w64(!all_in) == 0;  // wave-uniform
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
             const int y = Y0 + yb + 8 * jr;
             unsigned a[4];
+            if (fast_gather) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int v = id[jr][k];
-                // a 4-byte read of the frame's very last pixel would touch one byte past the buffer
-                a[k] = ((unsigned)v == last_px) ? pb_load_px(s, v) : pb_load_px32(s, v);
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned l = (rc[jr][k] < 0) ? 0u : la[jr][k];
+                    const unsigned lo = win[l >> 2], hi = win[(l >> 2) + 1];
+                    const unsigned px = __builtin_amdgcn_alignbyte(hi, lo, l & 3u) & 0xFFFFFFu;
+                    a[k] = (rc[jr][k] < 0) ? 0u : px;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int v = rc[jr][k];
+                    unsigned px = 0;
+                    if (v >= 0) {
+                        const unsigned r = (unsigned)v >> 16, c = (unsigned)v & 0xFFFFu;
+                        const unsigned row = r - (unsigned)r0;
+                        const unsigned g = r * rowbytes + 3u * c;
+                        const unsigned off = 3u * (c - (unsigned)c0) + ((a0 + row * rb16) & 15u);
+                        if (row < (unsigned)nrows && off + 4u <= pitch && g + 4u <= safe_len) {
+                            const unsigned l = row * pitch + off;
+                            const unsigned lo = win[l >> 2], hi = win[(l >> 2) + 1];
+                            px = __builtin_amdgcn_alignbyte(hi, lo, l & 3u) & 0xFFFFFFu;
+                        } else if (g + 4u <= frame_bytes) {
+                            unsigned t;
+                            __builtin_memcpy(&t, s + g, 4);
+                            px = t & 0xFFFFFFu;
+                        } else {
+                            px = (unsigned)s[g] | ((unsigned)s[g + 1] << 8) | ((unsigned)s[g + 2] << 16);
+                        }
+                    }
+                    a[k] = px;
+                }
             }
             if (y < H) {
                 const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
@@ -117,6 +476,10 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_kernel(const PbPara
                 }
             }
         }
+        PB_STAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PB_STAMP(4);
+        pb_wave_sync();  // the window is overwritten by the next frame's loads
     }
 }
 
@@ -233,6 +596,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_model_kernel(const PbPa
         e->anchor_c = any_bad ? 0 : (int)a1;
         e->flags = any_bad ? PB_TILE_FAILED : PB_TILE_HAS_MODEL;
         e->pad0 = 0;
+        e->win_r0 = e->win_rows = e->win_c0 = e->win_cols = 0;
     }
 }
 
@@ -258,20 +622,34 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const Pb
     if (!failed) {
         PbRowModel R;
         pb_model_row(P, e, X0, Y0, y, xh, R);
+        int rmin = 0x7fffffff, rmax = -1, cmin = 0x7fffffff, cmax = -1;
         for (int k = 0; k < 16; ++k) {
             const int j = X0 + xh + k;
             if (i < P.dst.height && j < P.dst.width) {
                 const int fast = pb_model_px<SRC_KIND>(P, R, xh, k);
+                if (fast >= 0) {
+                    const int r = fast / P.src.width, c = fast - r * P.src.width;
+                    rmin = min(rmin, r); rmax = max(rmax, r);
+                    cmin = min(cmin, c); cmax = max(cmax, c);
+                }
                 const int exact = pb_exact_index<SRC_KIND>(P, i, j);
                 diff |= (unsigned)(fast != exact) << k;
             }
         }
         unsigned total = __popc(diff);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        for (int o = 32; o > 0; o >>= 1) {
+            total += __shfl_xor(total, o);
+            rmin = min(rmin, __shfl_xor(rmin, o)); rmax = max(rmax, __shfl_xor(rmax, o));
+            cmin = min(cmin, __shfl_xor(cmin, o)); cmax = max(cmax, __shfl_xor(cmax, o));
+        }
         if (lane == 0) {
             atomicAdd(&counters[2], total);
             atomicAdd(&counters[3], 1u);
+            e->win_r0 = rmax < 0 ? 0 : rmin;
+            e->win_rows = rmax < 0 ? 0 : rmax - rmin + 1;
+            e->win_c0 = rmax < 0 ? 0 : cmin;
+            e->win_cols = rmax < 0 ? 0 : cmax - cmin + 1;
         }
         if (total > PB_TILE_FAIL_LIMIT) failed = true;
         if (!failed && total) {

@@ -32,7 +32,10 @@ struct __attribute__((aligned(256))) PbTileEntry {
     int32_t flags;
     int32_t pad0;
     float c[2][25];              // c[coord][m*5+n] multiplies v^m u^n  (v: rows, u: columns, both in [-1, 1])
-    int32_t pad1[10];
+    // bounding box of the tile's source samples (the hot path's own values, found by the plan builder):
+    // rows [win_r0, win_r0 + win_rows), columns [win_c0, win_c0 + win_cols); win_rows == 0: none
+    int32_t win_r0, win_rows, win_c0, win_cols;
+    int32_t pad1[6];
 };
 static_assert(sizeof(PbTileEntry) == 256, "PbTileEntry must be 256 bytes");
 
@@ -110,6 +113,29 @@ __device__ __forceinline__ void pb_model_row(const PbParams& P, const PbTileEntr
         R.vb = (int)(B < 0 ? 0 : (B > 0x7fffffffll ? 0x7fffffffll : B));
         R.x2 = 2 * (X0 + xh - (side ? P.dst_half_w : 0)) - (wc - 1);
     }
+}
+
+// Source (row, col) of pixel x = xh + k packed as (r << 16 | c), or -1 = black.  Needs src dims < 32768.
+template <int SRC_KIND>
+__device__ __forceinline__ int pb_model_px_rc(const PbParams& P, const PbRowModel& R, int xh, int k) {
+    const float half = 0.5f * (PB_TILE - 1), inv_half = 1.0f / (0.5f * (PB_TILE - 1));
+    const float u = ((float)(xh + k) - half) * inv_half;
+    float fr = R.ar[4], fc = R.ac[4];
+#pragma unroll
+    for (int n = 3; n >= 0; --n) {
+        fr = fmaf(fr, u, R.ar[n]);
+        fc = fmaf(fc, u, R.ac[n]);
+    }
+    int r = R.anchor_r + (int)floorf(fr), c = R.anchor_c + (int)floorf(fc);
+    const int h = P.src.height, w = P.src.width;
+    if (SRC_KIND == PB_KIND_PANO) {
+        if (r >= h) r -= h;
+        if (c >= w) c -= w;
+    }
+    int id = ((unsigned)r < (unsigned)h && (unsigned)c < (unsigned)w) ? ((r << 16) | c) : -1;
+    const int xx = R.x2 + 2 * k, q = (int)__mul24(xx, xx);
+    if (q >= R.va && q < R.vb) id = -1;
+    return id;
 }
 
 // Source index of pixel x = xh + k of the row prepared in R (or -1 = black).

@@ -24,6 +24,7 @@ struct pb_plan {
     int mode = PB_MODE_AUTO;     // PB_MODE_AUTO / PB_MODE_FAITHFUL / PB_MODE_FAST
     int device = -1;             // device that owns the tables below
     int fast_ready = 0;          // models + fix list built and certified on `device`
+    int staged = getenv("PB_STAGED") ? atoi(getenv("PB_STAGED")) : 0;  // gather through LDS windows
     PbTileEntry* table = nullptr;
     int32_t* fail_tiles = nullptr;
     int32_t* fix_px = nullptr;
@@ -157,15 +158,33 @@ static bool pb_use_fast(const pb_plan* plan) { return plan->fast_ready && plan->
 template <int OUT>
 static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, int n_frames, unsigned long long ss,
                            unsigned long long ds, int32_t* idx_out, hipStream_t st) {
-    const PbParams& P = pl->P;
+    PbParams P = pl->P;
+    if (getenv("PB_VARIANT")) P.pad0 = atoi(getenv("PB_VARIANT"));
     const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
     const unsigned fix_blocks = 4u * pl->n_fail_tiles + (pl->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
+    const bool windowed = OUT == 0 && pl->staged == 2 && P.src.width < 32768 && P.src.height < 32768 &&
+                          ((((uintptr_t)src) | ss) & 15u) == 0;
+    if (windowed) {
+        if (P.src.kind == PB_KIND_PANO)
+            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_PANO>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds);
+        else
+            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_CAMERA>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds);
+    }
+    const bool staged = windowed || (OUT == 0 && pl->staged == 1 && P.src.width < 32768 && P.src.height < 32768);
+    if (staged && !windowed) {
+        if (P.src.kind == PB_KIND_PANO)
+            hipLaunchKernelGGL(pb_hot_staged_kernel<PB_KIND_PANO>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds);
+        else
+            hipLaunchKernelGGL(pb_hot_staged_kernel<PB_KIND_CAMERA>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds);
+    }
     if (P.src.kind == PB_KIND_PANO) {
-        hipLaunchKernelGGL((pb_hot_kernel<PB_KIND_PANO, OUT>), grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, idx_out);
+        if (!staged)
+        hipLaunchKernelGGL((pb_hot_kernel<PB_KIND_PANO, OUT>), grid, block, getenv("PB_LDS_PAD") ? atoi(getenv("PB_LDS_PAD")) : 0, st, P, pl->table, src, dst, n_frames, ss, ds, idx_out);
         if (fix_blocks)
             hipLaunchKernelGGL((pb_fix_kernel<PB_KIND_PANO, OUT>), dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, pl->fail_tiles,
                                (int)pl->n_fail_tiles, pl->fix_px, (int)pl->n_fix_px, src, dst, n_frames, ss, ds, idx_out);
     } else {
+        if (!staged)
         hipLaunchKernelGGL((pb_hot_kernel<PB_KIND_CAMERA, OUT>), grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, idx_out);
         if (fix_blocks)
             hipLaunchKernelGGL((pb_fix_kernel<PB_KIND_CAMERA, OUT>), dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, pl->fail_tiles,
@@ -299,6 +318,18 @@ int pb_index_map_i32(const pb_plan* plan, int32_t* idx_dev, double* weights_dev,
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
+
+#ifdef PB_STAMPS
+__attribute__((visibility("default"))) int pb_debug_stamps(unsigned long long* out8, int reset) {
+    static unsigned long long hostbuf[65536 * 8];
+    if (out8) {
+        (void)hipMemcpyFromSymbol(hostbuf, HIP_SYMBOL(pb_stamp_acc), sizeof(hostbuf));
+        for (int i = 0; i < 8; ++i) { out8[i] = 0; for (int t = 0; t < 65536; ++t) out8[i] += hostbuf[(size_t)t * 8 + i]; }
+    }
+    if (reset) { memset(hostbuf, 0, sizeof(hostbuf)); (void)hipMemcpyToSymbol(HIP_SYMBOL(pb_stamp_acc), hostbuf, sizeof(hostbuf)); }
+    return 0;
+}
+#endif
 
 int pb_plan_set_mode(pb_plan* plan, int mode) {
     if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
