@@ -23,7 +23,7 @@ for i in range(N): plan.remap(frames[i % 4], outs[i % 4])
 e1.record(); torch.cuda.synchronize()
 lib.pb_debug_stamps(buf, 0)
 info = plan.info()
-waves = (info['tiles'] - info['fix_tiles']) * N
+waves = info['lean_tiles'] * N
 print('us/frame %.1f' % (e0.elapsed_time(e1) * 1e3 / N))
 names = ['issue window loads', 'model math', 'wait loads landed', 'gather (LDS) + issue stores', 'wait stores']
 for n, v in zip(names, buf): print('  %-30s %8.0f cycles/wave' % (n, v / waves))

@@ -104,12 +104,14 @@ void pb_plan_destroy(pb_plan* plan);
 #define PB_MODE_FAITHFUL 1
 #define PB_MODE_FAST 2
 int pb_plan_set_mode(pb_plan* plan, int mode);
-/* fast_path_enabled: 0/1 under the current mode; stats5: {32x32 tiles, tiles handled whole by the
+/* fast_path_enabled: 0/1 under the current mode; stats7: {32x32 tiles, tiles handled whole by the
  * fix kernel, single pixels on the fix list, pixels where model and faithful index differed,
- * bytes of the per-tile model table} (-1 when the plan has no device state); thresholds4:
+ * tiles on the lean LDS-window path, all-black tiles, tiles on the lean direct-gather path} (-1 when the
+ * plan has no device state);
+ * thresholds4:
  * {invalid_lo, invalid_hi} on (2x)^2+(2y)^2 for the left/single and the right eye of the
  * destination.  Any pointer may be NULL. */
-int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats5, long long* thresholds4);
+int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats7, long long* thresholds4);
 int pb_plan_dst_shape(const pb_plan* plan, int* height, int* width);
 int pb_plan_src_shape(const pb_plan* plan, int* height, int* width);
 

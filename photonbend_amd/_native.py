@@ -152,7 +152,7 @@ class Plan:
 
     def info(self) -> dict:
         fast = C.c_int()
-        st = (C.c_longlong * 5)()
+        st = (C.c_longlong * 7)()
         thr = (C.c_longlong * 4)()
         check(load().pb_plan_info(self._h, C.byref(fast), st, thr))
         return {
@@ -161,7 +161,9 @@ class Plan:
             "fix_tiles": int(st[1]),
             "fix_pixels": int(st[2]),
             "model_diff_pixels": int(st[3]),
-            "table_bytes": int(st[4]),
+            "lean_tiles": int(st[4]),
+            "black_tiles": int(st[5]),
+            "direct_tiles": int(st[6]),
             "thresholds": [int(t) for t in thr],
         }
 

@@ -1,7 +1,7 @@
 // pb_kernels_tile.hpp - the fast path for pano / camera sources.
 //
 //   per frame (pb_remap_u8):   pb_hot_kernel  -> pb_fix_kernel          (same stream)
-//   per plan  (pb_plan_create): pb_threshold_kernel -> pb_model_kernel -> pb_certify_kernel
+//   per plan  (pb_plan_create): pb_threshold_kernel -> pb_model_kernel -> pb_window_kernel -> pb_certify_kernel
 //
 // pb_hot_kernel: one WAVE per 32x32 output tile, 4 tiles (a 64x64 block) per workgroup,
 // no workgroup barrier.  Math phase: lane = (row, half-row), 16 pixels each, float32 model
@@ -157,19 +157,6 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_kernel(const PbPara
     }
 }
 
-// ---- LDS-staged variant of the hot kernel ---------------------------------------------------------
-// Same math phase; the gather goes through a wave-private LDS window.  The tile is processed as two
-// 32x16 halves; for each half the wave reduces the bounding box of its source samples, loads the box
-// with coalesced 16-byte loads (one row segment = `n16` consecutive lanes), and every pixel whose
-// sample lies inside the loaded box reads LDS (one aligned dword pair + alignbyte).  Samples outside
-// (seams, poles, boxes larger than the window) fall back to the unaligned global load.
-#define PB_WIN_BYTES 8192
-
-struct PbWaveLdsStaged {
-    int idx[PB_TILE * PB_TILE_PITCH];
-    __attribute__((aligned(16))) unsigned win[PB_WIN_BYTES / 4 + 4];
-};
-
 __device__ __forceinline__ int pb_wave_min(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
@@ -180,151 +167,33 @@ __device__ __forceinline__ int pb_wave_max(int v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
     return v;
 }
-
-template <int SRC_KIND>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_staged_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
-                                                                            const uint8_t* __restrict__ src,
-                                                                            uint8_t* __restrict__ dst, int n_frames,
-                                                                            unsigned long long src_stride,
-                                                                            unsigned long long dst_stride) {
-    __shared__ PbWaveLdsStaged lds[PB_TILE_WAVES];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int tx, ty;
-    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
-    const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
-    if (e->flags & PB_TILE_FAILED) return;
-    const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
-    PbWaveLdsStaged& L = lds[wave];
-    {
-        const int y = lane & 31, xh = (lane >> 5) * 16;
-        PbRowModel R;
-        pb_model_row(P, e, X0, Y0, y, xh, R);
+__device__ __forceinline__ int pb_wave_sum(int v) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) L.idx[y * PB_TILE_PITCH + xh + k] = pb_model_px_rc<SRC_KIND>(P, R, xh, k);
-    }
-    pb_wave_sync();
-    const int xg = lane & 7, yb = lane >> 3;
-    const int W = P.dst.width, H = P.dst.height;
-    const unsigned rowbytes = 3u * (unsigned)P.src.width;
-    const unsigned long long frame_bytes = (unsigned long long)rowbytes * P.src.height;
-    const int x = X0 + 4 * xg;
-    for (int f = 0; f < n_frames; ++f) {
-        const uint8_t* s = src + (unsigned long long)f * src_stride;
-        uint8_t* d = dst + (unsigned long long)f * dst_stride;
-#pragma unroll 1
-        for (int half_t = 0; half_t < 2; ++half_t) {
-            int rc[2][4];
-            int rmin = 0x7fffffff, rmax = -1, cmin = 0x7fffffff, cmax = -1;
-#pragma unroll
-            for (int jr = 0; jr < 2; ++jr)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int v = L.idx[(16 * half_t + yb + 8 * jr) * PB_TILE_PITCH + 4 * xg + k];
-                    rc[jr][k] = v;
-                    if (v >= 0) {
-                        const int r = v >> 16, c = v & 0xFFFF;
-                        rmin = min(rmin, r); rmax = max(rmax, r);
-                        cmin = min(cmin, c); cmax = max(cmax, c);
-                    }
-                }
-            rmin = pb_wave_min(rmin); rmax = pb_wave_max(rmax);
-            cmin = pb_wave_min(cmin); cmax = pb_wave_max(cmax);
-            // window geometry (wave-uniform)
-            int n16 = 0, nrows = 0;
-            if (rmax >= 0) {
-                n16 = (3 * (cmax - cmin + 1) + 16 + 15) >> 4;   // 16-byte chunks per row incl. alignment slack + 1 byte
-                if (n16 > 16) n16 = 16;
-                nrows = rmax - rmin + 1;
-                const int cap = PB_WIN_BYTES / (16 * n16);
-                if (nrows > cap) nrows = cap;
-            }
-            const unsigned pitch = 16u * n16;
-            if (nrows > 0) {
-                const unsigned inv = (65536u + n16 - 1) / n16;          // lane / n16 for lane < 64
-                const unsigned lrow = (lane * inv) >> 16, chunk = lane - lrow * n16;
-                const unsigned rpp = 64u / n16;
-                if (lrow < rpp)
-                    for (unsigned row = lrow; row < (unsigned)nrows; row += rpp) {
-                        const unsigned long long g = (unsigned long long)(rmin + row) * rowbytes + 3u * cmin;
-                        const uintptr_t abs0 = (uintptr_t)s + g;
-                        const uintptr_t ga = (abs0 & ~(uintptr_t)15) + 16u * chunk;
-                        uint4 v4 = make_uint4(0, 0, 0, 0);
-                        if (ga >= (uintptr_t)s && ga + 16 <= (uintptr_t)s + frame_bytes) {
-                            v4 = *reinterpret_cast<const uint4*>(ga);
-                        } else {
-                            unsigned char tmp[16];
-                            for (int b = 0; b < 16; ++b) {
-                                const uintptr_t a = ga + b;
-                                tmp[b] = (a >= (uintptr_t)s && a < (uintptr_t)s + frame_bytes) ? *reinterpret_cast<const uint8_t*>(a) : 0;
-                            }
-                            __builtin_memcpy(&v4, tmp, 16);
-                        }
-                        *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(L.win) + row * pitch + 16u * chunk) = v4;
-                    }
-            }
-            pb_wave_sync();
-#pragma unroll
-            for (int jr = 0; jr < 2; ++jr) {
-                const int y = Y0 + 16 * half_t + yb + 8 * jr;
-                unsigned a[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int v = rc[jr][k];
-                    unsigned px = 0;
-                    if (v >= 0) {
-                        const unsigned r = (unsigned)v >> 16, c = (unsigned)v & 0xFFFFu;
-                        const unsigned row = r - (unsigned)rmin;
-                        const unsigned long long g = (unsigned long long)r * rowbytes + 3u * c;
-                        const unsigned a0 = (unsigned)(((uintptr_t)s + (unsigned long long)r * rowbytes + 3u * cmin) & 15u);
-                        const unsigned off = 3u * (c - (unsigned)cmin) + a0;
-                        if (row < (unsigned)nrows && off + 4u <= pitch) {
-                            const unsigned la = row * pitch + off;
-                            const unsigned lo = L.win[la >> 2], hi = L.win[(la >> 2) + 1];
-                            px = __builtin_amdgcn_alignbyte(hi, lo, la & 3u) & 0xFFFFFFu;
-                        } else if (g + 4 <= frame_bytes) {
-                            unsigned t;
-                            __builtin_memcpy(&t, s + g, 4);
-                            px = t & 0xFFFFFFu;
-                        } else {
-                            px = (unsigned)s[g] | ((unsigned)s[g + 1] << 8) | ((unsigned)s[g + 2] << 16);
-                        }
-                    }
-                    a[k] = px;
-                }
-                if (y < H) {
-                    const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
-                    if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
-                        pb_u32x3 o;
-                        o.x = a[0] | (a[1] << 24);
-                        o.y = (a[1] >> 8) | (a[2] << 16);
-                        o.z = (a[2] >> 16) | (a[3] << 8);
-                        *reinterpret_cast<pb_u32x3*>(d + off) = o;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (x + k < W) {
-                                d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
-                                d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
-                                d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
-                            }
-                    }
-                }
-            }
-            pb_wave_sync();  // the window is reused by the next half
-        }
-    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
 }
 
+// 4 RGB pixels held as the low 3 bytes of a0..a3 -> 12 packed bytes (three v_perm_b32)
+__device__ __forceinline__ pb_u32x3 pb_pack_px4(unsigned a0, unsigned a1, unsigned a2, unsigned a3) {
+    pb_u32x3 o;
+    o.x = __builtin_amdgcn_perm(a1, a0, 0x04020100u);  // a0.b0 a0.b1 a0.b2 a1.b0
+    o.y = __builtin_amdgcn_perm(a2, a1, 0x05040201u);  // a1.b1 a1.b2 a2.b0 a2.b1
+    o.z = __builtin_amdgcn_perm(a3, a2, 0x06050402u);  // a2.b2 a3.b0 a3.b1 a3.b2
+    return o;
+}
 
 // ---- hot kernel with prefetched LDS windows ---------------------------------------------------------
-// The plan entry carries the exact bounding box of the tile's source samples.  The wave first issues
-// the whole box as LDS-DMA loads (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, one row
-// segment = n16 consecutive lanes, no VGPRs), then evaluates the tile model while the loads fly, then
-// gathers every pixel from LDS (aligned dword pair + alignbyte).  Samples outside the loaded window
-// (boxes taller than the LDS budget, the last bytes of a frame) use the unaligned global load.
+// The plan entry carries the bounding box of the tile's source samples.  The wave first issues the whole
+// box as LDS-DMA loads (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, one row segment =
+// n16 consecutive lanes, no VGPRs), evaluates the tile model while the loads fly, then gathers every pixel
+// from LDS (aligned dword pair + v_alignbyte) and stores 12 packed bytes per 4 pixels.
+//   LEAN tiles (the common case, flagged by the plan builder): the model is anchored at the window
+//   origin, so (int)f IS the window row / column: ~11 VALU instructions per pixel, no validity, bounds,
+//   wrap or fallback code.
+//   Other tiles: generic path - validity thresholds, wrap, per-pixel "inside the window" test with an
+//   unaligned global load as fallback.
 // Requires frame pointers and strides that are multiples of 16 bytes (else pb_hot_kernel is used).
-#define PB_WINLDS_BYTES 16384
+#define PB_WINLDS_BYTES 20224
 #ifdef PB_STAMPS
 __device__ unsigned long long pb_stamp_acc[65536 * 8];
 #define PB_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) pb_stamp_acc[(size_t)(ty * pb_tiles_x(P) + tx) * 8 + i] += t_ - t_prev; t_prev = t_; } while (0)
@@ -332,66 +201,184 @@ __device__ unsigned long long pb_stamp_acc[65536 * 8];
 #define PB_STAMP(i)
 #endif
 
+__device__ __forceinline__ void pb_issue_window_loads(const uint8_t* __restrict__ s, unsigned* win, int lane, unsigned gbase,
+                                                      unsigned rowbytes, int nrows, int n16, unsigned safe_len) {
+    const unsigned pitch = 16u * (unsigned)n16;
+    const unsigned inv = (65536u + n16 - 1) / n16;  // lane / n16 for lane < 64
+    const unsigned lrow = ((unsigned)lane * inv) >> 16, chunk = (unsigned)lane - lrow * n16;
+    const unsigned rpp = 64u / n16;
+    const bool lane_on = lrow < rpp;
+    for (unsigned rowb = 0; rowb < (unsigned)nrows; rowb += rpp) {
+        const unsigned row = rowb + lrow;
+        // a row segment starts at the 16-byte boundary at or below its first sample
+        const unsigned ga = ((gbase + row * rowbytes) & ~15u) + 16u * chunk;
+        if (lane_on && row < (unsigned)nrows && ga + 16u <= safe_len)
+            __builtin_amdgcn_global_load_lds(s + ga, (__attribute__((address_space(3))) void*)(win + ((rowb * pitch) >> 2)), 16, 0, 0);
+    }
+}
+
 template <int SRC_KIND>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
                                                                          const uint8_t* __restrict__ src,
                                                                          uint8_t* __restrict__ dst, int n_frames,
                                                                          unsigned long long src_stride,
                                                                          unsigned long long dst_stride) {
-    __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4];
+    __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tx, ty;
     if (!pb_tile_of_wave(P, wave, tx, ty)) return;
     const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
-    if (e->flags & PB_TILE_FAILED) return;
+    const int flags = e->flags;
+    if (flags & PB_TILE_FAILED) return;
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
     unsigned* win = win_all[wave];
     const unsigned rowbytes = 3u * (unsigned)P.src.width;
     const unsigned frame_bytes = rowbytes * (unsigned)P.src.height;   // < 2^31 (host check)
     const unsigned safe_len = frame_bytes & ~15u;                     // every 16-byte chunk below this is loadable
+    const int xg = lane & 7, yb = lane >> 3;
+    const int W = P.dst.width, H = P.dst.height;
+    const int x = X0 + 4 * xg;
 
-    // window geometry (wave-uniform)
+    if (flags & PB_TILE_BLACK) {
+        for (int f = 0; f < n_frames; ++f) {
+            uint8_t* d = dst + (unsigned long long)f * dst_stride;
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                const int y = Y0 + yb + 8 * jr;
+                if (y >= H) continue;
+                const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+                if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
+                    const pb_u32x3 z = {0u, 0u, 0u};
+                    *reinterpret_cast<pb_u32x3*>(d + off) = z;
+                } else {
+                    for (int k = 0; k < 4; ++k)
+                        if (x + k < W) d[off + 3 * k] = d[off + 3 * k + 1] = d[off + 3 * k + 2] = 0;
+                }
+            }
+        }
+        return;
+    }
+    if (flags & PB_TILE_DIRECT) {
+        const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = pb_tile_coord(4 * xg + k);
+        unsigned go[4][4];
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            pb_f2 a[5];
+            pb_collapse_row(e, yb + 8 * jr, a);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const pb_f2 fv = pb_eval_row(a, u[k]);
+                go[jr][k] = gbase + (unsigned)(int)fv.x * rowbytes + __umul24((unsigned)(int)fv.y, 3u);
+            }
+        }
+        for (int f = 0; f < n_frames; ++f) {
+            const uint8_t* s = src + (unsigned long long)f * src_stride;
+            uint8_t* d = dst + (unsigned long long)f * dst_stride;
+            unsigned a[4][4];
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_memcpy(&a[jr][k], s + go[jr][k], 4);
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
+                if ((((uintptr_t)d + off) & 3u) == 0) {
+                    *reinterpret_cast<pb_u32x3*>(d + off) = pb_pack_px4(a[jr][0], a[jr][1], a[jr][2], a[jr][3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        d[off + 3 * k + 0] = (uint8_t)(a[jr][k] & 0xFF);
+                        d[off + 3 * k + 1] = (uint8_t)((a[jr][k] >> 8) & 0xFF);
+                        d[off + 3 * k + 2] = (uint8_t)((a[jr][k] >> 16) & 0xFF);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    if (flags & PB_TILE_LEAN) {
+        const int nrows = e->win_rows, n16 = e->win_n16;
+        const unsigned a0 = (unsigned)e->win_a0, pitch = 16u * (unsigned)n16;
+        const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = pb_tile_coord(4 * xg + k);
+#ifdef PB_STAMPS
+        unsigned long long t_prev;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev) :: "memory");
+#endif
+        for (int f = 0; f < n_frames; ++f) {
+            const uint8_t* s = src + (unsigned long long)f * src_stride;
+            uint8_t* d = dst + (unsigned long long)f * dst_stride;
+            pb_issue_window_loads(s, win, lane, gbase, rowbytes, nrows, n16, safe_len);
+            PB_STAMP(0);
+            unsigned la[4][4];
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                pb_f2 a[5];
+                pb_collapse_row(e, yb + 8 * jr, a);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const pb_f2 fv = pb_eval_row(a, u[k]);
+                    const unsigned dr = (unsigned)(int)fv.x, dc = (unsigned)(int)fv.y;  // >= 0: truncation == floor
+                    la[jr][k] = __umul24(dr, pitch) + (__umul24(dc, 3u) + a0);
+                }
+            }
+            PB_STAMP(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pb_wave_sync();
+            PB_STAMP(2);
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                unsigned a[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned l = la[jr][k];
+                    a[k] = __builtin_amdgcn_alignbyte(win[(l >> 2) + 1], win[l >> 2], l);
+                }
+                // LEAN tiles lie fully inside the image; the 12-byte store is 4-byte aligned when the base is
+                const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
+                if ((((uintptr_t)d + off) & 3u) == 0) {
+                    *reinterpret_cast<pb_u32x3*>(d + off) = pb_pack_px4(a[0], a[1], a[2], a[3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+                        d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+                        d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+                    }
+                }
+            }
+            PB_STAMP(3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PB_STAMP(4);
+            pb_wave_sync();  // the window is overwritten by the next frame's loads
+        }
+        return;
+    }
+
+    // ---- generic tile ---------------------------------------------------------------------------------
     const int r0 = e->win_r0, c0 = e->win_c0;
     int nrows = e->win_rows;
     const unsigned gbase = (unsigned)r0 * rowbytes + 3u * (unsigned)c0;   // byte offset of the box's first sample
     const unsigned a0 = gbase & 15u;                                      // frames are 16-byte aligned, rows may not be
-    int n16 = 0;
+    int n16 = 1;
     if (nrows > 0) {
         n16 = (3 * e->win_cols + 15 + 1 + 15) >> 4;  // + worst-case alignment slack + 1 byte for the dword reads
-        if (n16 > 16) n16 = 16;
+        if (n16 > 64) n16 = 64;
         const int cap = PB_WINLDS_BYTES / (16 * n16);
         if (nrows > cap) nrows = cap;
     }
     const unsigned pitch = 16u * (unsigned)n16;
     const unsigned rb16 = rowbytes & 15u;  // row-to-row change of the alignment offset
-
-    const int xg = lane & 7, yb = lane >> 3;
-    const int W = P.dst.width, H = P.dst.height;
-    const int x = X0 + 4 * xg;
-#ifdef PB_STAMPS
-    unsigned long long t_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev) :: "memory");
-#endif
     for (int f = 0; f < n_frames; ++f) {
         const uint8_t* s = src + (unsigned long long)f * src_stride;
         uint8_t* d = dst + (unsigned long long)f * dst_stride;
-        if (nrows > 0) {
-            const unsigned inv = (65536u + n16 - 1) / n16;
-            const unsigned lrow = ((unsigned)lane * inv) >> 16, chunk = (unsigned)lane - lrow * n16;
-            const unsigned rpp = 64u / n16;
-            const bool lane_on = lrow < rpp;
-            for (unsigned rowb = 0; rowb < (unsigned)nrows; rowb += rpp) {
-                const unsigned row = rowb + lrow;
-                // row segment starts at the 16-byte boundary at or below its first sample
-                const unsigned g = gbase + row * rowbytes;
-                const unsigned ga = (g & ~15u) + 16u * chunk;
-                if (lane_on && row < (unsigned)nrows && ga + 16u <= safe_len)
-                    __builtin_amdgcn_global_load_lds(s + ga, (__attribute__((address_space(3))) void*)(win + (rowb * pitch >> 2)), 16, 0, 0);
-            }
-        }
-        PB_STAMP(0);
-        // model evaluation overlaps the loads: lane owns 4 consecutive pixels in rows yb + 8 * jr
+        if (nrows > 0) pb_issue_window_loads(s, win, lane, gbase, rowbytes, nrows, n16, safe_len);
         int rc[4][4];
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
@@ -400,71 +387,38 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
 #pragma unroll
             for (int k = 0; k < 4; ++k) rc[jr][k] = pb_model_px_rc<SRC_KIND>(P, R, 4 * xg, k);
         }
-        // LDS addresses + "inside the loaded window" predicate for all 16 pixels (no memory access yet)
-        unsigned la[4][4];
-        bool all_in = true;
-#pragma unroll
-        for (int jr = 0; jr < 4; ++jr)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int v = rc[jr][k];
-                const unsigned r = (unsigned)v >> 16, c = (unsigned)v & 0xFFFFu;
-                const unsigned row = r - (unsigned)r0;
-                const unsigned off = __umul24(c - (unsigned)c0, 3u) + ((a0 + row * rb16) & 15u);
-                la[jr][k] = __umul24(row, pitch) + off;
-                const bool in = row < (unsigned)nrows && off + 4u <= pitch && __umul24(r, rowbytes) + __umul24(c, 3u) + 4u <= safe_len;
-                all_in = all_in && (in || v < 0);
-            }
-        PB_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pb_wave_sync();
-        PB_STAMP(2);
-        const bool fast_gather = __builtin_amdgcn_ballot_w64(!all_in) == 0;  // wave-uniform
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
             const int y = Y0 + yb + 8 * jr;
             unsigned a[4];
-            if (fast_gather) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned l = (rc[jr][k] < 0) ? 0u : la[jr][k];
-                    const unsigned lo = win[l >> 2], hi = win[(l >> 2) + 1];
-                    const unsigned px = __builtin_amdgcn_alignbyte(hi, lo, l & 3u) & 0xFFFFFFu;
-                    a[k] = (rc[jr][k] < 0) ? 0u : px;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int v = rc[jr][k];
-                    unsigned px = 0;
-                    if (v >= 0) {
-                        const unsigned r = (unsigned)v >> 16, c = (unsigned)v & 0xFFFFu;
-                        const unsigned row = r - (unsigned)r0;
-                        const unsigned g = r * rowbytes + 3u * c;
-                        const unsigned off = 3u * (c - (unsigned)c0) + ((a0 + row * rb16) & 15u);
-                        if (row < (unsigned)nrows && off + 4u <= pitch && g + 4u <= safe_len) {
-                            const unsigned l = row * pitch + off;
-                            const unsigned lo = win[l >> 2], hi = win[(l >> 2) + 1];
-                            px = __builtin_amdgcn_alignbyte(hi, lo, l & 3u) & 0xFFFFFFu;
-                        } else if (g + 4u <= frame_bytes) {
-                            unsigned t;
-                            __builtin_memcpy(&t, s + g, 4);
-                            px = t & 0xFFFFFFu;
-                        } else {
-                            px = (unsigned)s[g] | ((unsigned)s[g + 1] << 8) | ((unsigned)s[g + 2] << 16);
-                        }
+            for (int k = 0; k < 4; ++k) {
+                const int v = rc[jr][k];
+                unsigned px = 0;
+                if (v >= 0) {
+                    const unsigned r = (unsigned)v >> 16, c = (unsigned)v & 0xFFFFu;
+                    const unsigned row = r - (unsigned)r0;
+                    const unsigned g = r * rowbytes + 3u * c;
+                    const unsigned off = 3u * (c - (unsigned)c0) + ((a0 + row * rb16) & 15u);
+                    if (row < (unsigned)nrows && off + 4u <= pitch && g + 4u <= safe_len) {
+                        const unsigned l = row * pitch + off;
+                        px = __builtin_amdgcn_alignbyte(win[(l >> 2) + 1], win[l >> 2], l) & 0xFFFFFFu;
+                    } else if (g + 4u <= frame_bytes) {
+                        unsigned t;
+                        __builtin_memcpy(&t, s + g, 4);
+                        px = t & 0xFFFFFFu;
+                    } else {
+                        px = (unsigned)s[g] | ((unsigned)s[g + 1] << 8) | ((unsigned)s[g + 2] << 16);
                     }
-                    a[k] = px;
                 }
+                a[k] = px;
             }
             if (y < H) {
                 const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
                 if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
-                    pb_u32x3 o;
-                    o.x = a[0] | (a[1] << 24);
-                    o.y = (a[1] >> 8) | (a[2] << 16);
-                    o.z = (a[2] >> 16) | (a[3] << 8);
-                    *reinterpret_cast<pb_u32x3*>(d + off) = o;
+                    *reinterpret_cast<pb_u32x3*>(d + off) = pb_pack_px4(a[0], a[1], a[2], a[3]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -476,10 +430,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
                 }
             }
         }
-        PB_STAMP(3);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PB_STAMP(4);
-        pb_wave_sync();  // the window is overwritten by the next frame's loads
+        pb_wave_sync();
     }
 }
 
@@ -588,22 +539,98 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_model_kernel(const PbPa
     // anchors from the constant terms (lane 0 holds C_00)
     const double a0 = floor(__shfl(c0, 0)), a1 = floor(__shfl(c1, 0));
     if (node) {
-        e->c[0][lane] = any_bad ? 0.0f : (float)(lane == 0 ? c0 - a0 : c0);
-        e->c[1][lane] = any_bad ? 0.0f : (float)(lane == 0 ? c1 - a1 : c1);
+        e->c[lane][0] = any_bad ? 0.0f : (float)(lane == 0 ? c0 - a0 : c0);
+        e->c[lane][1] = any_bad ? 0.0f : (float)(lane == 0 ? c1 - a1 : c1);
     }
     if (lane == 0) {
         e->anchor_r = any_bad ? 0 : (int)a0;
         e->anchor_c = any_bad ? 0 : (int)a1;
         e->flags = any_bad ? PB_TILE_FAILED : PB_TILE_HAS_MODEL;
-        e->pad0 = 0;
-        e->win_r0 = e->win_rows = e->win_c0 = e->win_cols = 0;
+        e->win_rows = 0;
+        e->win_r0 = e->win_c0 = e->win_cols = e->win_n16 = e->win_a0 = 0;
     }
+}
+
+// One wave per tile: evaluates the model for every pixel of the tile, finds the bounding box of its
+// source samples and decides whether the tile is LEAN; LEAN tiles are re-anchored at the window origin.
+template <int SRC_KIND>
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_window_kernel(const PbParams P, PbTileEntry* __restrict__ table) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int tx, ty;
+    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
+    PbTileEntry* e = table + ((size_t)ty * pb_tiles_x(P) + tx);
+    if (e->flags & PB_TILE_FAILED) return;
+    const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
+    const int y = lane & 31, xh = (lane >> 5) * 16;
+    const int i = Y0 + y;
+    const int h = P.src.height, w = P.src.width;
+    PbRowModel R;
+    pb_model_row(P, e, X0, Y0, y, xh, R);
+    int rmin = 0x7fffffff, rmax = -0x7fffffff, cmin = 0x7fffffff, cmax = -0x7fffffff;   // raw (unwrapped)
+    int wrmin = 0x7fffffff, wrmax = -1, wcmin = 0x7fffffff, wcmax = -1;               // as the generic path uses them
+    int not_plain = 0;  // pixels outside the image, invalid, black or wrapping
+    for (int k = 0; k < 16; ++k) {
+        const int j = X0 + xh + k;
+        if (i >= P.dst.height || j >= P.dst.width) { ++not_plain; continue; }
+        int r, c;
+        pb_f2 f;
+        pb_model_px_raw(R, xh, k, r, c, f);
+        if (pb_row_px_invalid(R, k)) { ++not_plain; continue; }
+        rmin = min(rmin, r); rmax = max(rmax, r);
+        cmin = min(cmin, c); cmax = max(cmax, c);
+        const int v = pb_model_px_rc<SRC_KIND>(P, R, xh, k);
+        if (v < 0) { ++not_plain; continue; }
+        const int wr = v >> 16, wc = v & 0xFFFF;
+        if (wr != r || wc != c) ++not_plain;
+        wrmin = min(wrmin, wr); wrmax = max(wrmax, wr);
+        wcmin = min(wcmin, wc); wcmax = max(wcmax, wc);
+    }
+    rmin = pb_wave_min(rmin); rmax = pb_wave_max(rmax); cmin = pb_wave_min(cmin); cmax = pb_wave_max(cmax);
+    wrmin = pb_wave_min(wrmin); wrmax = pb_wave_max(wrmax); wcmin = pb_wave_min(wcmin); wcmax = pb_wave_max(wcmax);
+    not_plain = pb_wave_sum(not_plain);
+    if (lane != 0) return;
+    if (wrmax < 0) {  // no pixel of the tile samples the source
+        e->win_r0 = e->win_rows = e->win_c0 = e->win_cols = 0;
+        e->flags |= PB_TILE_BLACK;
+        return;
+    }
+    // generic window: bounding box of the wrapped samples
+    e->win_r0 = wrmax < 0 ? 0 : wrmin;
+    e->win_rows = wrmax < 0 ? 0 : wrmax - wrmin + 1;
+    e->win_c0 = wrmax < 0 ? 0 : wcmin;
+    e->win_cols = wrmax < 0 ? 0 : wcmax - wcmin + 1;
+    // LEAN? one texel of margin on every side absorbs the last-bit effect of re-anchoring
+    const unsigned rowbytes = 3u * (unsigned)w;
+    const unsigned safe_len = (rowbytes * (unsigned)h) & ~15u;
+    if (not_plain != 0 || w >= 32768 || h >= 32768) return;
+    const int lr0 = rmin - 1, lc0 = cmin - 1, rows = rmax - rmin + 3, cols = cmax - cmin + 3;
+    if (lr0 < 0 || lc0 < 0 || lr0 + rows > h || lc0 + cols > w) return;
+    // the last sample's 4-byte read must stay inside the frame
+    if ((unsigned)(lr0 + rows - 1) * rowbytes + 3u * (unsigned)(lc0 + cols - 1) + 4u > rowbytes * (unsigned)h) return;
+    const unsigned a0 = (3u * (unsigned)lc0) & 15u;
+    const unsigned n16 = (a0 + 3u * (unsigned)cols + 1u + 15u) >> 4;
+    const unsigned last_chunk_end = (((unsigned)(lr0 + rows - 1) * rowbytes + 3u * (unsigned)lc0) & ~15u) + 16u * n16;
+    const bool stageable = (rowbytes & 15u) == 0 && n16 <= 64u && (unsigned)rows * 16u * n16 <= PB_WINLDS_BYTES &&
+                           ((unsigned)rows + (64u / (n16 > 64u ? 64u : n16)) - 1u) / (64u / (n16 > 64u ? 64u : n16)) <= PB_LEAN_MAX_PASSES &&
+                           last_chunk_end <= safe_len;
+    e->c[0][0] += (float)(e->anchor_r - lr0);
+    e->c[0][1] += (float)(e->anchor_c - lc0);
+    e->anchor_r = lr0;
+    e->anchor_c = lc0;
+    e->win_r0 = lr0;
+    e->win_c0 = lc0;
+    e->win_rows = rows;
+    e->win_cols = cols;
+    e->win_n16 = (int)n16;
+    e->win_a0 = (int)a0;
+    e->flags |= stageable ? PB_TILE_LEAN : PB_TILE_DIRECT;
 }
 
 // One wave per tile: compares the hot path's index with the faithful one for every pixel of the
 // tile; differing pixels go to the fix list, tiles with more than PB_TILE_FAIL_LIMIT of them (or
-// without a model) are marked failed.  counters: [0] fix pixels, [1] failed tiles, [2] pixels
-// differing in total (statistics), [3] tiles with a model.
+// without a model) are marked failed.  A LEAN tile whose pixels do not all satisfy the lean
+// invariants (non-negative offsets inside the window) loses the flag.  counters: [0] fix pixels,
+// [1] failed tiles, [2] pixels differing in total (statistics), [3] tiles with a model, [4] LEAN tiles.
 template <int SRC_KIND>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const PbParams P, PbTileEntry* __restrict__ table,
                                                                          int32_t* __restrict__ fail_tiles,
@@ -618,50 +645,44 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const Pb
     const int y = lane & 31, xh = (lane >> 5) * 16;
     const int i = Y0 + y;
     bool failed = (e->flags & PB_TILE_FAILED) != 0;
+    const bool lean = (e->flags & (PB_TILE_LEAN | PB_TILE_DIRECT)) != 0;
     unsigned diff = 0;  // bit k: pixel xh + k of this lane's row differs
     if (!failed) {
         PbRowModel R;
         pb_model_row(P, e, X0, Y0, y, xh, R);
-        int rmin = 0x7fffffff, rmax = -1, cmin = 0x7fffffff, cmax = -1;
+        bool lean_ok = true;
         for (int k = 0; k < 16; ++k) {
             const int j = X0 + xh + k;
             if (i < P.dst.height && j < P.dst.width) {
                 const int fast = pb_model_px<SRC_KIND>(P, R, xh, k);
-                if (fast >= 0) {
-                    const int r = fast / P.src.width, c = fast - r * P.src.width;
-                    rmin = min(rmin, r); rmax = max(rmax, r);
-                    cmin = min(cmin, c); cmax = max(cmax, c);
-                }
                 const int exact = pb_exact_index<SRC_KIND>(P, i, j);
                 diff |= (unsigned)(fast != exact) << k;
+                if (lean) {
+                    const pb_f2 f = pb_eval_row(R.a, pb_tile_coord(xh + k));
+                    lean_ok = lean_ok && f.x >= 0.0f && f.y >= 0.0f && (int)f.x < e->win_rows && (int)f.y < e->win_cols;
+                }
             }
         }
-        unsigned total = __popc(diff);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            total += __shfl_xor(total, o);
-            rmin = min(rmin, __shfl_xor(rmin, o)); rmax = max(rmax, __shfl_xor(rmax, o));
-            cmin = min(cmin, __shfl_xor(cmin, o)); cmax = max(cmax, __shfl_xor(cmax, o));
+        if (lean && __builtin_amdgcn_ballot_w64(!lean_ok) != 0) {
+            if (lane == 0) e->flags &= ~(PB_TILE_LEAN | PB_TILE_DIRECT);
+        } else if (lean && lane == 0) {
+            atomicAdd(&counters[(e->flags & PB_TILE_LEAN) ? 4 : 6], 1u);
         }
+        if (lane == 0 && (e->flags & PB_TILE_BLACK)) atomicAdd(&counters[5], 1u);
+        unsigned total = (unsigned)pb_wave_sum((int)__popc(diff));
         if (lane == 0) {
             atomicAdd(&counters[2], total);
             atomicAdd(&counters[3], 1u);
-            e->win_r0 = rmax < 0 ? 0 : rmin;
-            e->win_rows = rmax < 0 ? 0 : rmax - rmin + 1;
-            e->win_c0 = rmax < 0 ? 0 : cmin;
-            e->win_cols = rmax < 0 ? 0 : cmax - cmin + 1;
         }
         if (total > PB_TILE_FAIL_LIMIT) failed = true;
         if (!failed && total) {
-            // reserve `total` slots; if the list is full the tile is failed instead
             unsigned base = 0;
             if (lane == 0) base = atomicAdd(&counters[0], total);
             base = __shfl(base, 0);
             if (base + total > fix_capacity) {
                 failed = true;
             } else {
-                // exclusive prefix of per-lane counts
-                unsigned mine = __popc(diff), pre = mine;
+                unsigned mine = __popc(diff), pre = mine;  // inclusive prefix of per-lane counts
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
                     const unsigned t = __shfl_up(pre, o);

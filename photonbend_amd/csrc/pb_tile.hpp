@@ -26,16 +26,27 @@
 
 #define PB_TILE_HAS_MODEL 1
 #define PB_TILE_FAILED 2
+// LEAN: every pixel of the tile is a valid destination pixel whose sample lies inside the tile's source
+// window, the window fits the LDS budget, and the model is anchored at the window origin - so the hot
+// kernel needs no validity, bounds, wrap or fallback code for this tile (decided by the plan builder).
+#define PB_TILE_LEAN 4
+#define PB_TILE_DIRECT 16  // like LEAN (plain pixels, model anchored at the box origin) but the box is too sparse /
+                           // large to stage: samples are fetched with unaligned global loads, no LDS
+#define PB_TILE_BLACK 8  // every pixel of the tile (inside the image) is black: the hot kernel only stores zeros
+#define PB_LEAN_MAX_PASSES 24  // window rows / rows-per-load-instruction of a LEAN tile (register staging depth)
+
+typedef float pb_f2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(256))) PbTileEntry {
     int32_t anchor_r, anchor_c;  // integer anchors: coordinate = anchor + polynomial
     int32_t flags;
-    int32_t pad0;
-    float c[2][25];              // c[coord][m*5+n] multiplies v^m u^n  (v: rows, u: columns, both in [-1, 1])
-    // bounding box of the tile's source samples (the hot path's own values, found by the plan builder):
-    // rows [win_r0, win_r0 + win_rows), columns [win_c0, win_c0 + win_cols); win_rows == 0: none
-    int32_t win_r0, win_rows, win_c0, win_cols;
-    int32_t pad1[6];
+    int32_t win_rows;            // rows of the source window (after the LDS cap when LEAN)
+    float c[25][2];              // c[m*5+n] = (row, col) coefficient pair of v^m u^n  (v: rows, u: columns, in [-1, 1])
+    // source window = bounding box of the tile's samples (hot-path values, found by the plan builder):
+    // rows [win_r0, win_r0 + win_rows), columns [win_c0, win_c0 + win_cols); LEAN: origin == anchors
+    int32_t win_r0, win_c0, win_cols;
+    int32_t win_n16, win_a0;     // LEAN: 16-byte chunks per row, byte offset of column win_c0 in its first chunk
+    int32_t pad1[5];
 };
 static_assert(sizeof(PbTileEntry) == 256, "PbTileEntry must be 256 bytes");
 
@@ -74,29 +85,51 @@ __device__ __forceinline__ int pb_exact_index(const PbParams& P, int i, int j) {
 }
 
 // ---- the hot-path model evaluation (float32, bit-reproducible) ----------------------
+// Row and column coordinate are evaluated as one float2 (v_pk_fma_f32): same IEEE results as two
+// scalar fmaf chains, half the instructions.
+__device__ __forceinline__ pb_f2 pb_fma2(pb_f2 a, float b, pb_f2 c) {
+    const pb_f2 bb = {b, b};
+    return __builtin_elementwise_fma(a, bb, c);
+}
+
 struct PbRowModel {
-    float ar[5], ac[5];  // per-row collapsed coefficients (polynomials in u)
-    int va, vb, x2;      // validity window on x2^2 and the doubled x offset of the lane's first pixel
+    pb_f2 a[5];      // per-row collapsed coefficients (polynomials in u), (row, col) pairs
+    int va, vb, x2;  // validity window on x2^2 and the doubled x offset of the lane's first pixel
     int anchor_r, anchor_c;
 };
+
+__device__ __forceinline__ float pb_tile_coord(int t) {  // pixel offset 0..31 -> [-1, 1]
+    const float half = 0.5f * (PB_TILE - 1), inv_half = 1.0f / (0.5f * (PB_TILE - 1));
+    return ((float)t - half) * inv_half;
+}
+
+// collapse the tile model along v for row y (0..31): 5 float2 coefficients of the row polynomial in u
+__device__ __forceinline__ void pb_collapse_row(const PbTileEntry* __restrict__ e, int y, pb_f2 a[5]) {
+    const float v = pb_tile_coord(y);
+#pragma unroll
+    for (int n = 0; n < 5; ++n) {
+        pb_f2 s = {e->c[20 + n][0], e->c[20 + n][1]};
+#pragma unroll
+        for (int m = 3; m >= 0; --m) {
+            const pb_f2 cm = {e->c[m * 5 + n][0], e->c[m * 5 + n][1]};
+            s = pb_fma2(s, v, cm);
+        }
+        a[n] = s;
+    }
+}
+
+__device__ __forceinline__ pb_f2 pb_eval_row(const pb_f2 a[5], float u) {
+    pb_f2 f = a[4];
+#pragma unroll
+    for (int n = 3; n >= 0; --n) f = pb_fma2(f, u, a[n]);
+    return f;
+}
 
 // Collapses the tile model along v for the row `y` (0..31) of tile (X0, Y0) and prepares the
 // exact integer validity test of that row: invalid <=> va <= (x2 + 2k)^2 < vb.
 __device__ __forceinline__ void pb_model_row(const PbParams& P, const PbTileEntry* __restrict__ e, int X0, int Y0, int y,
                                              int xh, PbRowModel& R) {
-    const float half = 0.5f * (PB_TILE - 1), inv_half = 1.0f / (0.5f * (PB_TILE - 1));
-    const float v = ((float)y - half) * inv_half;
-#pragma unroll
-    for (int n = 0; n < 5; ++n) {
-        float s0 = e->c[0][20 + n], s1 = e->c[1][20 + n];
-#pragma unroll
-        for (int m = 3; m >= 0; --m) {
-            s0 = fmaf(s0, v, e->c[0][m * 5 + n]);
-            s1 = fmaf(s1, v, e->c[1][m * 5 + n]);
-        }
-        R.ar[n] = s0;
-        R.ac[n] = s1;
-    }
+    pb_collapse_row(e, y, R.a);
     R.anchor_r = e->anchor_r;
     R.anchor_c = e->anchor_c;
     R.va = 0x7fffffff;
@@ -115,48 +148,46 @@ __device__ __forceinline__ void pb_model_row(const PbParams& P, const PbTileEntr
     }
 }
 
+__device__ __forceinline__ bool pb_row_px_invalid(const PbRowModel& R, int k) {
+    const int xx = R.x2 + 2 * k, q = (int)__mul24(xx, xx);
+    return q >= R.va && q < R.vb;
+}
+
+// raw (unwrapped) source row / column of pixel x = xh + k of the row prepared in R
+__device__ __forceinline__ void pb_model_px_raw(const PbRowModel& R, int xh, int k, int& r, int& c, pb_f2& f) {
+    f = pb_eval_row(R.a, pb_tile_coord(xh + k));
+    r = R.anchor_r + (int)floorf(f.x);
+    c = R.anchor_c + (int)floorf(f.y);
+}
+
 // Source (row, col) of pixel x = xh + k packed as (r << 16 | c), or -1 = black.  Needs src dims < 32768.
 template <int SRC_KIND>
 __device__ __forceinline__ int pb_model_px_rc(const PbParams& P, const PbRowModel& R, int xh, int k) {
-    const float half = 0.5f * (PB_TILE - 1), inv_half = 1.0f / (0.5f * (PB_TILE - 1));
-    const float u = ((float)(xh + k) - half) * inv_half;
-    float fr = R.ar[4], fc = R.ac[4];
-#pragma unroll
-    for (int n = 3; n >= 0; --n) {
-        fr = fmaf(fr, u, R.ar[n]);
-        fc = fmaf(fc, u, R.ac[n]);
-    }
-    int r = R.anchor_r + (int)floorf(fr), c = R.anchor_c + (int)floorf(fc);
+    int r, c;
+    pb_f2 f;
+    pb_model_px_raw(R, xh, k, r, c, f);
     const int h = P.src.height, w = P.src.width;
     if (SRC_KIND == PB_KIND_PANO) {
-        if (r >= h) r -= h;
+        if (r >= h) r -= h;  // lat = pi wraps to row 0 (SURVEY 8 a-4)
         if (c >= w) c -= w;
     }
     int id = ((unsigned)r < (unsigned)h && (unsigned)c < (unsigned)w) ? ((r << 16) | c) : -1;
-    const int xx = R.x2 + 2 * k, q = (int)__mul24(xx, xx);
-    if (q >= R.va && q < R.vb) id = -1;
+    if (pb_row_px_invalid(R, k)) id = -1;  // invalid destination pixel -> black
     return id;
 }
 
 // Source index of pixel x = xh + k of the row prepared in R (or -1 = black).
 template <int SRC_KIND>
 __device__ __forceinline__ int pb_model_px(const PbParams& P, const PbRowModel& R, int xh, int k) {
-    const float half = 0.5f * (PB_TILE - 1), inv_half = 1.0f / (0.5f * (PB_TILE - 1));
-    const float u = ((float)(xh + k) - half) * inv_half;
-    float fr = R.ar[4], fc = R.ac[4];
-#pragma unroll
-    for (int n = 3; n >= 0; --n) {
-        fr = fmaf(fr, u, R.ar[n]);
-        fc = fmaf(fc, u, R.ac[n]);
-    }
-    int r = R.anchor_r + (int)floorf(fr), c = R.anchor_c + (int)floorf(fc);
+    int r, c;
+    pb_f2 f;
+    pb_model_px_raw(R, xh, k, r, c, f);
     const int h = P.src.height, w = P.src.width;
     if (SRC_KIND == PB_KIND_PANO) {
-        if (r >= h) r -= h;  // lat = pi wraps to row 0 (SURVEY 8 a-4)
+        if (r >= h) r -= h;
         if (c >= w) c -= w;
     }
     int id = ((unsigned)r < (unsigned)h && (unsigned)c < (unsigned)w) ? (int)__umul24(r, w) + c : -1;
-    const int xx = R.x2 + 2 * k, q = (int)__mul24(xx, xx);
-    if (q >= R.va && q < R.vb) id = -1;  // invalid destination pixel -> black
+    if (pb_row_px_invalid(R, k)) id = -1;
     return id;
 }

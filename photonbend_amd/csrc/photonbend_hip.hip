@@ -24,11 +24,11 @@ struct pb_plan {
     int mode = PB_MODE_AUTO;     // PB_MODE_AUTO / PB_MODE_FAITHFUL / PB_MODE_FAST
     int device = -1;             // device that owns the tables below
     int fast_ready = 0;          // models + fix list built and certified on `device`
-    int staged = getenv("PB_STAGED") ? atoi(getenv("PB_STAGED")) : 0;  // gather through LDS windows
+    int staged = getenv("PB_STAGED") ? atoi(getenv("PB_STAGED")) : 2;  // 2: LDS-window hot kernel (default); 0: direct-gather hot kernel
     PbTileEntry* table = nullptr;
     int32_t* fail_tiles = nullptr;
     int32_t* fix_px = nullptr;
-    unsigned n_tiles = 0, n_fail_tiles = 0, n_fix_px = 0;
+    unsigned n_tiles = 0, n_fail_tiles = 0, n_fix_px = 0, n_lean_tiles = 0, n_black_tiles = 0, n_direct_tiles = 0;
     long long diff_pixels = -1;  // pixels (outside failed tiles) where model and faithful index differed
 };
 
@@ -108,7 +108,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
     PbParams& P = pl->P;
     long long* scratch = nullptr;
     PB_HIP(hipGetDevice(&pl->device));
-    PB_HIP(hipMalloc((void**)&scratch, 8 * sizeof(long long)));
+    PB_HIP(hipMalloc((void**)&scratch, 12 * sizeof(long long)));
     int rc = PB_OK;
     do {
         if (P.dst.kind != PB_KIND_PANO) {
@@ -126,17 +126,22 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             hipMalloc((void**)&pl->fail_tiles, (size_t)ntiles * sizeof(int32_t)) != hipSuccess ||
             hipMalloc((void**)&pl->fix_px, (size_t)cap * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
         unsigned* counters = reinterpret_cast<unsigned*>(scratch + 4);
-        if (hipMemset(counters, 0, 4 * sizeof(unsigned)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+        if (hipMemset(counters, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = PB_ERR_HIP; break; }
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
         if (P.src.kind == PB_KIND_PANO) {
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table);
+            hipLaunchKernelGGL(pb_window_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters);
         } else {
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table);
+            hipLaunchKernelGGL(pb_window_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters);
         }
-        unsigned res[4] = {0, 0, 0, 0};
+        unsigned res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
+        pl->n_lean_tiles = res[4];
+        pl->n_black_tiles = res[5];
+        pl->n_direct_tiles = res[6];
         pl->n_fix_px = res[0] > cap ? cap : res[0];
         pl->n_fail_tiles = res[1];
         pl->diff_pixels = res[2];
@@ -170,13 +175,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
         else
             hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_CAMERA>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds);
     }
-    const bool staged = windowed || (OUT == 0 && pl->staged == 1 && P.src.width < 32768 && P.src.height < 32768);
-    if (staged && !windowed) {
-        if (P.src.kind == PB_KIND_PANO)
-            hipLaunchKernelGGL(pb_hot_staged_kernel<PB_KIND_PANO>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds);
-        else
-            hipLaunchKernelGGL(pb_hot_staged_kernel<PB_KIND_CAMERA>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds);
-    }
+    const bool staged = windowed;
     if (P.src.kind == PB_KIND_PANO) {
         if (!staged)
         hipLaunchKernelGGL((pb_hot_kernel<PB_KIND_PANO, OUT>), grid, block, getenv("PB_LDS_PAD") ? atoi(getenv("PB_LDS_PAD")) : 0, st, P, pl->table, src, dst, n_frames, ss, ds, idx_out);
@@ -331,6 +330,12 @@ __attribute__((visibility("default"))) int pb_debug_stamps(unsigned long long* o
 }
 #endif
 
+__attribute__((visibility("default"))) int pb_debug_copy_table(const pb_plan* plan, void* host, size_t bytes) {
+    if (!plan || !plan->table) return -1;
+    const size_t have = (size_t)plan->n_tiles * sizeof(PbTileEntry);
+    return hipMemcpy(host, plan->table, bytes < have ? bytes : have, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+
 int pb_plan_set_mode(pb_plan* plan, int mode) {
     if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
     if (mode < PB_MODE_AUTO || mode > PB_MODE_FAST) return pb_fail(PB_ERR_INVALID, "mode out of range");
@@ -338,7 +343,8 @@ int pb_plan_set_mode(pb_plan* plan, int mode) {
     return PB_OK;
 }
 
-int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats5, long long* thresholds4) {
+int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats7, long long* thresholds4) {
+    long long* stats5 = stats7;
     if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
     if (fast_path_enabled) *fast_path_enabled = pb_use_fast(plan) ? 1 : 0;
     if (stats5) {
@@ -346,7 +352,9 @@ int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats5,
         stats5[1] = plan->fast_ready ? (long long)plan->n_fail_tiles : -1;
         stats5[2] = plan->fast_ready ? (long long)plan->n_fix_px : -1;
         stats5[3] = plan->fast_ready ? plan->diff_pixels : -1;
-        stats5[4] = plan->fast_ready ? (long long)plan->n_tiles * (long long)sizeof(PbTileEntry) : 0;
+        stats5[4] = plan->fast_ready ? (long long)plan->n_lean_tiles : -1;
+        stats5[5] = plan->fast_ready ? (long long)plan->n_black_tiles : -1;
+        stats5[6] = plan->fast_ready ? (long long)plan->n_direct_tiles : -1;
     }
     if (thresholds4) {
         thresholds4[0] = plan->P.inv_lo[0];
