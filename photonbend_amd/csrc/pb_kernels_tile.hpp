@@ -32,9 +32,9 @@ __device__ __forceinline__ int pb_tiles_x(const PbParams& P) { return (P.dst.wid
 __device__ __forceinline__ int pb_tiles_y(const PbParams& P) { return (P.dst.height + PB_TILE - 1) / PB_TILE; }
 
 // block -> 2x2 group of tiles; wave -> tile.  Returns false for waves beyond the image.
-__device__ __forceinline__ bool pb_tile_of_wave(const PbParams& P, int wave, int& tx, int& ty) {
+__device__ __forceinline__ bool pb_tile_of_wave(const PbParams& P, int wave, int& tx, int& ty, unsigned block = blockIdx.x) {
     const int gx = (pb_tiles_x(P) + 1) / 2;
-    const int by = blockIdx.x / gx, bx = blockIdx.x - by * gx;
+    const int by = (int)block / gx, bx = (int)block - by * gx;
     tx = 2 * bx + (wave & 1);
     ty = 2 * by + (wave >> 1);
     return tx < pb_tiles_x(P) && ty < pb_tiles_y(P);
@@ -217,22 +217,13 @@ __device__ __forceinline__ void pb_issue_window_loads(const uint8_t* __restrict_
     }
 }
 
+// One tile of the windowed hot kernel (the four tile classes); returns when the tile's pixels are stored.
 template <int SRC_KIND>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
-                                                                         const uint8_t* __restrict__ src,
-                                                                         uint8_t* __restrict__ dst, int n_frames,
-                                                                         unsigned long long src_stride,
-                                                                         unsigned long long dst_stride) {
-    __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 4];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int tx, ty;
-    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
-    const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
-    const int flags = e->flags;
-    if (flags & PB_TILE_FAILED) return;
+__device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry* __restrict__ e, const int flags, const int tx,
+                                            const int ty, const int lane, unsigned* win, const uint8_t* __restrict__ src,
+                                            uint8_t* __restrict__ dst, const int n_frames, const unsigned long long src_stride,
+                                            const unsigned long long dst_stride) {
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
-    unsigned* win = win_all[wave];
     const unsigned rowbytes = 3u * (unsigned)P.src.width;
     const unsigned frame_bytes = rowbytes * (unsigned)P.src.height;   // < 2^31 (host check)
     const unsigned safe_len = frame_bytes & ~15u;                     // every 16-byte chunk below this is loadable
@@ -434,6 +425,63 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
     }
 }
 
+template <int SRC_KIND>
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
+                                                                         const uint8_t* __restrict__ src,
+                                                                         uint8_t* __restrict__ dst, int n_frames,
+                                                                         unsigned long long src_stride,
+                                                                         unsigned long long dst_stride, unsigned fail_blocks,
+                                                                         const int32_t* __restrict__ fail_tiles,
+                                                                         const int32_t* __restrict__ fix_px) {
+    __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 4];
+    if (blockIdx.x < fail_blocks) {
+        // leading blocks: the plan's failed tiles, 256 pixels per block, faithful chain (slow, so they are
+        // dispatched first).  They write pixels no hot wave touches and run next to the hot blocks.
+        const unsigned b = blockIdx.x;
+        const int t = fail_tiles[b >> 2];
+        const int fty = t / pb_tiles_x(P), ftx = t - fty * pb_tiles_x(P);
+        const int local = (int)(b & 3u) * 256 + (int)threadIdx.x;
+        const int i = fty * PB_TILE + (local >> 5), j = ftx * PB_TILE + (local & 31);
+        if (i >= P.dst.height || j >= P.dst.width) return;
+        const int id = pb_exact_index<SRC_KIND>(P, i, j);
+        const size_t p = (size_t)i * P.dst.width + j;
+        for (int f = 0; f < n_frames; ++f) {
+            const unsigned v = pb_load_px(src + (unsigned long long)f * src_stride, id);
+            uint8_t* o = dst + (unsigned long long)f * dst_stride + 3 * p;
+            o[0] = (uint8_t)(v & 0xFF);
+            o[1] = (uint8_t)((v >> 8) & 0xFF);
+            o[2] = (uint8_t)((v >> 16) & 0xFF);
+        }
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tx, ty;
+    if (!pb_tile_of_wave(P, wave, tx, ty, blockIdx.x - fail_blocks)) return;
+    const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
+    const int flags = e->flags;
+    if (flags & PB_TILE_FAILED) return;
+    pb_win_tile<SRC_KIND>(P, e, flags, tx, ty, lane, win_all[wave], src, dst, n_frames, src_stride, dst_stride);
+    // this tile's fix pixels (where the model's truncation differs from the faithful one): one faithful
+    // evaluation per listed pixel, stored after the wave's own stores have completed
+    const int n_fix = fix_px ? e->fix_cnt : 0;  // null list: the fix kernel takes the pixels
+    if (n_fix > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < n_fix) {
+            const unsigned p = (unsigned)fix_px[e->fix_off + lane];
+            const int i = (int)(p / (unsigned)P.dst.width), j = (int)(p - (unsigned)i * (unsigned)P.dst.width);
+            const int id = pb_exact_index<SRC_KIND>(P, i, j);
+            for (int f = 0; f < n_frames; ++f) {
+                const unsigned v = pb_load_px(src + (unsigned long long)f * src_stride, id);
+                uint8_t* o = dst + (unsigned long long)f * dst_stride + 3ull * p;
+                o[0] = (uint8_t)(v & 0xFF);
+                o[1] = (uint8_t)((v >> 8) & 0xFF);
+                o[2] = (uint8_t)((v >> 16) & 0xFF);
+            }
+        }
+    }
+}
+
 // The plan's fix list: blocks [0, 4 * n_fail_tiles) take the failed tiles (256 px each), the
 // remaining blocks take single pixels (linear output positions).
 template <int SRC_KIND, int OUT>
@@ -548,6 +596,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_model_kernel(const PbPa
         e->flags = any_bad ? PB_TILE_FAILED : PB_TILE_HAS_MODEL;
         e->win_rows = 0;
         e->win_r0 = e->win_c0 = e->win_cols = e->win_n16 = e->win_a0 = 0;
+        e->fix_off = e->fix_cnt = 0;
     }
 }
 
@@ -691,6 +740,10 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const Pb
                 unsigned pos = base + pre - mine;
                 for (int k = 0; k < 16; ++k)
                     if (diff & (1u << k)) fix_px[pos++] = i * P.dst.width + (X0 + xh + k);
+                if (lane == 0) {
+                    e->fix_off = (int)base;
+                    e->fix_cnt = (int)total;
+                }
             }
         }
     }

@@ -46,7 +46,8 @@ struct __attribute__((aligned(256))) PbTileEntry {
     // rows [win_r0, win_r0 + win_rows), columns [win_c0, win_c0 + win_cols); LEAN: origin == anchors
     int32_t win_r0, win_c0, win_cols;
     int32_t win_n16, win_a0;     // LEAN: 16-byte chunks per row, byte offset of column win_c0 in its first chunk
-    int32_t pad1[5];
+    int32_t fix_off, fix_cnt;    // this tile's slice of the plan's fix-pixel list (<= PB_TILE_FAIL_LIMIT entries)
+    int32_t pad1[3];
 };
 static_assert(sizeof(PbTileEntry) == 256, "PbTileEntry must be 256 bytes");
 

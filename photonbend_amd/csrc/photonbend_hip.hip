@@ -170,10 +170,28 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
     const bool windowed = OUT == 0 && pl->staged == 2 && P.src.width < 32768 && P.src.height < 32768 &&
                           ((((uintptr_t)src) | ss) & 15u) == 0;
     if (windowed) {
-        if (P.src.kind == PB_KIND_PANO)
-            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_PANO>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds);
-        else
-            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_CAMERA>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds);
+        // hot blocks apply their own tiles' fix pixels; a handful of failed tiles ride along as leading
+        // blocks of the same launch, many failed tiles get their own (high-occupancy) launch afterwards
+        // (a faithful evaluation costs microseconds of latency: worth hiding inside the hot launch only
+        // when few waves have to do it)
+        const bool fused = pl->n_fail_tiles <= 64 && pl->n_fix_px <= 2048;
+        const unsigned lead = fused ? 4u * pl->n_fail_tiles : 0u;
+        const unsigned fix_blocks_w = 4u * pl->n_fail_tiles + (pl->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
+        const dim3 wgrid(grid.x + lead);
+        if (P.src.kind == PB_KIND_PANO) {
+            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_PANO>, wgrid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds,
+                               lead, pl->fail_tiles, fused ? pl->fix_px : nullptr);
+            if (!fused && fix_blocks_w)
+                hipLaunchKernelGGL((pb_fix_kernel<PB_KIND_PANO, 0>), dim3(fix_blocks_w), dim3(PB_BLOCK), 0, st, P, pl->fail_tiles,
+                                   (int)pl->n_fail_tiles, pl->fix_px, (int)pl->n_fix_px, src, dst, n_frames, ss, ds, idx_out);
+        } else {
+            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_CAMERA>, wgrid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds,
+                               lead, pl->fail_tiles, fused ? pl->fix_px : nullptr);
+            if (!fused && fix_blocks_w)
+                hipLaunchKernelGGL((pb_fix_kernel<PB_KIND_CAMERA, 0>), dim3(fix_blocks_w), dim3(PB_BLOCK), 0, st, P, pl->fail_tiles,
+                                   (int)pl->n_fail_tiles, pl->fix_px, (int)pl->n_fix_px, src, dst, n_frames, ss, ds, idx_out);
+        }
+        return;
     }
     const bool staged = windowed;
     if (P.src.kind == PB_KIND_PANO) {
