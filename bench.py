@@ -55,19 +55,24 @@ def c2_objects():
     return dst._proj(), src_proj
 
 
-def cpu_baseline(frames: int = 2):
-    """The oracle (kind 'port') on this host's cores: `frames` full c2 frames."""
+def cpu_baseline(min_seconds: float = 12.0, max_frames: int = 40):
+    """The oracle (kind 'port') on this host's cores: full c2 frames until about
+    `min_seconds` of CPU work have been timed (a bounded sample of the workload)."""
     from oracle import reference_path as orc  # CPU baseline leg only
     from oracle.synth import synth_frame
 
     fov = orc.to_radians(360)
     d = orc.Proj("camera", DST, DST, "equidistant", fov, DST / 2 - 0.5)
     s = orc.Proj("pano", SRC_H, SRC_W)
-    imgs = [synth_frame(SRC_H, SRC_W, frame=f) for f in range(frames)]
+    imgs = [synth_frame(SRC_H, SRC_W, frame=f) for f in range(2)]
+    frames = 0
     t0 = time.perf_counter()
-    for img in imgs:
-        out = orc.remap(d, s, img)
-    dt = time.perf_counter() - t0
+    while True:
+        out = orc.remap(d, s, imgs[frames % 2])
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds or frames >= max_frames:
+            break
     assert out.shape == (DST, DST, 3)
     return {
         "value": round(frames * MPX_PER_FRAME / dt, 3),
@@ -193,7 +198,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32 tile models + f64 plan/fix chain",
             "data": "synthetic",
             "config": {
                 "workload": "c2: one 8192x4096 equirectangular frame -> 4096x4096 equidistant-360 inscribed per step",
@@ -211,7 +216,8 @@ def main():
                 "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES,
                 "kernel_ms_mean": round(kern_ms, 5) if kern_ms else None,
                 "kernel_ms_median": round(kern_med, 5) if kern_ms else None,
-                "timing": "per-launch hipEvent pairs on the launch stream" if use_events else "wall / steps",
+                "timing": "per-launch hipEvent pairs on the launch stream (one pb_remap_u8 call = hot kernel incl. its fix work)" if use_events else "wall / steps",
+                "plan": plan.info(),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

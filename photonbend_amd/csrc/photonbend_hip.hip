@@ -348,11 +348,13 @@ __attribute__((visibility("default"))) int pb_debug_stamps(unsigned long long* o
 }
 #endif
 
+#ifdef PB_STAMPS
 __attribute__((visibility("default"))) int pb_debug_copy_table(const pb_plan* plan, void* host, size_t bytes) {
     if (!plan || !plan->table) return -1;
     const size_t have = (size_t)plan->n_tiles * sizeof(PbTileEntry);
     return hipMemcpy(host, plan->table, bytes < have ? bytes : have, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
+#endif
 
 int pb_plan_set_mode(pb_plan* plan, int mode) {
     if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");

@@ -1,0 +1,86 @@
+"""Plan behaviour on the GPU: the fast path (tile models + fix list) and the faithful path produce the
+same bytes; plan statistics are sane; batches, strides and unaligned frames take the right kernels."""
+
+import numpy as np
+import pytest
+import torch
+
+from photonbend_amd import _native as nat
+from tests import helpers as H
+from tests.cases import Case, cam, case_by_name, inscribed, pano, small_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plan_info_and_modes_c2_like():
+    case = Case("mid", cam(1024, 1024, "equidistant", 360, inscribed(1024)), pano(1024, 2048))
+    plan = H.pb_plan(case)
+    info = plan.info()
+    assert info["fast_path"] and info["tiles"] == 32 * 32
+    assert 0 <= info["fix_tiles"] <= 16 and 0 <= info["fix_pixels"] < 1024 * 1024 // 100
+    assert info["lean_tiles"] + info["direct_tiles"] + info["black_tiles"] + info["fix_tiles"] <= info["tiles"]
+    assert info["lean_tiles"] > info["tiles"] // 3 and info["black_tiles"] > 0
+    # thresholds: invalid <=> lo <= (2x)^2+(2y)^2 < hi; the inscribed circle of diameter 1023 px is valid
+    lo, hi = info["thresholds"][:2]
+    assert 1023 * 1023 <= lo <= 1023 * 1023 + 4 * 1024 and hi > lo
+    frame = nat.synth_frame(1024, 2048, frame=3)
+    outs = {}
+    for mode in (nat.MODE_FAITHFUL, nat.MODE_FAST, nat.MODE_AUTO):
+        plan.set_mode(mode)
+        assert plan.info()["fast_path"] == (mode != nat.MODE_FAITHFUL)
+        outs[mode] = (plan.remap(frame).clone(), plan.index_map().clone())
+    for mode in (nat.MODE_FAST, nat.MODE_AUTO):
+        assert torch.equal(outs[mode][0], outs[nat.MODE_FAITHFUL][0])
+        assert torch.equal(outs[mode][1], outs[nat.MODE_FAITHFUL][1])
+
+
+@pytest.mark.parametrize("name", ["A_photo_odd", "C_alter_eqd_eqs_rot", "B_pano_equisolid_360", "D_pano_chain", "E_double_dst_rot"])
+def test_fast_equals_faithful_small(name):
+    case = case_by_name(name)
+    plan = H.pb_plan(case)
+    frame = torch.from_numpy(H.case_frame(case)).cuda()
+    plan.set_mode(nat.MODE_FAITHFUL)
+    ref = plan.remap(frame).clone()
+    plan.set_mode(nat.MODE_FAST)
+    assert torch.equal(plan.remap(frame), ref)
+
+
+def test_unaligned_frames_and_strided_batches():
+    """Frame pointers that are not 16-byte aligned take the direct-gather hot kernel + fix kernel; the
+    bytes must not change.  Same for a batch addressed through explicit strides."""
+    import ctypes
+
+    case = Case("mid", cam(512, 512, "equisolid", 200, inscribed(512)), pano(512, 1024), [(10, 20, 30)])
+    plan = H.pb_plan(case)
+    n_src, n_dst = 512 * 1024 * 3, 512 * 512 * 3
+    frames = [nat.synth_frame(512, 1024, frame=f) for f in range(3)]
+    want = [plan.remap(f).clone() for f in frames]
+    lib = nat.load()
+    # 1) source frame at an odd byte offset, destination at an offset of 4 (store alignment kept) and of 1
+    for s_off, d_off in ((1, 4), (16, 1), (7, 3)):
+        sbuf = torch.zeros(n_src + 64, dtype=torch.uint8, device="cuda")
+        dbuf = torch.zeros(n_dst + 64, dtype=torch.uint8, device="cuda")
+        sbuf[s_off : s_off + n_src] = frames[0].reshape(-1)
+        nat.check(lib.pb_remap_u8(plan.handle, sbuf.data_ptr() + s_off, dbuf.data_ptr() + d_off, 1, 0, 0, nat.current_stream()))
+        assert torch.equal(dbuf[d_off : d_off + n_dst].reshape(512, 512, 3), want[0]), (s_off, d_off)
+        assert int(dbuf[:d_off].sum()) == 0 and int(dbuf[d_off + n_dst :].sum()) == 0  # nothing written outside
+    # 2) batch of 3 with padded strides (multiples of 16 -> windowed kernel; odd -> direct kernel)
+    for pad in (48, 5):
+        ss, ds = n_src + pad, n_dst + pad
+        sbuf = torch.zeros(3 * ss + 64, dtype=torch.uint8, device="cuda")
+        dbuf = torch.zeros(3 * ds + 64, dtype=torch.uint8, device="cuda")
+        for f in range(3):
+            sbuf[f * ss : f * ss + n_src] = frames[f].reshape(-1)
+        nat.check(lib.pb_remap_u8(plan.handle, sbuf.data_ptr(), dbuf.data_ptr(), 3, ss, ds, nat.current_stream()))
+        for f in range(3):
+            assert torch.equal(dbuf[f * ds : f * ds + n_dst].reshape(512, 512, 3), want[f]), (pad, f)
+            assert int(dbuf[f * ds + n_dst : (f + 1) * ds].sum()) == 0
+
+
+def test_every_small_case_has_consistent_plan_stats():
+    for case in small_cases():
+        info = H.pb_plan(case).info()
+        if case.src[0] == "double":
+            assert not info["fast_path"]
+        else:
+            assert info["fast_path"] and info["tiles"] > 0 and info["fix_pixels"] >= 0
