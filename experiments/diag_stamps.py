@@ -27,3 +27,4 @@ waves = info['lean_tiles'] * N
 print('us/frame %.1f' % (e0.elapsed_time(e1) * 1e3 / N))
 names = ['issue window loads', 'model math', 'wait loads landed', 'gather (LDS) + issue stores', 'wait stores']
 for n, v in zip(names, buf): print('  %-30s %8.0f cycles/wave' % (n, v / waves))
+print('  whole tile: lean %.0f cyc x %d, direct %.0f cyc x %d, other(black+generic) %.0f cyc x %d' % (buf[5] / max(1, info['lean_tiles'] * N), info['lean_tiles'], buf[6] / max(1, info['direct_tiles'] * N), info['direct_tiles'], buf[7] / max(1, (info['tiles'] - info['lean_tiles'] - info['direct_tiles'] - info['fix_tiles']) * N), info['tiles'] - info['lean_tiles'] - info['direct_tiles'] - info['fix_tiles']))

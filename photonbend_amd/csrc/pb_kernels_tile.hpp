@@ -461,7 +461,20 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
     const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
     const int flags = e->flags;
     if (flags & PB_TILE_FAILED) return;
+#ifdef PB_STAMPS
+    unsigned long long tw0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tw0) :: "memory");
+#endif
     pb_win_tile<SRC_KIND>(P, e, flags, tx, ty, lane, win_all[wave], src, dst, n_frames, src_stride, dst_stride);
+#ifdef PB_STAMPS
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long tw1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tw1) :: "memory");
+        const int cls = (flags & PB_TILE_LEAN) ? 5 : ((flags & PB_TILE_DIRECT) ? 6 : 7);
+        if (lane == 0) pb_stamp_acc[(size_t)(ty * pb_tiles_x(P) + tx) * 8 + cls] += tw1 - tw0;
+    }
+#endif
     // this tile's fix pixels (where the model's truncation differs from the faithful one): one faithful
     // evaluation per listed pixel, stored after the wave's own stores have completed
     const int n_fix = fix_px ? e->fix_cnt : 0;  // null list: the fix kernel takes the pixels

@@ -18,6 +18,7 @@
 #include "pb_kernels_faithful.hpp"
 #include "pb_tile.hpp"
 #include "pb_kernels_tile.hpp"
+#include "pb_kernels_sep.hpp"
 
 struct pb_plan {
     PbParams P;
@@ -30,6 +31,10 @@ struct pb_plan {
     int32_t* fix_px = nullptr;
     unsigned n_tiles = 0, n_fail_tiles = 0, n_fix_px = 0, n_lean_tiles = 0, n_black_tiles = 0, n_direct_tiles = 0;
     long long diff_pixels = -1;  // pixels (outside failed tiles) where model and faithful index differed
+    // separable path (double source, unrotated pano destination): row / column tables
+    int sep_ready = 0;
+    PbSepRow* sep_rows = nullptr;
+    PbSepCol* sep_cols = nullptr;
 };
 
 static thread_local std::string g_err;
@@ -119,6 +124,22 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             P.inv_lo[1] = thr[2]; P.inv_hi[1] = thr[3];
         }
         P.thresholds_ready = 1;
+        if (P.src.kind == PB_KIND_DOUBLE && P.dst.kind == PB_KIND_PANO && P.n_rot == 0) {
+            // separable path: tables + exhaustive check against the faithful taps
+            if (hipMalloc((void**)&pl->sep_rows, (size_t)P.dst.height * sizeof(PbSepRow)) != hipSuccess ||
+                hipMalloc((void**)&pl->sep_cols, (size_t)P.dst.width * sizeof(PbSepCol)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            unsigned* bad = reinterpret_cast<unsigned*>(scratch + 4);
+            if (hipMemset(bad, 0, sizeof(unsigned)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            hipLaunchKernelGGL(pb_sep_tables_kernel, dim3(pb_blocks((unsigned long long)P.dst.height + P.dst.width)), dim3(PB_BLOCK), 0, 0,
+                               P, pl->sep_rows, pl->sep_cols);
+            hipLaunchKernelGGL(pb_sep_check_kernel, dim3(pb_blocks((unsigned long long)P.dst.height * P.dst.width)), dim3(PB_BLOCK), 0,
+                               0, P, pl->sep_rows, pl->sep_cols, bad);
+            unsigned nbad = 1;
+            if (hipMemcpy(&nbad, bad, sizeof(nbad), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            pl->sep_ready = nbad == 0;
+            pl->diff_pixels = nbad;
+            break;
+        }
         if (!pb_fast_possible(P)) break;
         const unsigned ntiles = pb_num_tiles(P);
         const unsigned cap = ntiles * PB_TILE_FAIL_LIMIT;
@@ -151,7 +172,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
     if (rc != PB_OK) {
         g_err = std::string("plan preparation on device failed: ") + hipGetErrorString(hipGetLastError());
         (void)hipFree(pl->table); (void)hipFree(pl->fail_tiles); (void)hipFree(pl->fix_px);
-        pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr;
+        (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols);
+        pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr; pl->sep_rows = nullptr; pl->sep_cols = nullptr;
     }
     (void)hipFree(scratch);
     return rc;
@@ -278,6 +300,8 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->table);
     (void)hipFree(plan->fail_tiles);
     (void)hipFree(plan->fix_px);
+    (void)hipFree(plan->sep_rows);
+    (void)hipFree(plan->sep_cols);
     delete plan;
 }
 
@@ -305,7 +329,10 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
     if (!dst_frame_stride) dst_frame_stride = 3ull * npx;
     if (dst_frame_stride < 3ull * npx) return pb_fail(PB_ERR_INVALID, "dst_frame_stride smaller than a frame");
     hipStream_t st = (hipStream_t)stream;
-    if (pb_use_fast(plan)) {
+    if (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL) {
+        hipLaunchKernelGGL(pb_sep_double_kernel, dim3(pb_hot_blocks(P)), dim3(64 * PB_TILE_WAVES), 0, st, P, plan->sep_rows, plan->sep_cols,
+                           src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
+    } else if (pb_use_fast(plan)) {
         pb_launch_fast<0>(plan, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride, nullptr, st);
     } else if (P.src.kind == PB_KIND_PANO) {
         pb_launch_faithful_remap<PB_KIND_PANO>(P, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride, st);
@@ -366,7 +393,7 @@ int pb_plan_set_mode(pb_plan* plan, int mode) {
 int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats7, long long* thresholds4) {
     long long* stats5 = stats7;
     if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
-    if (fast_path_enabled) *fast_path_enabled = pb_use_fast(plan) ? 1 : 0;
+    if (fast_path_enabled) *fast_path_enabled = (pb_use_fast(plan) || (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL)) ? 1 : 0;
     if (stats5) {
         stats5[0] = plan->fast_ready ? (long long)plan->n_tiles : -1;
         stats5[1] = plan->fast_ready ? (long long)plan->n_fail_tiles : -1;
