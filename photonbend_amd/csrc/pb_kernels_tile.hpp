@@ -33,7 +33,17 @@ __device__ __forceinline__ int pb_tiles_y(const PbParams& P) { return (P.dst.hei
 
 // block -> 2x2 group of tiles; wave -> tile.  Returns false for waves beyond the image.
 __device__ __forceinline__ bool pb_tile_of_wave(const PbParams& P, int wave, int& tx, int& ty, unsigned block = blockIdx.x) {
-    const int gx = (pb_tiles_x(P) + 1) / 2;
+    const int gx = (pb_tiles_x(P) + 1) / 2, gy = (pb_tiles_y(P) + 1) / 2;
+    // XCD-aware order (speed only): blocks with equal id % 8 share an XCD and its L2 (observed round-robin
+    // dispatch), and neighbouring tiles share source lines - so each XCD gets whole 4x4-block super-tiles
+    // (256x256 px), super-tiles dealt round-robin over the XCDs to keep them balanced.
+    if (P.pad0 == 0 && (gx & 3) == 0 && (gy & 3) == 0 && ((gx * gy) & 127) == 0) {
+        const unsigned xcd = block & 7u, slot = block >> 3;
+        const unsigned S = (slot >> 4) * 8u + xcd, inner = slot & 15u;   // super-tile id, block inside it
+        const unsigned sgx = (unsigned)gx >> 2;
+        const unsigned sy = S / sgx, sx = S - sy * sgx;
+        block = (sy * 4u + (inner >> 2)) * (unsigned)gx + sx * 4u + (inner & 3u);
+    }
     const int by = (int)block / gx, bx = (int)block - by * gx;
     tx = 2 * bx + (wave & 1);
     ty = 2 * by + (wave >> 1);
@@ -193,7 +203,7 @@ __device__ __forceinline__ pb_u32x3 pb_pack_px4(unsigned a0, unsigned a1, unsign
 //   Other tiles: generic path - validity thresholds, wrap, per-pixel "inside the window" test with an
 //   unaligned global load as fallback.
 // Requires frame pointers and strides that are multiples of 16 bytes (else pb_hot_kernel is used).
-#define PB_WINLDS_BYTES 20224
+#define PB_WINLDS_BYTES 12288
 #ifdef PB_STAMPS
 __device__ unsigned long long pb_stamp_acc[65536 * 8];
 #define PB_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) pb_stamp_acc[(size_t)(ty * pb_tiles_x(P) + tx) * 8 + i] += t_ - t_prev; t_prev = t_; } while (0)
