@@ -99,18 +99,26 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # one rank per GPU; PB_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the multi-rank code
+    # path on a one-GPU box (ranks then share a device and the collectives run over gloo on CPU tensors)
+    backend = os.environ.get("PB_DIST_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
 
     # rank 0 owns the parameters; everyone else receives the block over RCCL
     block = None
     if rank == 0:
         d, s = c2_objects()
         block = parallel.pack_params(d, [], s)
-    block = parallel.broadcast_params(block, device=device, src=0)
+    block = parallel.broadcast_params(block, device=coll_device, src=0)
     d, rots, s = parallel.unpack_params(block)
     plan = nat.Plan(d, rots, s)
 
@@ -168,7 +176,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
 
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
