@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_sep_double_kernel(const
             if (y < H) {
                 const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
                 if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
-                    *reinterpret_cast<pb_u32x3*>(d + off) = pb_pack_px4(a[0], a[1], a[2], a[3]);
+                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)

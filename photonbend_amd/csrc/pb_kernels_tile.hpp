@@ -288,7 +288,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             for (int jr = 0; jr < 4; ++jr) {
                 const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
                 if ((((uintptr_t)d + off) & 3u) == 0) {
-                    *reinterpret_cast<pb_u32x3*>(d + off) = pb_pack_px4(a[jr][0], a[jr][1], a[jr][2], a[jr][3]);
+                    __builtin_nontemporal_store(pb_pack_px4(a[jr][0], a[jr][1], a[jr][2], a[jr][3]), reinterpret_cast<pb_u32x3*>(d + off));
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -344,7 +344,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
                 // LEAN tiles lie fully inside the image; the 12-byte store is 4-byte aligned when the base is
                 const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
                 if ((((uintptr_t)d + off) & 3u) == 0) {
-                    *reinterpret_cast<pb_u32x3*>(d + off) = pb_pack_px4(a[0], a[1], a[2], a[3]);
+                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));  // write-once output: keep it out of the source's cache space
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -419,7 +419,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             if (y < H) {
                 const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
                 if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
-                    *reinterpret_cast<pb_u32x3*>(d + off) = pb_pack_px4(a[0], a[1], a[2], a[3]);
+                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));  // write-once output: keep it out of the source's cache space
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
