@@ -48,6 +48,28 @@ def _shape_hw(image) -> tuple:
     return int(shp[0]), int(shp[1])
 
 
+_PINNED: dict = {}
+
+
+def _pinned(shape, dtype, slot: str) -> torch.Tensor:
+    """A cached page-locked staging buffer (pageable copies run at a fraction of PCIe speed)."""
+    key = (tuple(shape), dtype, slot)
+    buf = _PINNED.get(key)
+    if buf is None:
+        if len(_PINNED) >= 8:
+            _PINNED.clear()
+        buf = _PINNED[key] = torch.empty(tuple(shape), dtype=dtype).pin_memory()
+    return buf
+
+
+def _to_host(t: torch.Tensor) -> np.ndarray:
+    """Device tensor -> fresh ndarray (the reference returns freshly allocated arrays) via pinned staging."""
+    stage = _pinned(t.shape, t.dtype, "d2h")
+    stage.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return stage.numpy().copy()
+
+
 def _device_image(image, height: int, width: int) -> torch.Tensor:
     """uint8 CUDA tensor (h, w, 3) of the pixels behind ``.image``."""
     nat.require_gpu()
@@ -61,7 +83,11 @@ def _device_image(image, height: int, width: int) -> torch.Tensor:
         a = np.asarray(image)
         if a.dtype != np.uint8:
             raise TypeError(f"images are uint8 (H, W, 3) RGB arrays (core/__init__.py:31-36), got {a.dtype}")
-        t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        if tuple(a.shape) != (height, width, 3):
+            raise ValueError(f"image must have shape ({height}, {width}, 3), got {tuple(a.shape)}")
+        stage = _pinned(a.shape, torch.uint8, "h2d")
+        stage.numpy()[...] = a
+        t = stage.to("cuda", non_blocking=True)
     if tuple(t.shape) != (height, width, 3):
         raise ValueError(f"image must have shape ({height}, {width}, 3), got {tuple(t.shape)}")
     return t.contiguous()
@@ -104,12 +130,12 @@ class _GpuProjection:
             out = plan.remap(img)
             if src.kind == nat.KIND_PANO:
                 coordinate_map.note_invalid_zeroed()  # projection.py:534-536
-            return out if on_device else out.cpu().numpy()
+            return out if on_device else _to_host(out)
         if isinstance(coordinate_map, torch.Tensor):
             if not (coordinate_map.is_cuda and coordinate_map.dtype == torch.float64 and coordinate_map.is_contiguous()):
                 raise TypeError("tensor coordinate maps must be contiguous float64 CUDA tensors")
             out = nat.sample_map(src, coordinate_map, img)
-            return out if on_device else out.cpu().numpy()
+            return out if on_device else _to_host(out)
         host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
         if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
             raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
@@ -117,7 +143,7 @@ class _GpuProjection:
         out = nat.sample_map(src, dev, img)
         if src.kind == nat.KIND_PANO:
             host[...] = dev.cpu().numpy()  # the in-place zeroing of invalid pixels
-        return out if on_device else out.cpu().numpy()
+        return out if on_device else _to_host(out)
 
 
 def _builtin_lens_id(lens: Lens) -> int:
