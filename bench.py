@@ -173,8 +173,11 @@ def main():
     else:
         for k in range(K):
             step(k)
-    sync_all()
+    # closing bracket: this rank's clock stops when ITS device has drained; the barrier follows and the
+    # MAX over ranks is what gets reported, so no rank's time hides behind another's barrier latency
+    torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
+    sync_all()
 
     t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
     if world > 1:

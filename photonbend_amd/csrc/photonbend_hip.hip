@@ -323,6 +323,11 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
     if (!plan || !src_dev || !dst_dev) return pb_fail(PB_ERR_INVALID, "null argument");
     if (n_frames < 0) return pb_fail(PB_ERR_INVALID, "negative frame count");
     if (n_frames == 0) return PB_OK;
+    if (plan->device >= 0) {  // the plan's tables live on the device it was created on
+        int dev = -1;
+        PB_HIP(hipGetDevice(&dev));
+        if (dev != plan->device) return pb_fail(PB_ERR_INVALID, "plan was prepared on another device; create one plan per device");
+    }
     const PbParams& P = plan->P;
     const unsigned long long npx = (unsigned long long)P.dst.height * P.dst.width;
     if (!src_frame_stride) src_frame_stride = 3ull * P.src.height * P.src.width;
