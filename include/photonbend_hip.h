@@ -103,6 +103,7 @@ void pb_plan_destroy(pb_plan* plan);
 #define PB_MODE_AUTO 0
 #define PB_MODE_FAITHFUL 1
 #define PB_MODE_FAST 2
+#define PB_MODE_FAST_DIRECT 3 /* FAST, but always the direct-gather hot kernel + fix kernel (the path of unaligned frames) */
 int pb_plan_set_mode(pb_plan* plan, int mode);
 /* fast_path_enabled: 0/1 under the current mode; stats7: {32x32 tiles, tiles handled whole by the
  * fix kernel, single pixels on the fix list, pixels where model and faithful index differed,

@@ -19,7 +19,7 @@ import torch  # noqa: F401  (must precede the CDLL below - see module docstring)
 from .build import LIB_PATH
 
 PB_MAX_ROTATIONS = 8
-MODE_AUTO, MODE_FAITHFUL, MODE_FAST = 0, 1, 2
+MODE_AUTO, MODE_FAITHFUL, MODE_FAST, MODE_FAST_DIRECT = 0, 1, 2, 3
 KIND_CAMERA, KIND_DOUBLE, KIND_PANO = 0, 1, 2
 LENS_IDS = {
     "equidistant": 0,

@@ -37,7 +37,7 @@ __device__ __forceinline__ bool pb_tile_of_wave(const PbParams& P, int wave, int
     // XCD-aware order (speed only): blocks with equal id % 8 share an XCD and its L2 (observed round-robin
     // dispatch), and neighbouring tiles share source lines - so each XCD gets whole 4x4-block super-tiles
     // (256x256 px), super-tiles dealt round-robin over the XCDs to keep them balanced.
-    if (P.pad0 == 0 && (gx & 3) == 0 && (gy & 3) == 0 && ((gx * gy) & 127) == 0) {
+    if ((gx & 3) == 0 && (gy & 3) == 0 && ((gx * gy) & 127) == 0) {
         const unsigned xcd = block & 7u, slot = block >> 3;
         const unsigned S = (slot >> 4) * 8u + xcd, inner = slot & 15u;   // super-tile id, block inside it
         const unsigned sgx = (unsigned)gx >> 2;
@@ -95,53 +95,18 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_kernel(const PbPara
         return;
     }
     const unsigned last_px = (unsigned)P.src.height * (unsigned)P.src.width - 1u;
-    const int variant = P.pad0;  // experiment switch
     for (int f = 0; f < n_frames; ++f) {
         const uint8_t* s = src + (unsigned long long)f * src_stride;
         uint8_t* d = dst + (unsigned long long)f * dst_stride;
         unsigned a[4][4];
-        if (variant == 1) {
-            // A: first pixel of every row group, wait, then the rest (they should hit L1 now)
 #pragma unroll
-            for (int jr = 0; jr < 4; ++jr) a[jr][0] = ((unsigned)id[jr][0] == last_px) ? pb_load_px(s, id[jr][0]) : pb_load_px32(s, id[jr][0]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int jr = 0; jr < 4; ++jr)
 #pragma unroll
-            for (int jr = 0; jr < 4; ++jr)
-#pragma unroll
-                for (int k = 1; k < 4; ++k) a[jr][k] = ((unsigned)id[jr][k] == last_px) ? pb_load_px(s, id[jr][k]) : pb_load_px32(s, id[jr][k]);
-        } else if (variant == 2) {
-            // B: one 16-byte load at the lowest texel of the 4; pixels it covers are extracted, others loaded separately
-#pragma unroll
-            for (int jr = 0; jr < 4; ++jr) {
-                int lo = 0x7fffffff;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (id[jr][k] >= 0) lo = min(lo, id[jr][k]);
-                uint4 q = make_uint4(0, 0, 0, 0);
-                const bool have = lo != 0x7fffffff && (unsigned)lo + 6u <= last_px;
-                if (have) __builtin_memcpy(&q, s + 3ull * (unsigned)lo, 16);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int v = id[jr][k];
-                    const unsigned dlt = (unsigned)(v - lo);
-                    if (v < 0) a[jr][k] = 0;
-                    else if (have && dlt <= 4u) {
-                        const unsigned sh = 3u * dlt;  // byte offset 0..12
-                        const unsigned w0 = sh < 4 ? q.x : (sh < 8 ? q.y : (sh < 12 ? q.z : q.w));
-                        const unsigned w1 = sh < 4 ? q.y : (sh < 8 ? q.z : (sh < 12 ? q.w : 0u));
-                        a[jr][k] = __builtin_amdgcn_alignbyte(w1, w0, sh & 3u) & 0xFFFFFFu;
-                    } else a[jr][k] = ((unsigned)v == last_px) ? pb_load_px(s, v) : pb_load_px32(s, v);
-                }
+            for (int k = 0; k < 4; ++k) {
+                const int v = id[jr][k];
+                // a 4-byte read of the frame's very last pixel would touch one byte past the buffer
+                a[jr][k] = ((unsigned)v == last_px) ? pb_load_px(s, v) : pb_load_px32(s, v);
             }
-        } else {
-#pragma unroll
-            for (int jr = 0; jr < 4; ++jr)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int v = id[jr][k];
-                    // a 4-byte read of the frame's very last pixel would touch one byte past the buffer
-                    a[jr][k] = ((unsigned)v == last_px) ? pb_load_px(s, v) : pb_load_px32(s, v);
-                }
-        }
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
             const int y = Y0 + yb + 8 * jr;

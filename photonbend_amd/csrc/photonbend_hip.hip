@@ -25,7 +25,6 @@ struct pb_plan {
     int mode = PB_MODE_AUTO;     // PB_MODE_AUTO / PB_MODE_FAITHFUL / PB_MODE_FAST
     int device = -1;             // device that owns the tables below
     int fast_ready = 0;          // models + fix list built and certified on `device`
-    int staged = getenv("PB_STAGED") ? atoi(getenv("PB_STAGED")) : 2;  // 2: LDS-window hot kernel (default); 0: direct-gather hot kernel
     PbTileEntry* table = nullptr;
     int32_t* fail_tiles = nullptr;
     int32_t* fix_px = nullptr;
@@ -185,11 +184,12 @@ static bool pb_use_fast(const pb_plan* plan) { return plan->fast_ready && plan->
 template <int OUT>
 static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, int n_frames, unsigned long long ss,
                            unsigned long long ds, int32_t* idx_out, hipStream_t st) {
-    PbParams P = pl->P;
-    if (getenv("PB_VARIANT")) P.pad0 = atoi(getenv("PB_VARIANT"));
+    const PbParams& P = pl->P;
     const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
     const unsigned fix_blocks = 4u * pl->n_fail_tiles + (pl->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
-    const bool windowed = OUT == 0 && pl->staged == 2 && P.src.width < 32768 && P.src.height < 32768 &&
+    // the windowed kernel needs 16-byte aligned frames (LDS-DMA row segments); PB_MODE_FAST_DIRECT and
+    // unaligned frames take the direct-gather hot kernel + the fix kernel
+    const bool windowed = OUT == 0 && pl->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
                           ((((uintptr_t)src) | ss) & 15u) == 0;
     if (windowed) {
         // hot blocks apply their own tiles' fix pixels; a handful of failed tiles ride along as leading
@@ -218,7 +218,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
     const bool staged = windowed;
     if (P.src.kind == PB_KIND_PANO) {
         if (!staged)
-        hipLaunchKernelGGL((pb_hot_kernel<PB_KIND_PANO, OUT>), grid, block, getenv("PB_LDS_PAD") ? atoi(getenv("PB_LDS_PAD")) : 0, st, P, pl->table, src, dst, n_frames, ss, ds, idx_out);
+        hipLaunchKernelGGL((pb_hot_kernel<PB_KIND_PANO, OUT>), grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, idx_out);
         if (fix_blocks)
             hipLaunchKernelGGL((pb_fix_kernel<PB_KIND_PANO, OUT>), dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, pl->fail_tiles,
                                (int)pl->n_fail_tiles, pl->fix_px, (int)pl->n_fix_px, src, dst, n_frames, ss, ds, idx_out);
@@ -390,7 +390,7 @@ __attribute__((visibility("default"))) int pb_debug_copy_table(const pb_plan* pl
 
 int pb_plan_set_mode(pb_plan* plan, int mode) {
     if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
-    if (mode < PB_MODE_AUTO || mode > PB_MODE_FAST) return pb_fail(PB_ERR_INVALID, "mode out of range");
+    if (mode < PB_MODE_AUTO || mode > PB_MODE_FAST_DIRECT) return pb_fail(PB_ERR_INVALID, "mode out of range");
     plan->mode = mode;
     return PB_OK;
 }

@@ -25,11 +25,11 @@ def test_plan_info_and_modes_c2_like():
     assert 1023 * 1023 <= lo <= 1023 * 1023 + 4 * 1024 and hi > lo
     frame = nat.synth_frame(1024, 2048, frame=3)
     outs = {}
-    for mode in (nat.MODE_FAITHFUL, nat.MODE_FAST, nat.MODE_AUTO):
+    for mode in (nat.MODE_FAITHFUL, nat.MODE_FAST, nat.MODE_AUTO, nat.MODE_FAST_DIRECT):
         plan.set_mode(mode)
         assert plan.info()["fast_path"] == (mode != nat.MODE_FAITHFUL)
         outs[mode] = (plan.remap(frame).clone(), plan.index_map().clone())
-    for mode in (nat.MODE_FAST, nat.MODE_AUTO):
+    for mode in (nat.MODE_FAST, nat.MODE_AUTO, nat.MODE_FAST_DIRECT):
         assert torch.equal(outs[mode][0], outs[nat.MODE_FAITHFUL][0])
         assert torch.equal(outs[mode][1], outs[nat.MODE_FAITHFUL][1])
 
