@@ -85,3 +85,23 @@ def test_every_small_case_has_consistent_plan_stats():
             assert info["fast_path"] == (case.dst[0] == "pano" and not case.rotations)
         else:
             assert info["fast_path"] and info["tiles"] > 0 and info["fix_pixels"] >= 0
+
+
+def test_streaming_batch_overlaps_and_matches():
+    """batch.remap_frames (H2D / remap / D2H on three streams) == the per-frame facade, in order."""
+    import photonbend_amd as pb
+    from photonbend_amd import batch
+    from oracle.synth import synth_frame
+
+    fov = pb.utils.to_radians(200)
+    dst = pb.CameraImage(np.zeros((200, 200, 3), np.uint8), fov, pb.equisolid(), magnitude=99.5)
+    rot = pb.Rotation(0.3, -0.2, 0.5)
+    frames = [synth_frame(160, 320, frame=f) for f in range(7)]
+    src0 = pb.PanoramaImage(frames[0])
+    plan = batch.plan_for(dst, [rot], src0)
+    got = list(batch.remap_frames(plan, iter(frames), depth=3))
+    assert len(got) == 7
+    for f, out in zip(frames, got):
+        want = pb.PanoramaImage(f).process_coordinate_map(rot.rotate_coordinate_map(dst.get_coordinate_map()))
+        assert np.array_equal(out, want)
+    assert list(batch.remap_frames(plan, iter([]))) == []
