@@ -142,6 +142,12 @@ int pb_rotate_f64(const double* rot3x3, double* map_in_dev, double* map_out_dev,
 int pb_sample_map_u8(const pb_proj* src, double* map_dev, int height, int width, const uint8_t* src_dev,
                      uint8_t* dst_dev, void* stream);
 
+/* map_projection (projection.py:550-599): coordinate map -> colour map (red = latitude stretched to
+ * 0..255 over the valid pixels, green = longitude * 255 / 2pi, blue = invalid * 255).  Zeroes invalid
+ * lat/lon in map_dev like the reference.  workspace24_dev: 24 bytes of device scratch; after the call it
+ * holds {min key, max key, number of valid pixels} (uint64 each). */
+int pb_map_projection_u8(double* map_dev, int height, int width, uint8_t* out_dev, void* workspace24_dev, void* stream);
+
 /* ---- deterministic synthetic frames (bench + tests) -------- */
 /* circle_mask: 0 none, 1 black outside the inscribed circle, 2 black outside
  * the two side-by-side inscribed circles. */

@@ -162,6 +162,27 @@ def gen_small():
     print("small.npz written,", len(out), "arrays")
 
 
+def gen_mapproj():
+    """f-3: map_projection (projection.py:550-599) on the float64 maps of the keep_map cases."""
+    from photonbend.core.projection import map_projection
+
+    out = {}
+    for case in small_cases():
+        if not case.keep_map:
+            continue
+        _, m, _, _ = ref_map(case)
+        given = np.copy(m)
+        img = map_projection(given)
+        assert np.array_equal(orc.map_projection(np.copy(m)), img), case.name
+        # the input is small.npz's last map of the case; the reference zeroes invalid lat/lon in it
+        expect = np.copy(m)
+        expect[:, :, :2][expect[:, :, 2] != 0.0] = 0
+        assert np.array_equal(bits(given), bits(expect)), case.name
+        out[f"{case.name}/out"] = img
+    np.savez_compressed(os.path.join(GOLD, "mapproj.npz"), **out)
+    print("mapproj.npz written,", len(out), "cases")
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -222,8 +243,9 @@ if __name__ == "__main__":
     ap.add_argument("--lens", action="store_true")
     ap.add_argument("--small", action="store_true")
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--mapproj", action="store_true")
     a = ap.parse_args()
-    everything = not (a.lens or a.small or a.full)
+    everything = not (a.lens or a.small or a.full or a.mapproj)
     os.makedirs(GOLD, exist_ok=True)
     if a.lens or everything:
         gen_lens()
@@ -231,3 +253,5 @@ if __name__ == "__main__":
         gen_small()
     if a.full or everything:
         gen_full()
+    if a.mapproj or everything:
+        gen_mapproj()

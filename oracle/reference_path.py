@@ -410,3 +410,23 @@ def fragile_mask(coords, rel=2.0**-40) -> np.ndarray:
             near |= ~np.isfinite(a)
             m = near if m is None else (m | near)
     return m
+
+
+def map_projection(cmap: np.ndarray) -> np.ndarray:
+    """projection.py:550-599 - coordinate map -> colour map (red: latitude stretched to 0..255 over the
+    valid pixels, green: longitude * 255 / 2pi, blue: invalid * 255).  Zeroes invalid lat/lon in ``cmap``."""
+    invalid = cmap[:, :, 2] != 0.0
+    valid = np.logical_not(invalid)
+    polar = cmap[:, :, :2]
+    polar[invalid] = 0
+    dist = polar[:, :, 0]
+    mn, mx = np.min(dist[valid]), np.max(dist[valid])
+    factor = 255.0 / (mx - mn)
+    nd = dist.copy()
+    nd[valid] -= mn
+    nd[valid] *= factor
+    with np.errstate(all="ignore"):
+        red = np.round(nd).astype(np.uint8)
+        green = np.round((255.0 / (np.pi * 2)) * polar[:, :, 1]).astype(np.uint8)
+    blue = (invalid.astype(np.uint8) * 255).astype(np.uint8)
+    return np.stack([red, green, blue], axis=2)

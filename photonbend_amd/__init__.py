@@ -6,6 +6,6 @@ __version__ = "0.1.0"
 
 from . import core, utils  # noqa: F401
 from .core.lens import Lens, equidistant, equisolid, orthographic, rectilinear, stereographic, thoby  # noqa: F401
-from .core.projection import CameraImage, DoubleCameraImage, PanoramaImage, ProjectionImage  # noqa: F401
+from .core.projection import CameraImage, DoubleCameraImage, PanoramaImage, ProjectionImage, map_projection  # noqa: F401
 from .core.rotation import Rotation  # noqa: F401
 from .core._coordmap import CoordinateMap  # noqa: F401

@@ -69,6 +69,7 @@ SIGNATURES = {
     "pb_coordmap_f64": (C.c_int, [C.POINTER(pb_proj), _VP, _VP]),
     "pb_rotate_f64": (C.c_int, [C.POINTER(C.c_double), _VP, _VP, C.c_int, C.c_int, _VP]),
     "pb_sample_map_u8": (C.c_int, [C.POINTER(pb_proj), _VP, C.c_int, C.c_int, _VP, _VP, _VP]),
+    "pb_map_projection_u8": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP]),
     "pb_synth_frame_u8": (C.c_int, [_VP, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, _VP]),
     "pb_malloc": (C.c_int, [C.POINTER(_VP), C.c_size_t]),
     "pb_free": (C.c_int, [_VP]),
@@ -234,6 +235,18 @@ def sample_map(src: pb_proj, cmap: torch.Tensor, image: torch.Tensor) -> torch.T
     out = torch.empty((cmap.shape[0], cmap.shape[1], 3), dtype=torch.uint8, device=cmap.device)
     with torch.cuda.device(cmap.device):
         check(load().pb_sample_map_u8(C.byref(src), cmap.data_ptr(), cmap.shape[0], cmap.shape[1], image.data_ptr(), out.data_ptr(), current_stream()))
+    return out
+
+
+def map_projection(cmap: torch.Tensor) -> torch.Tensor:
+    """cmap (H, W, 3) float64 cuda, contiguous -> uint8 (H, W, 3); invalid lat/lon are zeroed in cmap."""
+    require_gpu()
+    out = torch.empty((cmap.shape[0], cmap.shape[1], 3), dtype=torch.uint8, device=cmap.device)
+    ws = torch.empty(3, dtype=torch.int64, device=cmap.device)
+    with torch.cuda.device(cmap.device):
+        check(load().pb_map_projection_u8(cmap.data_ptr(), cmap.shape[0], cmap.shape[1], out.data_ptr(), ws.data_ptr(), current_stream()))
+    if int(ws[2].item()) == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")  # np.min of no valid pixel
     return out
 
 

@@ -215,3 +215,21 @@ class PanoramaImage(_GpuProjection):
     def _proj(self) -> nat.pb_proj:
         h, w = _shape_hw(self.image)
         return nat.make_proj(nat.KIND_PANO, h, w)
+
+
+def map_projection(coordinate_map):
+    """Coordinate map -> RGB colour map for eyeballing a projection (projection.py:550-599): latitude in
+    red (stretched over the valid pixels), longitude in green, the invalid flag in blue.  Runs on the GPU
+    (pb_map_projection_u8); like the reference it zeroes lat/lon of invalid pixels in the map it is given."""
+    if isinstance(coordinate_map, torch.Tensor):
+        if not (coordinate_map.is_cuda and coordinate_map.dtype == torch.float64 and coordinate_map.is_contiguous()):
+            raise TypeError("tensor coordinate maps must be contiguous float64 CUDA tensors")
+        return nat.map_projection(coordinate_map)
+    host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
+    if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
+        raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
+    nat.require_gpu()
+    dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+    out = nat.map_projection(dev)
+    host[...] = dev.cpu().numpy()
+    return _to_host(out)

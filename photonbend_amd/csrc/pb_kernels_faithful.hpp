@@ -248,3 +248,65 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_synth_kernel(uint8_t* __restrict_
 }
 
 
+
+// ---- map_projection (projection.py:550-599): coordinate map -> colour map ------------------------
+// pass 1: min / max of the latitude over the valid pixels (invalid lat/lon zeroed in place, :563-567);
+// doubles are reduced through their order-preserving uint64 image
+__device__ __forceinline__ unsigned long long pb_f64_key(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double pb_key_f64(unsigned long long k) {
+    const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// ws[0] = min key, ws[1] = max key, ws[2] = number of valid pixels (caller zero-initialises as {~0, 0, 0})
+__global__ __launch_bounds__(PB_BLOCK) void pb_mapproj_minmax_kernel(double* __restrict__ map, unsigned total,
+                                                                     unsigned long long* __restrict__ ws) {
+    const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+    unsigned long long kmin = ~0ull, kmax = 0ull, cnt = 0;
+    if (p < total) {
+        double* a = map + 3ull * p;
+        if (a[2] != 0.0) {
+            a[0] = 0.0;
+            a[1] = 0.0;
+        } else {
+            kmin = kmax = pb_f64_key(a[0]);   // NaN latitudes order above +inf / below -inf: np.min/np.max would
+            cnt = 1;                          // return NaN; the facade rejects maps whose valid latitudes hold NaN
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o), c = __shfl_xor(cnt, o);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+        cnt += c;
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicMin(&ws[0], kmin);
+        atomicMax(&ws[1], kmax);
+        atomicAdd(&ws[2], cnt);
+    }
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void pb_mapproj_colour_kernel(const double* __restrict__ map, unsigned total,
+                                                                     const unsigned long long* __restrict__ ws,
+                                                                     uint8_t* __restrict__ out) {
+    const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    const double mn = pb_key_f64(ws[0]), mx = pb_key_f64(ws[1]);
+    const double factor = 255.0 / (mx - mn);            // rgb_range / min_max_distance, :573-574
+    const double* a = map + 3ull * p;
+    const bool invalid = a[2] != 0.0;
+    double d = a[0];
+    if (!invalid) {
+        d = d - mn;                                      // :576
+        d = d * factor;                                  // :577
+    }
+    const double g = (255.0 / (PB_PI * 2)) * a[1];      // :583-584
+    uint8_t* o = out + 3ull * p;
+    o[0] = (uint8_t)pb_cvt_u8(rint(d));                  // np.round = half-to-even; astype(uint8) wraps
+    o[1] = (uint8_t)pb_cvt_u8(rint(g));
+    o[2] = invalid ? 255 : 0;
+}

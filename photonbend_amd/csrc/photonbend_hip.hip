@@ -479,6 +479,21 @@ int pb_sample_map_u8(const pb_proj* src, double* map_dev, int height, int width,
     return PB_OK;
 }
 
+int pb_map_projection_u8(double* map_dev, int height, int width, uint8_t* out_dev, void* workspace24_dev, void* stream) {
+    if (!map_dev || !out_dev || !workspace24_dev) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (height < 1 || width < 1 || (long long)height * width > 0x7FFFFFFFll / 4)
+        return pb_fail(PB_ERR_INVALID, "map size out of range");
+    const unsigned total = (unsigned)height * (unsigned)width;
+    hipStream_t st = (hipStream_t)stream;
+    static const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+    PB_HIP(hipMemcpyAsync(workspace24_dev, init, sizeof(init), hipMemcpyHostToDevice, st));
+    unsigned long long* ws = reinterpret_cast<unsigned long long*>(workspace24_dev);
+    hipLaunchKernelGGL(pb_mapproj_minmax_kernel, dim3(pb_blocks(total)), dim3(PB_BLOCK), 0, st, map_dev, total, ws);
+    hipLaunchKernelGGL(pb_mapproj_colour_kernel, dim3(pb_blocks(total)), dim3(PB_BLOCK), 0, st, map_dev, total, ws, out_dev);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
 int pb_synth_frame_u8(uint8_t* frame_dev, int height, int width, uint32_t frame, uint32_t seed, int circle_mask,
                       void* stream) {
     if (!frame_dev) return pb_fail(PB_ERR_INVALID, "null argument");

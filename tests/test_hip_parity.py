@@ -180,3 +180,20 @@ def test_ragged_sizes_and_unaligned_tails():
         d = pb.CameraImage(np.zeros((h, w, 3), np.uint8), 3.0, pb.equidistant())
         got = pb.PanoramaImage(frame).process_coordinate_map(d.get_coordinate_map())
         assert np.array_equal(got, want), (h, w)
+
+
+@pytest.mark.parametrize("case", [c for c in small_cases() if c.keep_map], ids=lambda c: c.name)
+def test_map_projection_matches_reference(case):
+    """f-3: map_projection on the reference's own float64 map -> the reference's colour map, bit for bit
+    (pure IEEE work: subtract, multiply, round-half-even, wrap to uint8), plus the in-place side effect."""
+    import photonbend_amd as pb
+
+    g = np.load(H.GOLD + "/mapproj.npz")
+    shape = (case.dst[1], case.dst[2], 3)
+    m = np.array(SMALL[f"{case.name}/map{len(case.rotations)}"].view(np.float64).reshape(shape))
+    given = m.copy()
+    out = pb.map_projection(given)
+    assert out.dtype == np.uint8 and np.array_equal(out, g[f"{case.name}/out"])
+    expect = m.copy()
+    expect[..., :2][expect[..., 2] != 0.0] = 0.0
+    assert np.array_equal(H.bits(given), H.bits(expect))

@@ -100,3 +100,13 @@ def test_synth_formula_spot_values():
     for r, c, ch in [(0, 0, 0), (4, 6, 2), (2, 3, 1)]:
         key = ((3 * 0x9E3779B1) ^ (r * 0x85EBCA6B) ^ (c * 0xC2B2AE35) ^ (ch * 0x27D4EB2F) ^ 9) & 0xFFFFFFFF
         assert img[r, c, ch] == mix(key) & 0xFF
+
+
+def test_map_projection_matches_reference():
+    g = np.load(H.GOLD + "/mapproj.npz")
+    for case in small_cases():
+        if not case.keep_map:
+            continue
+        shape = (case.dst[1], case.dst[2], 3)
+        m = np.array(SMALL[f"{case.name}/map{len(case.rotations)}"].view(np.float64).reshape(shape))
+        assert np.array_equal(orc.map_projection(m), g[f"{case.name}/out"]), case.name
