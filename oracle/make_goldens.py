@@ -183,6 +183,29 @@ def gen_mapproj():
     print("mapproj.npz written,", len(out), "cases")
 
 
+def gen_cli():
+    """f-2: the reference's own CLI (click CliRunner) on small synthetic PNGs -> output pixel arrays."""
+    import tempfile
+
+    from click.testing import CliRunner
+    from PIL import Image
+    from photonbend.scripts.main import main as ref_main
+    from tests.cases import cli_cases
+
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, cmd, opts, (h, w, mask) in cli_cases():
+            inp, outp = os.path.join(tmp, name + "_in.png"), os.path.join(tmp, name + "_out.png")
+            Image.fromarray(synth_frame(h, w, frame=5, seed=0, circle_mask=mask)).save(inp)
+            # argument order differs per command only in where OUTPUT sits; click accepts options anywhere
+            res = CliRunner().invoke(ref_main, [cmd, inp, *opts, outp])
+            assert res.exit_code == 0, (name, res.output, res.exception)
+            out[name] = np.asarray(Image.open(outp))
+            print(f"  {name}: {out[name].shape}")
+    np.savez_compressed(os.path.join(GOLD, "cli.npz"), **out)
+    print("cli.npz written,", len(out), "cases")
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -244,8 +267,9 @@ if __name__ == "__main__":
     ap.add_argument("--small", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--mapproj", action="store_true")
+    ap.add_argument("--cli", action="store_true")
     a = ap.parse_args()
-    everything = not (a.lens or a.small or a.full or a.mapproj)
+    everything = not (a.lens or a.small or a.full or a.mapproj or a.cli)
     os.makedirs(GOLD, exist_ok=True)
     if a.lens or everything:
         gen_lens()
@@ -255,3 +279,5 @@ if __name__ == "__main__":
         gen_full()
     if a.mapproj or everything:
         gen_mapproj()
+    if a.cli or everything:
+        gen_cli()

@@ -114,3 +114,21 @@ def case_by_name(name: str) -> Case:
         if c.name == name:
             return c
     raise KeyError(name)
+
+
+def cli_cases():
+    """(name, command, option list, (input height, input width, circle mask)) for the CLI facade (f-2).
+    INPUT / OUTPUT paths are appended by the runner; outputs are PNG (lossless)."""
+    return [
+        ("photo_inscribed", "make-photo", ["--type", "inscribed", "--lens", "equidistant", "--fov", "360", "-s", "72"], (64, 128, 0)),
+        ("photo_rot2", "make-photo", ["--type", "inscribed", "--lens", "equisolid", "--fov", "180", "-r", "-90", "0", "195", "-r", "10", "20", "30"], (48, 96, 0)),
+        ("photo_double", "make-photo", ["--type", "double", "--lens", "equidistant", "--fov", "195", "-s", "40"], (64, 128, 0)),
+        ("photo_full_rect", "make-photo", ["--type", "full", "--lens", "rectilinear", "--fov", "120", "-s", "50"], (64, 128, 0)),
+        ("photo_cropped_stereo", "make-photo", ["--type", "cropped", "--lens", "stereographic", "--fov", "200"], (40, 80, 0)),
+        ("pano_inscribed", "make-pano", ["--type", "inscribed", "--lens", "equidistant", "--fov", "360", "-s", "48"], (72, 72, 1)),
+        ("pano_double_195", "make-pano", ["--type", "double", "--lens", "equidistant", "--fov", "195"], (40, 80, 2)),
+        ("pano_ortho_rot", "make-pano", ["--type", "inscribed", "--lens", "orthographic", "--fov", "170", "-r", "15", "-40", "5"], (60, 60, 1)),
+        ("alter_eqd_eqs_rot", "alter-photo", ["--itype", "inscribed", "--ilens", "equidistant", "--ifov", "360", "--otype", "inscribed", "--olens", "equisolid", "--ofov", "360", "-r", "30", "45", "10"], (64, 64, 1)),
+        ("alter_size_quirk", "alter-photo", ["--itype", "inscribed", "--ilens", "equidistant", "--ifov", "180", "--otype", "full", "--olens", "rectilinear", "--ofov", "100", "-s", "40"], (64, 64, 1)),
+        ("alter_double_in", "alter-photo", ["--itype", "double", "--ilens", "equidistant", "--ifov", "200", "--otype", "inscribed", "--olens", "equidistant", "--ofov", "180"], (48, 96, 2)),
+    ]
