@@ -105,3 +105,36 @@ def test_streaming_batch_overlaps_and_matches():
         want = pb.PanoramaImage(f).process_coordinate_map(rot.rotate_coordinate_map(dst.get_coordinate_map()))
         assert np.array_equal(out, want)
     assert list(batch.remap_frames(plan, iter([]))) == []
+
+
+def test_remap_is_graph_capturable():
+    """Launch functions neither allocate nor synchronise: a burst of pb_remap_u8 calls captures into a HIP
+    graph (torch.cuda.CUDAGraph) and replays with the same bytes."""
+    case = Case("g", cam(256, 256, "equidistant", 360, inscribed(256)), pano(256, 512), [(5, 10, 15)])
+    plan = H.pb_plan(case)
+    frames = [nat.synth_frame(256, 512, frame=f) for f in range(4)]
+    outs = [torch.zeros((256, 256, 3), dtype=torch.uint8, device="cuda") for _ in range(4)]
+    want = [plan.remap(f).clone() for f in frames]
+    lib = nat.load()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for f in range(4):
+                nat.check(lib.pb_remap_u8(plan.handle, frames[f].data_ptr(), outs[f].data_ptr(), 1, 0, 0, int(side.cuda_stream)))
+    torch.cuda.current_stream().wait_stream(side)
+    for o in outs:
+        o.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for f in range(4):
+        assert torch.equal(outs[f], want[f])
+    # new pixels in the same buffers, replay again
+    for f in range(4):
+        frames[f].copy_(nat.synth_frame(256, 512, frame=10 + f))
+    want2 = [plan.remap(f).clone() for f in frames]
+    g.replay()
+    torch.cuda.synchronize()
+    for f in range(4):
+        assert torch.equal(outs[f], want2[f])
