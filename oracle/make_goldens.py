@@ -210,6 +210,30 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def gen_real():
+    """G8: BASELINE config c1 on the reference's real image (examples/equidistant.jpg stays in the reference;
+    only hashes and samples of the reference's OUTPUT are kept)."""
+    from PIL import Image
+
+    img = np.asarray(Image.open("/root/reference/examples/equidistant.jpg"))
+    h = img.shape[0]
+    src = CameraImage(img, to_radians(360), ref_lens.equidistant(), magnitude=img.shape[1] / 2 - 0.5)
+    dst = PanoramaImage(np.zeros((2048, 4096, 3), np.uint8))
+    out = src.process_coordinate_map(dst.get_coordinate_map())
+    pos = np.random.default_rng(2024).integers(0, 2048 * 4096, size=4096)
+    pin = {
+        "input": "examples/equidistant.jpg",
+        "input_shape": list(img.shape),
+        "input_sha256": sha(img),
+        "u8_sha256": sha(out),
+        "sample_seed": 2024,
+        "u8_samples": [int(v) for v in out.reshape(-1, 3)[pos].ravel()],
+    }
+    with open(os.path.join(GOLD, "c1_real.json"), "w") as f:
+        json.dump(pin, f)
+    print("c1_real.json written", out.shape, h)
+
+
 def gen_full():
     pins = {}
     for case in full_cases():
@@ -268,8 +292,9 @@ if __name__ == "__main__":
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--mapproj", action="store_true")
     ap.add_argument("--cli", action="store_true")
+    ap.add_argument("--real", action="store_true")
     a = ap.parse_args()
-    everything = not (a.lens or a.small or a.full or a.mapproj or a.cli)
+    everything = not (a.lens or a.small or a.full or a.mapproj or a.cli or a.real)
     os.makedirs(GOLD, exist_ok=True)
     if a.lens or everything:
         gen_lens()
@@ -281,3 +306,5 @@ if __name__ == "__main__":
         gen_mapproj()
     if a.cli or everything:
         gen_cli()
+    if a.real or everything:
+        gen_real()

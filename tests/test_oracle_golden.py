@@ -110,3 +110,22 @@ def test_map_projection_matches_reference():
         shape = (case.dst[1], case.dst[2], 3)
         m = np.array(SMALL[f"{case.name}/map{len(case.rotations)}"].view(np.float64).reshape(shape))
         assert np.array_equal(orc.map_projection(m), g[f"{case.name}/out"]), case.name
+
+
+def test_c1_real_image_pin():
+    """G8: config c1 on the reference's own example image.  The JPEG never leaves /root/reference, so this runs
+    only where the reference is mounted (the build container); the GPU box exercises c1 on a synthetic frame."""
+    import json
+    import os
+
+    path = "/root/reference/examples/equidistant.jpg"
+    if not os.path.exists(path):
+        pytest.skip("reference examples not mounted")
+    from PIL import Image
+
+    pin = json.load(open(H.GOLD + "/c1_real.json"))
+    img = np.asarray(Image.open(path))
+    assert list(img.shape) == pin["input_shape"] and _sha(img) == pin["input_sha256"]
+    src = orc.Proj("camera", img.shape[0], img.shape[1], "equidistant", orc.to_radians(360), img.shape[1] / 2 - 0.5)
+    out = orc.remap(orc.Proj("pano", 2048, 4096), src, img)
+    assert _sha(out) == pin["u8_sha256"]
