@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
     ap.add_argument("--event-every", type=int, default=8, help="bracket every n-th timed launch with a HIP event pair")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the (independent) frames are dealt to round-robin")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,15 +128,17 @@ def main():
     srcs = [nat.synth_frame(SRC_H, SRC_W, frame=rank * pool + f, seed=0, device=device) for f in range(pool)]
     dsts = [torch.empty((DST, DST, 3), dtype=torch.uint8, device=device) for _ in range(pool)]
     lib = nat.load()
-    stream = torch.cuda.Stream(device=device)
-    st = int(stream.cuda_stream)
+    n_streams = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+    sts = [int(x.cuda_stream) for x in streams]
+    st = sts[0]
     sp = [t.data_ptr() for t in srcs]
     dp = [t.data_ptr() for t in dsts]
     h = plan.handle
 
     def step(k):
         i = k % pool
-        rc = lib.pb_remap_u8(h, sp[i], dp[i], 1, 0, 0, st)
+        rc = lib.pb_remap_u8(h, sp[i], dp[i], 1, 0, 0, sts[k % n_streams])
         if rc:
             nat.check(rc)
 
@@ -164,9 +167,9 @@ def main():
         n = 0
         for k in range(K):
             if k % every == 0:
-                lib.pb_event_record(ev[2 * n], st)
+                lib.pb_event_record(ev[2 * n], sts[k % n_streams])
                 step(k)
-                lib.pb_event_record(ev[2 * n + 1], st)
+                lib.pb_event_record(ev[2 * n + 1], sts[k % n_streams])
                 n += 1
             else:
                 step(k)
@@ -223,6 +226,7 @@ def main():
             "config": {
                 "workload": "c2: one 8192x4096 equirectangular frame -> 4096x4096 equidistant-360 inscribed per step",
                 "frames_resident_per_gpu": pool,
+                "streams": n_streams,
                 "sampling": "nearest (truncating), the reference's",
                 "parallelism": f"frames sharded over {world} GPU(s); RCCL broadcast of the parameter block only",
             },
