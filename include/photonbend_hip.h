@@ -123,6 +123,13 @@ int pb_plan_src_shape(const pb_plan* plan, int* height, int* width);
 int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames,
                 size_t src_frame_stride, size_t dst_frame_stride, void* stream);
 
+/* OPT-IN extension with no reference counterpart (the reference samples nearest-by-truncation only):
+ * bilinear interpolation at the reference's pre-truncation coordinate (pixel k covers [k, k+1), centre
+ * k + 0.5; taps clamped to the image, panorama columns wrap; round half to even).  Pixels the nearest mode
+ * paints black stay black.  Camera and panorama sources only (PB_ERR_UNSUPPORTED for double-fisheye sources). */
+int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames,
+                         size_t src_frame_stride, size_t dst_frame_stride, void* stream);
+
 /* Integer coordinate map: for camera / pano sources idx_dev is int32 [H*W], the
  * linear source pixel index (row * src_width + col) or -1 where the output is
  * black.  For a double source idx_dev is int32 [2][H*W] (left-eye index, then

@@ -65,6 +65,7 @@ SIGNATURES = {
     "pb_plan_dst_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_plan_src_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_remap_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
+    "pb_remap_bilinear_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
     "pb_index_map_i32": (C.c_int, [_VP, _VP, _VP, _VP]),
     "pb_coordmap_f64": (C.c_int, [C.POINTER(pb_proj), _VP, _VP]),
     "pb_rotate_f64": (C.c_int, [C.POINTER(C.c_double), _VP, _VP, C.c_int, C.c_int, _VP]),
@@ -174,8 +175,11 @@ class Plan:
             _lib.pb_plan_destroy(h)
 
     # -- launches (torch tensors in, torch tensors out; all on the current stream)
-    def remap(self, src: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        """src: uint8 cuda tensor (h, w, 3) or (N, h, w, 3) -> (H, W, 3) / (N, H, W, 3)."""
+    def remap(self, src: torch.Tensor, out: torch.Tensor | None = None, interpolation: str = "nearest") -> torch.Tensor:
+        """src: uint8 cuda tensor (h, w, 3) or (N, h, w, 3) -> (H, W, 3) / (N, H, W, 3).
+        interpolation: "nearest" (the reference's truncating sample) or the opt-in "bilinear"."""
+        if interpolation not in ("nearest", "bilinear"):
+            raise ValueError("interpolation must be 'nearest' or 'bilinear'")
         require_gpu()
         batched = src.dim() == 4
         s = src if batched else src.unsqueeze(0)
@@ -190,8 +194,9 @@ class Plan:
             o = out if out.dim() == 4 else out.unsqueeze(0)
             if o.dtype != torch.uint8 or not o.is_contiguous() or tuple(o.shape) != (n, self.dst.height, self.dst.width, 3):
                 raise PbError("out must be a contiguous uint8 cuda tensor of the destination shape")
+        fn = load().pb_remap_u8 if interpolation == "nearest" else load().pb_remap_bilinear_u8
         with torch.cuda.device(s.device):
-            check(load().pb_remap_u8(self._h, s.data_ptr(), o.data_ptr(), n, 0, 0, current_stream()))
+            check(fn(self._h, s.data_ptr(), o.data_ptr(), n, 0, 0, current_stream()))
         return o if batched else o[0]
 
     def index_map(self, weights: bool = False, device=None):

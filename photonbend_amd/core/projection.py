@@ -119,15 +119,23 @@ class _GpuProjection:
         """This image's coordinate map, as a lazy recipe (see ``CoordinateMap``)."""
         return CoordinateMap(self._proj())
 
-    def process_coordinate_map(self, coordinate_map):
+    def process_coordinate_map(self, coordinate_map, interpolation: str = "nearest"):
         """Maps this image's pixels through ``coordinate_map`` and returns the new
-        uint8 image (projection.py:197-245, :408-462, :515-547)."""
+        uint8 image (projection.py:197-245, :408-462, :515-547).
+
+        ``interpolation="bilinear"`` is an opt-in extension with no reference counterpart (the reference
+        truncates to the nearest pixel): lazy maps and camera / panorama sources only."""
         src = self._proj()
+        if interpolation != "nearest":
+            if interpolation != "bilinear":
+                raise ValueError("interpolation must be 'nearest' or 'bilinear'")
+            if not (isinstance(coordinate_map, CoordinateMap) and coordinate_map.is_lazy):
+                raise NotImplementedError("bilinear sampling needs a lazy coordinate map (a recipe), not a materialised array")
         on_device = isinstance(self.image, torch.Tensor)
         img = _device_image(self.image, src.height, src.width)
         if isinstance(coordinate_map, CoordinateMap) and coordinate_map.is_lazy:
             plan = _plan_for(coordinate_map.dst_proj, coordinate_map.rotations, src)
-            out = plan.remap(img)
+            out = plan.remap(img, interpolation=interpolation)
             if src.kind == nat.KIND_PANO:
                 coordinate_map.note_invalid_zeroed()  # projection.py:534-536
             return out if on_device else _to_host(out)

@@ -1,0 +1,150 @@
+// pb_kernels_bilinear.hpp - OPT-IN bilinear sampling.
+//
+// The reference samples nearest-by-truncation only (projection.py:254-259, :545); this mode has NO reference
+// behaviour to be at parity with ("parity unpinned": its oracle is oracle/reference_path.py:remap_bilinear,
+// our own definition).  Definition: the continuous source coordinate is the reference's PRE-truncation
+// coordinate f (pixel k covers [k, k+1), centre k + 0.5).  s = f - 0.5, i0 = floor(s), t = s - i0; the four taps
+// (i0, i0 + 1) x (j0, j0 + 1) are clamped to the image (pano columns wrap), weights (1-t, t); the channel value is
+// rounded half-to-even.  Pixels the nearest mode paints black (invalid destination pixel, camera source position
+// outside [0, h) x [0, w)) stay black.  Double-fisheye sources are not supported in this mode.
+//
+//   pb_bilinear_hot_kernel   modelled tiles: float32 tile models give f (error ~1e-5 px, no fix list needed: there
+//                            is no truncation to protect), exact integer validity thresholds, four direct gathers
+//   pb_bilinear_fix_kernel   failed tiles (seam, pole, centre, no model): float64 faithful chain per pixel
+#pragma once
+#include "pb_kernels_tile.hpp"
+
+template <int SRC_KIND>
+__device__ __forceinline__ unsigned pb_bilinear_taps(const PbParams& P, const uint8_t* __restrict__ s, float sy, float sx, int by,
+                                                     int bx) {
+    // sy / sx: s = f - 0.5 relative to the integer bases (by, bx); all taps are clamped / wrapped into the image
+    const int h = P.src.height, w = P.src.width;
+    const float fy0 = floorf(sy), fx0 = floorf(sx);
+    const float ty = sy - fy0, tx = sx - fx0;
+    int r0 = by + (int)fy0, c0 = bx + (int)fx0;
+    int r1 = r0 + 1, c1 = c0 + 1;
+    r0 = min(max(r0, 0), h - 1);
+    r1 = min(max(r1, 0), h - 1);
+    if (SRC_KIND == PB_KIND_PANO) {
+        c0 = c0 < 0 ? c0 + w : (c0 >= w ? c0 - w : c0);
+        c1 = c1 < 0 ? c1 + w : (c1 >= w ? c1 - w : c1);
+        c0 = min(max(c0, 0), w - 1);
+        c1 = min(max(c1, 0), w - 1);
+    } else {
+        c0 = min(max(c0, 0), w - 1);
+        c1 = min(max(c1, 0), w - 1);
+    }
+    // unaligned dword loads; only the frame's very last pixel must be read bytewise
+    const unsigned last_px = (unsigned)h * (unsigned)w - 1u;
+    const unsigned i00 = r0 * w + c0, i01 = r0 * w + c1, i10 = r1 * w + c0, i11 = r1 * w + c1;
+    const unsigned p00 = i00 == last_px ? pb_load_px(s, (int)i00) : pb_load_px32(s, (int)i00);
+    const unsigned p01 = i01 == last_px ? pb_load_px(s, (int)i01) : pb_load_px32(s, (int)i01);
+    const unsigned p10 = i10 == last_px ? pb_load_px(s, (int)i10) : pb_load_px32(s, (int)i10);
+    const unsigned p11 = i11 == last_px ? pb_load_px(s, (int)i11) : pb_load_px32(s, (int)i11);
+    unsigned out = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float a = (float)((p00 >> (8 * ch)) & 0xFF), b = (float)((p01 >> (8 * ch)) & 0xFF);
+        const float c = (float)((p10 >> (8 * ch)) & 0xFF), d = (float)((p11 >> (8 * ch)) & 0xFF);
+        const float top = fmaf(tx, b - a, a), bot = fmaf(tx, d - c, c);
+        const float v = fmaf(ty, bot - top, top);
+        out |= ((unsigned)(int)rintf(fminf(fmaxf(v, 0.0f), 255.0f))) << (8 * ch);
+    }
+    return out;
+}
+
+template <int SRC_KIND>
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
+                                                                              const uint8_t* __restrict__ src,
+                                                                              uint8_t* __restrict__ dst, int n_frames,
+                                                                              unsigned long long src_stride,
+                                                                              unsigned long long dst_stride) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tx, ty;
+    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
+    const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
+    const int flags = e->flags;
+    if (flags & PB_TILE_FAILED) return;
+    const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
+    const int xg = lane & 7, yb = lane >> 3;
+    const int W = P.dst.width, H = P.dst.height;
+    const int x = X0 + 4 * xg;
+    const int h = P.src.height, w = P.src.width;
+    for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* s = src + (unsigned long long)f * src_stride;
+        uint8_t* d = dst + (unsigned long long)f * dst_stride;
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const int y = Y0 + yb + 8 * jr;
+            PbRowModel R;
+            pb_model_row(P, e, X0, Y0, yb + 8 * jr, 4 * xg, R);
+            unsigned a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const pb_f2 fv = pb_eval_row(R.a, pb_tile_coord(4 * xg + k));
+                unsigned px = 0;
+                // black where the nearest mode is black: invalid destination pixel / camera position outside the image
+                const float ay = (float)R.anchor_r + fv.x, ax = (float)R.anchor_c + fv.y;
+                bool live = !(flags & PB_TILE_BLACK) && !pb_row_px_invalid(R, k) && y < H && x + k < W;
+                if (SRC_KIND == PB_KIND_CAMERA) live = live && ay >= 0.0f && ay < (float)h && ax >= 0.0f && ax < (float)w;
+                if (live) px = pb_bilinear_taps<SRC_KIND>(P, s, fv.x - 0.5f, fv.y - 0.5f, R.anchor_r, R.anchor_c);
+                a[k] = px;
+            }
+            if (y < H) {
+                const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+                if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
+                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (x + k < W) {
+                            d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+                            d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+                            d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+                        }
+                }
+            }
+        }
+    }
+}
+
+// float64 faithful coordinates; mode 0: the plan's failed tiles (4 blocks each), mode 1: every pixel (no plan state)
+template <int SRC_KIND>
+__global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_fix_kernel(const PbParams P, const int32_t* __restrict__ fail_tiles,
+                                                                   int all_pixels, const uint8_t* __restrict__ src,
+                                                                   uint8_t* __restrict__ dst, int n_frames,
+                                                                   unsigned long long src_stride, unsigned long long dst_stride) {
+    int i, j;
+    if (all_pixels) {
+        const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+        if (p >= (unsigned)P.dst.height * (unsigned)P.dst.width) return;
+        i = p / (unsigned)P.dst.width;
+        j = p - (unsigned)i * (unsigned)P.dst.width;
+    } else {
+        const int t = fail_tiles[blockIdx.x >> 2];
+        const int ty = t / pb_tiles_x(P), tx = t - ty * pb_tiles_x(P);
+        const int local = (blockIdx.x & 3) * 256 + threadIdx.x;
+        i = ty * PB_TILE + (local >> 5);
+        j = tx * PB_TILE + (local & 31);
+        if (i >= P.dst.height || j >= P.dst.width) return;
+    }
+    PbCoord c = pb_dst_coord(P, i, j);
+    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    double f0, f1;
+    pb_src_pretrunc<SRC_KIND>(P, c, f0, f1);
+    bool live = !c.inv && f0 == f0 && f1 == f1 && fabs(f0) < 1.0e9 && fabs(f1) < 1.0e9;
+    if (SRC_KIND == PB_KIND_CAMERA) live = live && f0 >= 0.0 && f0 < (double)P.src.height && f1 >= 0.0 && f1 < (double)P.src.width;
+    const size_t p = (size_t)i * P.dst.width + j;
+    // integer bases keep the float32 tap arithmetic exact enough: s - base is in [-1, 1)
+    const double sy = f0 - 0.5, sx = f1 - 0.5;
+    const int by = live ? (int)floor(sy) : 0, bx = live ? (int)floor(sx) : 0;
+    for (int f = 0; f < n_frames; ++f) {
+        unsigned v = 0;
+        if (live) v = pb_bilinear_taps<SRC_KIND>(P, src + (unsigned long long)f * src_stride, (float)(sy - by), (float)(sx - bx), by, bx);
+        uint8_t* o = dst + (unsigned long long)f * dst_stride + 3 * p;
+        o[0] = (uint8_t)(v & 0xFF);
+        o[1] = (uint8_t)((v >> 8) & 0xFF);
+        o[2] = (uint8_t)((v >> 16) & 0xFF);
+    }
+}

@@ -19,6 +19,7 @@
 #include "pb_tile.hpp"
 #include "pb_kernels_tile.hpp"
 #include "pb_kernels_sep.hpp"
+#include "pb_kernels_bilinear.hpp"
 
 struct pb_plan {
     PbParams P;
@@ -345,6 +346,50 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
         pb_launch_faithful_remap<PB_KIND_CAMERA>(P, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride, st);
     } else {
         pb_launch_faithful_remap<PB_KIND_DOUBLE>(P, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride, st);
+    }
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames, size_t src_frame_stride,
+                         size_t dst_frame_stride, void* stream) {
+    if (!plan || !src_dev || !dst_dev) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (n_frames < 0) return pb_fail(PB_ERR_INVALID, "negative frame count");
+    if (n_frames == 0) return PB_OK;
+    const PbParams& P = plan->P;
+    if (P.src.kind == PB_KIND_DOUBLE) return pb_fail(PB_ERR_UNSUPPORTED, "bilinear sampling does not support double-fisheye sources");
+    if (plan->device >= 0) {
+        int dev = -1;
+        PB_HIP(hipGetDevice(&dev));
+        if (dev != plan->device) return pb_fail(PB_ERR_INVALID, "plan was prepared on another device; create one plan per device");
+    }
+    const unsigned long long npx = (unsigned long long)P.dst.height * P.dst.width;
+    if (!src_frame_stride) src_frame_stride = 3ull * P.src.height * P.src.width;
+    if (!dst_frame_stride) dst_frame_stride = 3ull * npx;
+    if (dst_frame_stride < 3ull * npx) return pb_fail(PB_ERR_INVALID, "dst_frame_stride smaller than a frame");
+    hipStream_t st = (hipStream_t)stream;
+    if (pb_use_fast(plan)) {
+        const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
+        if (P.src.kind == PB_KIND_PANO) {
+            hipLaunchKernelGGL(pb_bilinear_hot_kernel<PB_KIND_PANO>, grid, block, 0, st, P, plan->table, src_dev, dst_dev, n_frames,
+                               src_frame_stride, dst_frame_stride);
+            if (plan->n_fail_tiles)
+                hipLaunchKernelGGL(pb_bilinear_fix_kernel<PB_KIND_PANO>, dim3(4u * plan->n_fail_tiles), dim3(PB_BLOCK), 0, st, P,
+                                   plan->fail_tiles, 0, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
+        } else {
+            hipLaunchKernelGGL(pb_bilinear_hot_kernel<PB_KIND_CAMERA>, grid, block, 0, st, P, plan->table, src_dev, dst_dev, n_frames,
+                               src_frame_stride, dst_frame_stride);
+            if (plan->n_fail_tiles)
+                hipLaunchKernelGGL(pb_bilinear_fix_kernel<PB_KIND_CAMERA>, dim3(4u * plan->n_fail_tiles), dim3(PB_BLOCK), 0, st, P,
+                                   plan->fail_tiles, 0, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
+        }
+    } else {
+        if (P.src.kind == PB_KIND_PANO)
+            hipLaunchKernelGGL(pb_bilinear_fix_kernel<PB_KIND_PANO>, dim3(pb_blocks(npx)), dim3(PB_BLOCK), 0, st, P, nullptr, 1, src_dev,
+                               dst_dev, n_frames, src_frame_stride, dst_frame_stride);
+        else
+            hipLaunchKernelGGL(pb_bilinear_fix_kernel<PB_KIND_CAMERA>, dim3(pb_blocks(npx)), dim3(PB_BLOCK), 0, st, P, nullptr, 1, src_dev,
+                               dst_dev, n_frames, src_frame_stride, dst_frame_stride);
     }
     PB_HIP(hipGetLastError());
     return PB_OK;
