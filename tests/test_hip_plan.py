@@ -138,3 +138,20 @@ def test_remap_is_graph_capturable():
     torch.cuda.synchronize()
     for f in range(4):
         assert torch.equal(outs[f], want2[f])
+
+
+def test_remap_batch_sharded_single_process():
+    """parallel.remap_batch_sharded without a process group = one shard holding every frame, launched in chunks."""
+    import photonbend_amd as pb
+    from photonbend_amd import parallel
+
+    fov = pb.utils.to_radians(180)
+    dst = pb.CameraImage(np.zeros((96, 96, 3), np.uint8), fov, pb.equidistant(), magnitude=47.5)
+    rot = pb.Rotation(0.2, 0.1, -0.4)
+    srcp = nat.make_proj(nat.KIND_PANO, 64, 128)
+    ids, outs = parallel.remap_batch_sharded(dst._proj(), [rot.rotation_matrix], srcp, lambda i: nat.synth_frame(64, 128, frame=i), 11, chunk=4)
+    assert ids == list(range(11)) and len(outs) == 11
+    for i in (0, 5, 10):
+        frame = nat.synth_frame(64, 128, frame=i).cpu().numpy()
+        want = pb.PanoramaImage(frame).process_coordinate_map(rot.rotate_coordinate_map(dst.get_coordinate_map()))
+        assert np.array_equal(outs[i].cpu().numpy(), want)
