@@ -1,0 +1,307 @@
+// Builds the c2 hot kernel up from its memory skeleton to find where the streaming rate is lost.
+//   16384 tiles; tile t pulls a source window of R rows x (16 * n16) bytes into LDS (LDS-DMA) and
+//   (stage >= 1) gathers 16 pixels per lane from it and stores a 32x32x3-byte output tile,
+//   (stage >= 2) runs a dependent packed-FMA chain like the tile model before the gather,
+//   (stage >= 3) every third tile fetches its pixels with scattered dword gathers instead of a window.
+// Rows are 24 576 B apart (c2's panorama pitch).  One wave = one tile at a time, WAVES waves per CU,
+// either one resident workgroup per CU (grid 256) or 4-wave workgroups dealt by the hardware.
+// build: hipcc --offload-arch=gfx950 -O3 -o exp_window exp_window.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+#define WIN_BYTES 12288
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct Args {
+    const uint8_t* src; uint8_t* dst; unsigned* sink;
+    int R, n16; unsigned rowbytes; int wins_per_row, n_tiles, stage, dst_w, rstride, spat, misalign, lpr;
+};
+
+template <int WAVES>
+__device__ __forceinline__ void one_tile(const Args& A, int w, unsigned* win, int lane, unsigned& acc) {
+    const int R = A.R, n16 = A.n16, lpr = A.lpr;
+    const unsigned inv = (65536u + lpr - 1) / lpr;
+    const unsigned lrow = ((unsigned)lane * inv) >> 16, chunk = (unsigned)lane - lrow * lpr;
+    const unsigned rpp = 64u / lpr;
+    const bool lane_on = lrow < rpp && chunk < (unsigned)n16;
+    const unsigned wr = (unsigned)w / A.wins_per_row, wc = (unsigned)w % A.wins_per_row;
+    const unsigned gbase = wr * A.rstride * A.rowbytes + wc * n16 * 16u + A.misalign;
+    const bool direct = A.stage >= 3 && (w % 3) == 0;
+    const unsigned pitch = 16u * lpr;
+    unsigned px[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) px[n] = lane * 3 + n + w;
+    if (!direct && A.stage >= 0) {
+        for (unsigned rowb = 0; rowb < (unsigned)R; rowb += rpp) {
+            const unsigned row = rowb + lrow;
+            const unsigned ga = gbase + row * A.rowbytes + 16u * chunk;
+            if (lane_on && row < (unsigned)R)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.src + ga),
+                                                 (__attribute__((address_space(3))) void*)(win + ((rowb * pitch) >> 2)), 16, 0, 0);
+        }
+    }
+    // per-pixel window coordinates: a smooth map of the 32x32 tile onto the R x (pitch / 3) window
+    const int xg = lane & 7, yb = lane >> 3;
+    unsigned la[16];
+    f2 c = {0.001f * lane, 0.002f * lane};
+    if (A.stage >= 2) {
+        const f2 m = {1.0001f, 0.9999f};
+        for (int i = 0; i < 36; ++i) c = __builtin_elementwise_fma(c, m, m);  // collapse-like dependent chain
+    }
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f2 v = c;
+            if (A.stage >= 2) {
+                const f2 m = {0.5f, 0.25f};
+                for (int i = 0; i < 9; ++i) v = __builtin_elementwise_fma(v, m, c);
+            }
+            const unsigned y = (unsigned)(yb + 8 * jr), x = (unsigned)(4 * xg + k);
+            unsigned dr = (y * (unsigned)R) >> 5, dc = (x * (pitch - 4u) / 3u) >> 5;
+            if (A.stage >= 2) { dr += ((unsigned)(int)v.x) & 0u; dc += ((unsigned)(int)v.y) & 0u; }
+            la[jr * 4 + k] = direct ? gbase + dr * A.rowbytes + dc * 3u : dr * pitch + dc * 3u;
+        }
+    if (direct) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) __builtin_memcpy(&px[n], A.src + la[n], 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (A.stage >= 1 || A.stage < 0) {
+        if (!direct && A.stage >= 0) {
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const unsigned l = la[n];
+                px[n] = __builtin_amdgcn_alignbyte(win[(l >> 2) + 1], win[l >> 2], l);
+            }
+        }
+        // output tile shapes (all 1024 px = 3 KiB per tile): 0: 32x32, 1: 64x16, 2: 128x8, 3: 3 KiB contiguous
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            u32x3 o;
+            o.x = __builtin_amdgcn_perm(px[jr * 4 + 1], px[jr * 4 + 0], 0x04020100u);
+            o.y = __builtin_amdgcn_perm(px[jr * 4 + 2], px[jr * 4 + 1], 0x05040201u);
+            o.z = __builtin_amdgcn_perm(px[jr * 4 + 3], px[jr * 4 + 2], 0x06050402u);
+            size_t off;
+            if (A.spat == 0) { const int tx = w & 127, ty = w >> 7; off = 3ull * ((size_t)(ty * 32 + (lane >> 3) + 8 * jr) * A.dst_w + tx * 32 + 4 * (lane & 7)); }
+            else if (A.spat == 1) { const int tx = w & 63, ty = w >> 6; off = 3ull * ((size_t)(ty * 16 + (lane >> 4) + 4 * jr) * A.dst_w + tx * 64 + 4 * (lane & 15)); }
+            else if (A.spat == 2) { const int tx = w & 31, ty = w >> 5; off = 3ull * ((size_t)(ty * 8 + (lane >> 5) + 2 * jr) * A.dst_w + tx * 128 + 4 * (lane & 31)); }
+            else off = (size_t)w * 3072 + jr * 768 + lane * 12;
+            __builtin_nontemporal_store(o, reinterpret_cast<u32x3*>(A.dst + off));
+        }
+    } else {
+        acc ^= win[(lane * 37 + w) % (WIN_BYTES / 4)];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_resident(const Args A) {
+    __shared__ __attribute__((aligned(16))) unsigned win_all[WAVES][WIN_BYTES / 4 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned acc = 0;
+    const int stride = gridDim.x * WAVES;
+    for (int w = blockIdx.x * WAVES + wave; w < A.n_tiles; w += stride) one_tile<WAVES>(A, w, win_all[wave], lane, acc);
+    if (acc == 0x12345678u) A.sink[0] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_dealt(const Args A) {
+    __shared__ __attribute__((aligned(16))) unsigned win_all[4][WIN_BYTES / 4 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned acc = 0;
+    const int w = blockIdx.x * 4 + wave;
+    if (w < A.n_tiles) one_tile<4>(A, w, win_all[wave], lane, acc);
+    if (acc == 0x12345678u) A.sink[0] = acc;
+}
+
+
+// "pair" variant: one wave = two horizontally adjacent 32x32 tiles (w, w + 1), one half-wave each:
+// two windows in LDS, 32 pixels per lane, stores cover 64-pixel rows (192 B per row, 4 rows per instruction)
+__global__ __launch_bounds__(128) void k_pair(const Args A) {
+    __shared__ __attribute__((aligned(16))) unsigned win_all[2][2][WIN_BYTES / 4 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w0 = (blockIdx.x * 2 + wave) * 2;
+    if (w0 >= A.n_tiles) return;
+    const int R = A.R, n16 = A.n16;
+    const unsigned inv = (65536u + n16 - 1) / n16;
+    const unsigned lrow = ((unsigned)lane * inv) >> 16, chunk = (unsigned)lane - lrow * n16;
+    const unsigned rpp = 64u / n16;
+    const bool lane_on = lrow < rpp;
+    const unsigned pitch = 16u * n16;
+    const int half = (lane >> 3) & 1;
+    const int w = w0 + half;                       // this lane's tile
+    const bool direct = A.stage >= 3 && (w % 3) == 0;
+    unsigned gb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const unsigned wr = (unsigned)(w0 + t) / A.wins_per_row, wc = (unsigned)(w0 + t) % A.wins_per_row;
+        gb[t] = wr * A.rstride * A.rowbytes + wc * n16 * 16u;
+        const bool tdirect = A.stage >= 3 && ((w0 + t) % 3) == 0;
+        if (!tdirect)
+            for (unsigned rowb = 0; rowb < (unsigned)R; rowb += rpp) {
+                const unsigned row = rowb + lrow;
+                const unsigned ga = gb[t] + row * A.rowbytes + 16u * chunk;
+                if (lane_on && row < (unsigned)R)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.src + ga),
+                                                     (__attribute__((address_space(3))) void*)(win_all[wave][t] + ((rowb * pitch) >> 2)), 16, 0, 0);
+            }
+    }
+    const unsigned gbase = half ? gb[1] : gb[0];
+    const unsigned* win = win_all[wave][0];
+    const unsigned wofs = half ? (unsigned)((WIN_BYTES / 4 + 4) * 4) : 0u;
+    const int xg = lane & 7, ys = lane >> 4;  // 4 px group inside the tile, row inside a group of 4
+    unsigned la[32];
+    f2 c = {0.001f * lane, 0.002f * lane};
+    if (A.stage >= 2) { const f2 m = {1.0001f, 0.9999f}; for (int i = 0; i < 36; ++i) c = __builtin_elementwise_fma(c, m, m); }
+#pragma unroll
+    for (int jr = 0; jr < 8; ++jr)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned y = (unsigned)(ys + 4 * jr), x = (unsigned)(4 * xg + k);
+            const unsigned dr = (y * (unsigned)R) >> 5, dc = (x * (pitch - 4u) / 3u) >> 5;
+            la[jr * 4 + k] = direct ? gbase + dr * A.rowbytes + dc * 3u : wofs + dr * pitch + dc * 3u;
+        }
+    unsigned px[32];
+    if (direct) {
+#pragma unroll
+        for (int n = 0; n < 32; ++n) __builtin_memcpy(&px[n], A.src + la[n], 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!direct) {
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            const unsigned l = la[n];
+            px[n] = __builtin_amdgcn_alignbyte(win[(l >> 2) + 1], win[l >> 2], l);
+        }
+    }
+    const int tx = w0 & 127, ty = w0 >> 7;
+#pragma unroll
+    for (int jr = 0; jr < 8; ++jr) {
+        u32x3 o;
+        o.x = __builtin_amdgcn_perm(px[jr * 4 + 1], px[jr * 4 + 0], 0x04020100u);
+        o.y = __builtin_amdgcn_perm(px[jr * 4 + 2], px[jr * 4 + 1], 0x05040201u);
+        o.z = __builtin_amdgcn_perm(px[jr * 4 + 3], px[jr * 4 + 2], 0x06050402u);
+        const size_t off = 3ull * ((size_t)(ty * 32 + ys + 4 * jr) * A.dst_w + tx * 32 + 4 * (lane & 15));
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x3*>(A.dst + off));
+    }
+}
+
+
+// "exchange" variant: 4 waves = a 64x64 block of 32x32 tiles (wave -> tile (wave >> 1, wave & 1) of the block);
+// gathered pixels are packed, parked in the (now dead) window LDS, and after one workgroup barrier every wave
+// stores a 16-row band of the block as 192-byte row pieces (4 rows per instruction).
+__global__ __launch_bounds__(256) void k_exchange(const Args A) {
+    __shared__ __attribute__((aligned(16))) unsigned win_all[4][WIN_BYTES / 4 + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bx = blockIdx.x & 63, by = blockIdx.x >> 6;        // 64 x 64 blocks of a 4096 x 4096 output
+    const int tx = 2 * bx + (wave & 1), ty = 2 * by + (wave >> 1);
+    const int w = ty * 128 + tx;
+    const int R = A.R, n16 = A.n16;
+    const unsigned inv = (65536u + n16 - 1) / n16;
+    const unsigned lrow = ((unsigned)lane * inv) >> 16, chunk = (unsigned)lane - lrow * n16;
+    const unsigned rpp = 64u / n16;
+    const bool lane_on = lrow < rpp;
+    const unsigned wr = (unsigned)w / A.wins_per_row, wc = (unsigned)w % A.wins_per_row;
+    const unsigned gbase = wr * A.rstride * A.rowbytes + wc * n16 * 16u;
+    const bool direct = A.stage >= 3 && (w % 3) == 0;
+    const unsigned pitch = 16u * n16;
+    unsigned* win = win_all[wave];
+    unsigned px[16];
+    if (!direct)
+        for (unsigned rowb = 0; rowb < (unsigned)R; rowb += rpp) {
+            const unsigned row = rowb + lrow;
+            const unsigned ga = gbase + row * A.rowbytes + 16u * chunk;
+            if (lane_on && row < (unsigned)R)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.src + ga),
+                                                 (__attribute__((address_space(3))) void*)(win + ((rowb * pitch) >> 2)), 16, 0, 0);
+        }
+    const int xg = lane & 7, yb = lane >> 3;
+    unsigned la[16];
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned y = (unsigned)(yb + 8 * jr), x = (unsigned)(4 * xg + k);
+            const unsigned dr = (y * (unsigned)R) >> 5, dc = (x * (pitch - 4u) / 3u) >> 5;
+            la[jr * 4 + k] = direct ? gbase + dr * A.rowbytes + dc * 3u : dr * pitch + dc * 3u;
+        }
+    if (direct) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) __builtin_memcpy(&px[n], A.src + la[n], 4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!direct) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const unsigned l = la[n];
+            px[n] = __builtin_amdgcn_alignbyte(win[(l >> 2) + 1], win[l >> 2], l);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // park: tile row y (0..31), 4-px group g (0..7) at dword (y * 8 + g) * 3
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+        u32x3 o;
+        o.x = __builtin_amdgcn_perm(px[jr * 4 + 1], px[jr * 4 + 0], 0x04020100u);
+        o.y = __builtin_amdgcn_perm(px[jr * 4 + 2], px[jr * 4 + 1], 0x05040201u);
+        o.z = __builtin_amdgcn_perm(px[jr * 4 + 3], px[jr * 4 + 2], 0x06050402u);
+        unsigned* p = win + ((yb + 8 * jr) * 8 + xg) * 3;
+        p[0] = o.x; p[1] = o.y; p[2] = o.z;
+    }
+    __syncthreads();
+    // band: wave stores block rows 16 * wave .. + 15; lane -> row (lane >> 4) + 4 * s, 4-px group lane & 15
+    const int g = lane & 15, rs = lane >> 4;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int yblk = 16 * wave + rs + 4 * s4;               // row inside the 64 x 64 block
+        const unsigned* srcw = win_all[(yblk >> 5) * 2 + (g >> 3)];
+        const unsigned* p = srcw + ((yblk & 31) * 8 + (g & 7)) * 3;
+        u32x3 o = {p[0], p[1], p[2]};
+        const size_t off = 3ull * ((size_t)(by * 64 + yblk) * A.dst_w + bx * 64 + 4 * g);
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x3*>(A.dst + off));
+    }
+}
+
+int main() {
+    const unsigned rowbytes = 24576, H = 4096;
+    const size_t bytes = (size_t)rowbytes * H;  // 100 MB
+    const size_t dbytes = 3ull * 4096 * 4096;
+    const int POOL = 6;
+    std::vector<uint8_t*> srcs(POOL), dsts(POOL);
+    for (int p = 0; p < POOL; p++) {
+        CK(hipMalloc((void**)&srcs[p], bytes + 80 * rowbytes)); CK(hipMemset(srcs[p], p + 1, bytes + 80 * rowbytes));
+        CK(hipMalloc((void**)&dsts[p], dbytes));
+    }
+    unsigned* sink; CK(hipMalloc((void**)&sink, 64));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int shapes[][2] = {{64, 11}, {64, 10}, {64, 9}, {64, 7}, {64, 6}, {64, 5}, {48, 13}, {48, 14}};
+    for (auto& sh : shapes)
+        for (int stage : {1})
+            for (int mis : {0, 1}) {
+                const int spat = 0;
+                Args A;
+                A.R = sh[0]; A.n16 = sh[1]; A.rowbytes = rowbytes; A.wins_per_row = rowbytes / (A.n16 * 16);
+                A.n_tiles = 16384; A.stage = stage; A.dst_w = 4096; A.sink = sink; A.spat = spat; A.misalign = 0; A.lpr = mis ? ((sh[1] + 3) & ~3) : sh[1];
+                if (A.n_tiles / A.wins_per_row * 32 + A.R + 2 > (int)H + 70) A.n_tiles = ((int)H + 60 - A.R) / 32 * A.wins_per_row;
+                A.rstride = 32;
+                auto launch = [&](int p) {
+                    A.src = srcs[p]; A.dst = dsts[p];
+                    k_dealt<<<(A.n_tiles + 3) / 4, 256>>>(A);
+                };
+                for (int i = 0; i < 5; i++) launch(i % POOL);
+                CK(hipDeviceSynchronize());
+                const int N = 40;
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < N; i++) launch(i % POOL);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("window %2d x %3d B, quad-padded lanes %d, stage %d: %5d tiles %7.2f us  (%.2f ns/tile)\n", sh[0], sh[1] * 16, mis, stage, A.n_tiles, ms * 1e3 / N, ms * 1e6 / N / A.n_tiles);
+            }
+    return 0;
+}
