@@ -1,0 +1,372 @@
+// pb_kernels_double.hpp - fast path for DOUBLE-fisheye sources (DoubleCameraImage.process_coordinate_map,
+// projection.py:408-462): the Gear-360 stitch (BASELINE c5) and every other chain that ends in a
+// side-by-side double fisheye, rotated or not.
+//
+// A double source is two camera sources - the left eye, and the right eye looking backwards and mirrored -
+// whose samples are blended per pixel: out = (l * fl + r * fr).astype(uint8), with fl = fr = 1.0 outside the
+// merge band (projection.py:440-444).  The plan therefore carries TWO tile tables, one per eye, built and
+// certified by the same kernels as a camera source's (pb_kernels_tile.hpp with SRC_KIND = PB_KIND_EYE_L /
+// PB_KIND_EYE_R: per-tile float32 models, source windows, every pixel's index compared with the faithful
+// one), plus a weight class per tile, also certified against the faithful chain for every pixel
+// (pb_double_pair_kernel):
+//   UNIT  every pixel of the tile has fl == fr == 1.0 exactly: the blend is the integer l + r (mod 256);
+//   ROW   unrotated panorama destination: the factors depend on the output row only and come from the
+//         separable path's row table (exact float64, pb_kernels_sep.hpp);
+//   else  the tile is listed as failed and recomputed by the faithful chain (merge band under a rotation).
+// pb_hot_double_kernel: one wave per 32x32 tile; both eyes' windows are pulled into the wave's LDS by
+// LDS-DMA while the two models are evaluated, pixels are gathered from LDS (or straight from the frame for
+// sparse windows), blended and stored.  pb_fix_double_kernel: faithful chain for failed tiles + fix pixels.
+// The union is bit-identical to the faithful kernel for every pixel, by construction.
+#pragma once
+#include "pb_kernels_sep.hpp"
+#include "pb_kernels_tile.hpp"
+
+#define PB_TILE_W_UNIT 64   // (left-eye entry) blend factors are exactly 1.0 for every pixel of the tile
+#define PB_TILE_W_ROW 128   // (left-eye entry) blend factors come from the row table
+
+struct PbTileCtx {
+    unsigned rowbytes, frame_bytes, safe_len;
+    int lane, xg, yb, W, H, X0, Y0;
+    float u[4];
+};
+
+struct PbDesc {  // the scalar part of a tile entry
+    int flags, anchor_r, anchor_c, win_rows, win_r0, win_c0, win_cols, win_n16, win_a0;
+};
+
+__device__ __forceinline__ PbDesc pb_load_desc(const PbTileEntry* __restrict__ e) {
+    PbDesc d;
+    d.flags = e->flags; d.anchor_r = e->anchor_r; d.anchor_c = e->anchor_c; d.win_rows = e->win_rows;
+    d.win_r0 = e->win_r0; d.win_c0 = e->win_c0; d.win_cols = e->win_cols; d.win_n16 = e->win_n16; d.win_a0 = e->win_a0;
+    return d;
+}
+
+#define PB_D_PLAIN(flags) ((flags) & (PB_TILE_LEAN | PB_TILE_DIRECT))
+#define PB_D_GENERIC(flags) (!((flags) & (PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK | PB_TILE_FAILED)))
+
+__device__ __forceinline__ int pb_d_lean_bytes(const PbDesc& D) { return (D.flags & PB_TILE_LEAN) ? D.win_rows * 16 * D.win_n16 : 0; }
+
+// The wave's LDS window is shared by the two eyes: LEAN windows take what they need (the plan made sure
+// they fit together), generic windows share the rest.
+__device__ __forceinline__ void pb_d_budgets(const PbDesc& L, const PbDesc& R, int& budget_l, int& budget_r) {
+    const int need_l = pb_d_lean_bytes(L), need_r = pb_d_lean_bytes(R);
+    const int rest = PB_WINLDS_BYTES - need_l - need_r;
+    const bool gen_l = PB_D_GENERIC(L.flags), gen_r = PB_D_GENERIC(R.flags);
+    const int share = ((gen_l && gen_r) ? rest / 2 : rest) & ~15;
+    budget_l = (L.flags & PB_TILE_LEAN) ? need_l : (gen_l ? share : 0);
+    budget_r = (R.flags & PB_TILE_LEAN) ? need_r : (gen_r ? share : 0);
+}
+
+// window geometry of a generic tile under an LDS budget (the rule of pb_win_tile)
+__device__ __forceinline__ void pb_d_generic_window(const PbDesc& D, const PbTileCtx& C, int budget, int& nrows, int& n16, unsigned& gbase) {
+    nrows = D.win_rows;
+    gbase = (unsigned)D.win_r0 * C.rowbytes + 3u * (unsigned)D.win_c0;
+    n16 = 1;
+    if (nrows > 0) {
+        n16 = (3 * D.win_cols + 15 + 1 + 15) >> 4;
+        if (n16 > 64) n16 = 64;
+        const int cap = budget / (16 * n16);
+        if (nrows > cap) nrows = cap;
+    }
+}
+
+// issue the LDS-DMA loads of one eye's source window (nothing for BLACK / DIRECT tiles)
+__device__ __forceinline__ void pb_d_issue(const PbDesc& D, const PbTileCtx& C, int budget, const uint8_t* __restrict__ s, unsigned* win) {
+    if (D.flags & PB_TILE_LEAN) {
+        const unsigned gbase = (unsigned)D.anchor_r * C.rowbytes + 3u * (unsigned)D.anchor_c;
+        pb_issue_window_loads(s, win, C.lane, gbase, C.rowbytes, D.win_rows, D.win_n16, C.safe_len);
+    } else if (PB_D_GENERIC(D.flags)) {
+        int nrows, n16;
+        unsigned gbase;
+        pb_d_generic_window(D, C, budget, nrows, n16, gbase);
+        if (nrows > 0) pb_issue_window_loads(s, win, C.lane, gbase, C.rowbytes, nrows, n16, C.safe_len);
+    }
+}
+
+// one eye's model math -> per-pixel addresses q[jr * 4 + k]
+//   LEAN: byte address in the eye's LDS window; DIRECT: byte offset in the frame; generic: (row << 16 | col) or -1
+template <int SRC_KIND>
+__device__ __forceinline__ void pb_d_math(const PbParams& P, const PbDesc& D, const PbTileCtx& C, const PbTileEntry* __restrict__ e,
+                                          unsigned q[16]) {
+    if (PB_D_PLAIN(D.flags)) {
+        const bool lean = (D.flags & PB_TILE_LEAN) != 0;
+        const unsigned pitch = lean ? 16u * (unsigned)D.win_n16 : C.rowbytes;
+        const unsigned off = lean ? (unsigned)D.win_a0 : (unsigned)D.anchor_r * C.rowbytes + 3u * (unsigned)D.anchor_c;
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            pb_f2 a[5];
+            pb_collapse_row(e, C.yb + 8 * jr, a);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const pb_f2 fv = pb_eval_row(a, C.u[k]);
+                const unsigned dr = (unsigned)(int)fv.x, dc = (unsigned)(int)fv.y;  // >= 0: truncation == floor
+                q[jr * 4 + k] = (lean ? __umul24(dr, pitch) : dr * pitch) + (__umul24(dc, 3u) + off);
+            }
+        }
+    } else if (PB_D_GENERIC(D.flags)) {
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            PbRowModel R;
+            pb_model_row(P, e, C.X0, C.Y0, C.yb + 8 * jr, 4 * C.xg, R);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[jr * 4 + k] = (unsigned)pb_model_px_rc<SRC_KIND>(P, R, 4 * C.xg, k);
+        }
+    }
+}
+
+// DIRECT tiles: 16 unaligned dword gathers per lane straight from the frame (land in a[])
+__device__ __forceinline__ void pb_d_direct_loads(const unsigned q[16], const uint8_t* __restrict__ s, unsigned a[16]) {
+#pragma unroll
+    for (int n = 0; n < 16; ++n) __builtin_memcpy(&a[n], s + q[n], 4);
+}
+
+// one eye's 16 pixels per lane -> a[] (low 3 bytes valid; DIRECT tiles already hold them)
+__device__ __forceinline__ void pb_d_gather(const PbDesc& D, const PbTileCtx& C, int budget, const unsigned q[16], const unsigned* win,
+                                            const uint8_t* __restrict__ s, unsigned a[16]) {
+    if (D.flags & PB_TILE_LEAN) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const unsigned l = q[n];
+            a[n] = __builtin_amdgcn_alignbyte(win[(l >> 2) + 1], win[l >> 2], l);
+        }
+    } else if (PB_D_GENERIC(D.flags)) {
+        int nrows, n16;
+        unsigned gbase;
+        pb_d_generic_window(D, C, budget, nrows, n16, gbase);
+        const unsigned a0 = gbase & 15u, pitch = 16u * (unsigned)n16, rb16 = C.rowbytes & 15u;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int v = (int)q[n];
+            unsigned px = 0;
+            if (v >= 0) {
+                const unsigned r = (unsigned)v >> 16, c = (unsigned)v & 0xFFFFu;
+                const unsigned row = r - (unsigned)D.win_r0;
+                const unsigned g = r * C.rowbytes + 3u * c;
+                const unsigned off = 3u * (c - (unsigned)D.win_c0) + ((a0 + row * rb16) & 15u);
+                if (row < (unsigned)nrows && off + 4u <= pitch && g + 4u <= C.safe_len) {
+                    const unsigned l = row * pitch + off;
+                    px = __builtin_amdgcn_alignbyte(win[(l >> 2) + 1], win[l >> 2], l) & 0xFFFFFFu;
+                } else if (g + 4u <= C.frame_bytes) {
+                    unsigned t;
+                    __builtin_memcpy(&t, s + g, 4);
+                    px = t & 0xFFFFFFu;
+                } else {
+                    px = (unsigned)s[g] | ((unsigned)s[g + 1] << 8) | ((unsigned)s[g + 2] << 16);
+                }
+            }
+            a[n] = px;
+        }
+    } else if (!(D.flags & PB_TILE_DIRECT)) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) a[n] = 0u;  // BLACK: this eye contributes nothing to the tile
+    }
+}
+
+template <bool ROWS>
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
+                                                                            const PbTileEntry* __restrict__ table_r,
+                                                                            const PbSepRow* __restrict__ rows,
+                                                                            const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                            int n_frames, unsigned long long src_stride,
+                                                                            unsigned long long dst_stride) {
+    __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 8];
+    PbTileCtx C;
+    C.lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tx, ty;
+    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
+    const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
+    const PbTileEntry* __restrict__ el = table_l + tile;
+    const PbTileEntry* __restrict__ er = table_r + tile;
+    const PbDesc DL = pb_load_desc(el), DR = pb_load_desc(er);
+    if ((DL.flags | DR.flags) & PB_TILE_FAILED) return;  // the fix kernel owns this tile
+    const bool by_row = ROWS && (DL.flags & PB_TILE_W_ROW) != 0;
+    C.rowbytes = 3u * (unsigned)P.src.width;
+    C.frame_bytes = C.rowbytes * (unsigned)P.src.height;  // < 2^31 (host check)
+    C.safe_len = C.frame_bytes & ~15u;
+    C.xg = C.lane & 7;
+    C.yb = C.lane >> 3;
+    C.W = P.dst.width;
+    C.H = P.dst.height;
+    C.X0 = tx * PB_TILE;
+    C.Y0 = ty * PB_TILE;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) C.u[k] = pb_tile_coord(4 * C.xg + k);
+    int budget_l, budget_r;
+    pb_d_budgets(DL, DR, budget_l, budget_r);
+    unsigned* win_l = win_all[wave];
+    unsigned* win_r = win_all[wave] + (budget_l >> 2);
+    unsigned ql[16], qr[16], al[16], ar[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) ql[n] = qr[n] = al[n] = ar[n] = 0u;
+    pb_d_issue(DL, C, budget_l, src, win_l);
+    pb_d_issue(DR, C, budget_r, src, win_r);
+    pb_d_math<PB_KIND_EYE_L>(P, DL, C, el, ql);
+    if (DL.flags & PB_TILE_DIRECT) pb_d_direct_loads(ql, src, al);
+    pb_d_math<PB_KIND_EYE_R>(P, DR, C, er, qr);
+    if (DR.flags & PB_TILE_DIRECT) pb_d_direct_loads(qr, src, ar);
+    double fl[4], fr[4];
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) fl[jr] = fr[jr] = 1.0;
+    if (by_row) {
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const PbSepRow R = rows[min(C.Y0 + C.yb + 8 * jr, C.H - 1)];
+            fl[jr] = R.f_l;
+            fr[jr] = R.f_r;
+        }
+    }
+    const int x = C.X0 + 4 * C.xg;
+    const bool inside = C.X0 + PB_TILE <= C.W && C.Y0 + PB_TILE <= C.H;
+    for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* s = src + (unsigned long long)f * src_stride;
+        uint8_t* d = dst + (unsigned long long)f * dst_stride;
+        // the addresses are loop-invariant; keep the compiler from hoisting everything derived from them out of
+        // the frame loop (hundreds of live registers for nothing)
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            asm volatile("" : "+v"(ql[n]));
+            asm volatile("" : "+v"(qr[n]));
+        }
+        if (f > 0) {
+            pb_d_issue(DL, C, budget_l, s, win_l);
+            pb_d_issue(DR, C, budget_r, s, win_r);
+            if (DL.flags & PB_TILE_DIRECT) pb_d_direct_loads(ql, s, al);
+            if (DR.flags & PB_TILE_DIRECT) pb_d_direct_loads(qr, s, ar);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both windows / the direct gathers have landed
+        pb_wave_sync();
+        pb_d_gather(DL, C, budget_l, ql, win_l, s, al);
+        pb_d_gather(DR, C, budget_r, qr, win_r, s, ar);
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            unsigned a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = pb_sep_blend(al[jr * 4 + k], ar[jr * 4 + k], fl[jr], fr[jr]);
+            const int y = C.Y0 + C.yb + 8 * jr;
+            if (!inside && y >= C.H) continue;
+            const unsigned long long off = 3ull * ((unsigned long long)y * C.W + x);
+            if ((inside || x + 3 < C.W) && (((uintptr_t)d + off) & 3u) == 0) {
+                __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));  // write-once output
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (inside || x + k < C.W) {
+                        d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+                        d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+                        d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+                    }
+            }
+        }
+        if (f + 1 < n_frames) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // every lane has read its samples: the windows may be refilled
+            pb_wave_sync();
+        }
+    }
+}
+
+// The faithful double-source pixel (the per-pixel body of pb_remap_kernel<PB_KIND_DOUBLE>).
+__device__ __forceinline__ void pb_double_exact_px(const PbParams& P, int i, int j, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                   int n_frames, unsigned long long src_stride, unsigned long long dst_stride) {
+    PbCoord c = pb_dst_coord(P, i, j);
+    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    const PbDoubleTap t = pb_src_double_taps(P, c);
+    const size_t p = (size_t)i * P.dst.width + j;
+    for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* s = src + (unsigned long long)f * src_stride;
+        const unsigned l = pb_load_px(s, t.il), r = pb_load_px(s, t.ir);
+        unsigned v = 0;
+        if (!c.inv)  // final_image[invalid_map] = 0, projection.py:460
+            v = pb_blend_u8(l & 0xFF, r & 0xFF, t.fl, t.fr) | (pb_blend_u8((l >> 8) & 0xFF, (r >> 8) & 0xFF, t.fl, t.fr) << 8) |
+                (pb_blend_u8((l >> 16) & 0xFF, (r >> 16) & 0xFF, t.fl, t.fr) << 16);
+        uint8_t* o = dst + (unsigned long long)f * dst_stride + 3 * p;
+        o[0] = (uint8_t)(v & 0xFF);
+        o[1] = (uint8_t)((v >> 8) & 0xFF);
+        o[2] = (uint8_t)((v >> 16) & 0xFF);
+    }
+}
+
+// The plan's fix list for a double source: blocks [0, 4 * n_fail_tiles) take failed tiles (256 px each), the
+// remaining blocks single pixels (a tile or pixel may be listed by both eyes: it is then written twice with
+// the same bytes).
+__global__ __launch_bounds__(PB_BLOCK) void pb_fix_double_kernel(const PbParams P, const int32_t* __restrict__ fail_tiles, int n_fail_tiles,
+                                                                 const int32_t* __restrict__ fix_px, int n_fix_px,
+                                                                 const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n_frames,
+                                                                 unsigned long long src_stride, unsigned long long dst_stride) {
+    int i, j;
+    if ((int)blockIdx.x < 4 * n_fail_tiles) {
+        const int t = fail_tiles[blockIdx.x >> 2];
+        const int ty = t / pb_tiles_x(P), tx = t - ty * pb_tiles_x(P);
+        const int local = (blockIdx.x & 3) * 256 + threadIdx.x;
+        i = ty * PB_TILE + (local >> 5);
+        j = tx * PB_TILE + (local & 31);
+        if (i >= P.dst.height || j >= P.dst.width) return;
+    } else {
+        const unsigned item = (blockIdx.x - 4u * n_fail_tiles) * PB_BLOCK + threadIdx.x;
+        if (item >= (unsigned)n_fix_px) return;
+        const unsigned p = (unsigned)fix_px[item];
+        i = p / (unsigned)P.dst.width;
+        j = p - (unsigned)i * (unsigned)P.dst.width;
+    }
+    pb_double_exact_px(P, i, j, src, dst, n_frames, src_stride, dst_stride);
+}
+
+// Plan creation, after both eyes' tables are built and certified.  One wave per tile:
+//  * a tile failed for one eye is failed for both (the hot kernel skips it, the fix kernel owns it);
+//  * two LEAN windows that do not fit the wave's LDS together: the larger one becomes DIRECT;
+//  * the weight class: the faithful factors of EVERY pixel of the tile are compared with 1.0 (UNIT) and, when
+//    a row table is given, with the table's entries (ROW); a tile that is neither goes to the fail list.
+// counters: [1] failed tiles (shared with pb_certify_kernel), [7] tiles whose factors are taken per row.
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_double_pair_kernel(const PbParams P, PbTileEntry* __restrict__ table_l,
+                                                                             PbTileEntry* __restrict__ table_r,
+                                                                             const PbSepRow* __restrict__ rows,
+                                                                             int32_t* __restrict__ fail_tiles,
+                                                                             unsigned* __restrict__ counters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int tx, ty;
+    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
+    const int tile = ty * pb_tiles_x(P) + tx;
+    PbTileEntry* el = table_l + tile;
+    PbTileEntry* er = table_r + tile;
+    const int fl0 = el->flags, fr0 = er->flags;
+    if ((fl0 | fr0) & PB_TILE_FAILED) {  // already on the fail list (by the eye that failed)
+        if (lane == 0) {
+            el->flags = PB_TILE_FAILED;
+            er->flags = PB_TILE_FAILED;
+        }
+        return;
+    }
+    const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
+    const int y = lane & 31, xh = (lane >> 5) * 16;
+    const int i = Y0 + y;
+    bool unit = true, row_ok = rows != nullptr;
+    for (int k = 0; k < 16; ++k) {
+        const int j = X0 + xh + k;
+        if (i >= P.dst.height || j >= P.dst.width) continue;
+        PbCoord c = pb_dst_coord(P, i, j);
+        for (int r = 0; r < P.n_rot; ++r) c = pb_rotate(P.R[r], c);
+        const PbDoubleTap t = pb_src_double_taps(P, c);
+        unit = unit && t.fl == 1.0 && t.fr == 1.0;
+        if (row_ok) row_ok = rows[i].f_l == t.fl && rows[i].f_r == t.fr && !c.inv;
+    }
+    const bool all_unit = __builtin_amdgcn_ballot_w64(!unit) == 0;
+    const bool all_row = rows != nullptr && __builtin_amdgcn_ballot_w64(!row_ok) == 0;
+    if (lane != 0) return;
+    if (!all_unit && !all_row) {
+        el->flags = PB_TILE_FAILED;
+        er->flags = PB_TILE_FAILED;
+        fail_tiles[atomicAdd(&counters[1], 1u)] = tile;
+        return;
+    }
+    int nl = fl0, nr = fr0;
+    const int need_l = (nl & PB_TILE_LEAN) ? el->win_rows * 16 * el->win_n16 : 0;
+    const int need_r = (nr & PB_TILE_LEAN) ? er->win_rows * 16 * er->win_n16 : 0;
+    if (need_l + need_r > PB_WINLDS_BYTES) {
+        if (need_l >= need_r) nl = (nl & ~PB_TILE_LEAN) | PB_TILE_DIRECT;
+        else nr = (nr & ~PB_TILE_LEAN) | PB_TILE_DIRECT;
+    }
+    nl |= all_unit ? PB_TILE_W_UNIT : PB_TILE_W_ROW;
+    if (!all_unit) atomicAdd(&counters[7], 1u);
+    el->flags = nl;
+    er->flags = nr;
+}

@@ -641,6 +641,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_window_kernel(const PbP
     const unsigned safe_len = (rowbytes * (unsigned)h) & ~15u;
     if (not_plain != 0 || w >= 32768 || h >= 32768) return;
     const int lr0 = rmin - 1, lc0 = cmin - 1, rows = rmax - rmin + 3, cols = cmax - cmin + 3;
+    // (an eye's margin texel may lie in the other eye's half: inside the frame, never sampled)
     if (lr0 < 0 || lc0 < 0 || lr0 + rows > h || lc0 + cols > w) return;
     // the last sample's 4-byte read must stay inside the frame
     if ((unsigned)(lr0 + rows - 1) * rowbytes + 3u * (unsigned)(lc0 + cols - 1) + 4u > rowbytes * (unsigned)h) return;

@@ -154,12 +154,35 @@ __device__ __forceinline__ PbCoord pb_dst_coord_real(const PbParams& P, double f
     return c;
 }
 
-// pre-truncation source coordinates (row-like, column-like) of a pano / camera source
+// One eye of a double-fisheye source seen as a source of its own (plans only; never part of the ABI):
+// PB_KIND_EYE_L samples columns [0, w // 2) of the side-by-side frame, PB_KIND_EYE_R columns [w // 2, w),
+// mirrored (projection.py:430-431).
+#define PB_KIND_EYE_L 3
+#define PB_KIND_EYE_R 4
+
+// columns of the frame a source kind may sample: [cmin, cmax)
+template <int SRC_KIND>
+__device__ __forceinline__ void pb_src_col_range(const PbParams& P, int& cmin, int& cmax) {
+    cmin = (SRC_KIND == PB_KIND_EYE_R) ? P.src_eye_w : 0;
+    cmax = (SRC_KIND == PB_KIND_EYE_L) ? P.src_eye_w : P.src.width;
+}
+
+// pre-truncation source coordinates (row-like, column-like) of a pano / camera source (or one eye)
 template <int SRC_KIND>
 __device__ __forceinline__ void pb_src_pretrunc(const PbParams& P, const PbCoord& c, double& f0, double& f1) {
     if (SRC_KIND == PB_KIND_PANO) {
         f0 = c.lat / P.src_hseg;
         f1 = c.lon / P.src_wseg + P.src_half_w;
+    } else if (SRC_KIND == PB_KIND_EYE_R) {
+        // the right eye looks backwards (projection.py:426-427) and is mirrored: sampled column =
+        // eye_w + (eye_w_right - 1 - x) with x = trunc(re + cx_r), i.e. floor(w - (re + cx_r)) wherever that
+        // is not an exact integer (those pixels end on the plan's fix list like every other model miss)
+        const double lat_r = (c.lat * -1.0) + PB_PI;
+        const double dist = pb_lens_forward(P.src.lens, lat_r, P.rect_max) * P.src.f_distance;
+        double sl, cl;
+        sincos(c.lon, &sl, &cl);
+        f0 = ((sl * dist) * -1.0) + P.src_cy;
+        f1 = (double)P.src.width - ((cl * dist) + P.src_cx_r);
     } else {
         const double dist = pb_lens_forward(P.src.lens, c.lat, P.rect_max) * P.src.f_distance;
         double sl, cl;

@@ -82,6 +82,8 @@ template <int SRC_KIND>
 __device__ __forceinline__ int pb_exact_index(const PbParams& P, int i, int j) {
     PbCoord c = pb_dst_coord(P, i, j);
     for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    if (SRC_KIND == PB_KIND_EYE_L) return pb_src_double_taps(P, c).il;
+    if (SRC_KIND == PB_KIND_EYE_R) return pb_src_double_taps(P, c).ir;
     return (SRC_KIND == PB_KIND_PANO) ? pb_src_pano_index(P, c) : pb_src_camera_index(P, c);
 }
 
@@ -172,7 +174,9 @@ __device__ __forceinline__ int pb_model_px_rc(const PbParams& P, const PbRowMode
         if (r >= h) r -= h;  // lat = pi wraps to row 0
         if (c >= w) c -= w;
     }
-    int id = ((unsigned)r < (unsigned)h && (unsigned)c < (unsigned)w) ? ((r << 16) | c) : -1;
+    int cmin, cmax;
+    pb_src_col_range<SRC_KIND>(P, cmin, cmax);
+    int id = ((unsigned)r < (unsigned)h && c >= cmin && c < cmax) ? ((r << 16) | c) : -1;
     if (pb_row_px_invalid(R, k)) id = -1;  // invalid destination pixel -> black
     return id;
 }
@@ -188,7 +192,9 @@ __device__ __forceinline__ int pb_model_px(const PbParams& P, const PbRowModel& 
         if (r >= h) r -= h;
         if (c >= w) c -= w;
     }
-    int id = ((unsigned)r < (unsigned)h && (unsigned)c < (unsigned)w) ? (int)__umul24(r, w) + c : -1;
+    int cmin, cmax;
+    pb_src_col_range<SRC_KIND>(P, cmin, cmax);
+    int id = ((unsigned)r < (unsigned)h && c >= cmin && c < cmax) ? (int)__umul24(r, w) + c : -1;
     if (pb_row_px_invalid(R, k)) id = -1;
     return id;
 }

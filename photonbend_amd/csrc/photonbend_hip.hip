@@ -19,6 +19,7 @@
 #include "pb_tile.hpp"
 #include "pb_kernels_tile.hpp"
 #include "pb_kernels_sep.hpp"
+#include "pb_kernels_double.hpp"
 #include "pb_kernels_bilinear.hpp"
 
 struct pb_plan {
@@ -35,6 +36,10 @@ struct pb_plan {
     int sep_ready = 0;
     PbSepRow* sep_rows = nullptr;
     PbSepCol* sep_cols = nullptr;
+    // double-fisheye source: one certified tile table per eye (pb_kernels_double.hpp); `table` is the left eye's
+    int dbl_ready = 0;
+    PbTileEntry* table_r = nullptr;
+    unsigned n_row_weight_tiles = 0;
 };
 
 static thread_local std::string g_err;
@@ -98,8 +103,11 @@ static inline unsigned pb_num_tiles(const PbParams& P) {
     return ((P.dst.width + PB_TILE - 1) / PB_TILE) * ((P.dst.height + PB_TILE - 1) / PB_TILE);
 }
 
-static bool pb_fast_possible(const PbParams& P) {
+static bool pb_fast_possible_dims(const PbParams& P) {
     // the tile models need 32-bit squares of the doubled pixel offsets and u24 index arithmetic
+    return P.dst.width <= 16384 && P.dst.height <= 16384 && P.src.width < 32768 && P.src.height < 32768;
+}
+static bool pb_fast_possible(const PbParams& P) {
     return P.src.kind != PB_KIND_DOUBLE && P.dst.width <= 16384 && P.dst.height <= 16384 && P.src.width < (1 << 24) &&
            P.src.height < (1 << 24);
 }
@@ -138,6 +146,38 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             if (hipMemcpy(&nbad, bad, sizeof(nbad), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
             pl->sep_ready = nbad == 0;
             pl->diff_pixels = nbad;
+        }
+        if (P.src.kind == PB_KIND_DOUBLE) {
+            // two certified tile tables (one per eye) + the weight class of every tile
+            if (!pb_fast_possible_dims(P)) break;
+            const unsigned ntiles = pb_num_tiles(P);
+            const unsigned cap = 2u * ntiles * PB_TILE_FAIL_LIMIT;
+            if (hipMalloc((void**)&pl->table, (size_t)ntiles * sizeof(PbTileEntry)) != hipSuccess ||
+                hipMalloc((void**)&pl->table_r, (size_t)ntiles * sizeof(PbTileEntry)) != hipSuccess ||
+                hipMalloc((void**)&pl->fail_tiles, (size_t)2 * ntiles * sizeof(int32_t)) != hipSuccess ||
+                hipMalloc((void**)&pl->fix_px, (size_t)cap * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            unsigned* counters = reinterpret_cast<unsigned*>(scratch + 4);
+            if (hipMemset(counters, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
+            hipLaunchKernelGGL(pb_model_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table);
+            hipLaunchKernelGGL(pb_window_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table);
+            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters);
+            hipLaunchKernelGGL(pb_model_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r);
+            hipLaunchKernelGGL(pb_window_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r);
+            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r, pl->fail_tiles, pl->fix_px, cap, counters);
+            hipLaunchKernelGGL(pb_double_pair_kernel, grid, block, 0, 0, P, pl->table, pl->table_r, pl->sep_ready ? pl->sep_rows : nullptr,
+                               pl->fail_tiles, counters);
+            unsigned res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            pl->n_lean_tiles = res[4];
+            pl->n_black_tiles = res[5];
+            pl->n_direct_tiles = res[6];
+            pl->n_row_weight_tiles = res[7];
+            pl->n_fix_px = res[0] > cap ? cap : res[0];
+            pl->n_fail_tiles = res[1];
+            pl->diff_pixels = res[2];
+            pl->n_tiles = ntiles;
+            pl->dbl_ready = 1;
             break;
         }
         if (!pb_fast_possible(P)) break;
@@ -172,7 +212,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
     if (rc != PB_OK) {
         g_err = std::string("plan preparation on device failed: ") + hipGetErrorString(hipGetLastError());
         (void)hipFree(pl->table); (void)hipFree(pl->fail_tiles); (void)hipFree(pl->fix_px);
-        (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols);
+        (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols); (void)hipFree(pl->table_r);
+        pl->table_r = nullptr; pl->sep_ready = 0; pl->dbl_ready = 0;
         pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr; pl->sep_rows = nullptr; pl->sep_cols = nullptr;
     }
     (void)hipFree(scratch);
@@ -303,6 +344,7 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->fix_px);
     (void)hipFree(plan->sep_rows);
     (void)hipFree(plan->sep_cols);
+    (void)hipFree(plan->table_r);
     delete plan;
 }
 
@@ -335,7 +377,20 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
     if (!dst_frame_stride) dst_frame_stride = 3ull * npx;
     if (dst_frame_stride < 3ull * npx) return pb_fail(PB_ERR_INVALID, "dst_frame_stride smaller than a frame");
     hipStream_t st = (hipStream_t)stream;
-    if (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL) {
+    const bool windowable = ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;  // LDS-DMA row segments
+    if (plan->dbl_ready && plan->mode != PB_MODE_FAITHFUL && plan->mode != PB_MODE_FAST_DIRECT && windowable) {
+        const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
+        if (plan->sep_ready)
+            hipLaunchKernelGGL(pb_hot_double_kernel<true>, grid, block, 0, st, P, plan->table, plan->table_r, plan->sep_rows, src_dev, dst_dev,
+                               n_frames, src_frame_stride, dst_frame_stride);
+        else
+            hipLaunchKernelGGL(pb_hot_double_kernel<false>, grid, block, 0, st, P, plan->table, plan->table_r, nullptr, src_dev, dst_dev,
+                               n_frames, src_frame_stride, dst_frame_stride);
+        const unsigned fix_blocks = 4u * plan->n_fail_tiles + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
+        if (fix_blocks)
+            hipLaunchKernelGGL(pb_fix_double_kernel, dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, plan->fail_tiles, (int)plan->n_fail_tiles,
+                               plan->fix_px, (int)plan->n_fix_px, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
+    } else if (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL) {
         hipLaunchKernelGGL(pb_sep_double_kernel, dim3(pb_hot_blocks(P)), dim3(64 * PB_TILE_WAVES), 0, st, P, plan->sep_rows, plan->sep_cols,
                            src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
     } else if (pb_use_fast(plan)) {
@@ -443,15 +498,17 @@ int pb_plan_set_mode(pb_plan* plan, int mode) {
 int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats7, long long* thresholds4) {
     long long* stats5 = stats7;
     if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
-    if (fast_path_enabled) *fast_path_enabled = (pb_use_fast(plan) || (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL)) ? 1 : 0;
+    if (fast_path_enabled)
+        *fast_path_enabled = (pb_use_fast(plan) || ((plan->sep_ready || plan->dbl_ready) && plan->mode != PB_MODE_FAITHFUL)) ? 1 : 0;
     if (stats5) {
-        stats5[0] = plan->fast_ready ? (long long)plan->n_tiles : -1;
-        stats5[1] = plan->fast_ready ? (long long)plan->n_fail_tiles : -1;
-        stats5[2] = plan->fast_ready ? (long long)plan->n_fix_px : -1;
-        stats5[3] = plan->fast_ready ? plan->diff_pixels : -1;
-        stats5[4] = plan->fast_ready ? (long long)plan->n_lean_tiles : -1;
-        stats5[5] = plan->fast_ready ? (long long)plan->n_black_tiles : -1;
-        stats5[6] = plan->fast_ready ? (long long)plan->n_direct_tiles : -1;
+        const bool have = plan->fast_ready || plan->dbl_ready;  // a double source counts both eyes' tables
+        stats5[0] = have ? (long long)plan->n_tiles : -1;
+        stats5[1] = have ? (long long)plan->n_fail_tiles : -1;
+        stats5[2] = have ? (long long)plan->n_fix_px : -1;
+        stats5[3] = have ? plan->diff_pixels : -1;
+        stats5[4] = have ? (long long)plan->n_lean_tiles : -1;
+        stats5[5] = have ? (long long)plan->n_black_tiles : -1;
+        stats5[6] = have ? (long long)plan->n_direct_tiles : -1;
     }
     if (thresholds4) {
         thresholds4[0] = plan->P.inv_lo[0];
