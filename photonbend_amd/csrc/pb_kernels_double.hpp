@@ -162,10 +162,17 @@ __device__ __forceinline__ void pb_d_gather(const PbDesc& D, const PbTileCtx& C,
     }
 }
 
-template <bool ROWS>
+// forward: the faithful double-source pixel (below)
+__device__ __forceinline__ void pb_double_exact_px(const PbParams& P, int i, int j, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                   int n_frames, unsigned long long src_stride, unsigned long long dst_stride);
+
+// ROWS: a row table exists (unrotated panorama destination).  FUSED (single frame, no failed tiles, short fix
+// list): the wave also recomputes its tile's fix pixels, after its own stores - no second launch.
+template <bool ROWS, bool FUSED>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
                                                                             const PbTileEntry* __restrict__ table_r,
                                                                             const PbSepRow* __restrict__ rows,
+                                                                            const int32_t* __restrict__ fix_px,
                                                                             const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                             int n_frames, unsigned long long src_stride,
                                                                             unsigned long long dst_stride) {
@@ -218,7 +225,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     }
     const int x = C.X0 + 4 * C.xg;
     const bool inside = C.X0 + PB_TILE <= C.W && C.Y0 + PB_TILE <= C.H;
-    for (int f = 0; f < n_frames; ++f) {
+    const int frames = FUSED ? 1 : n_frames;
+    for (int f = 0; f < frames; ++f) {
         const uint8_t* s = src + (unsigned long long)f * src_stride;
         uint8_t* d = dst + (unsigned long long)f * dst_stride;
         // the addresses are loop-invariant; keep the compiler from hoisting everything derived from them out of
@@ -258,9 +266,23 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
                     }
             }
         }
-        if (f + 1 < n_frames) {
+        if (f + 1 < frames) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // every lane has read its samples: the windows may be refilled
             pb_wave_sync();
+        }
+    }
+    if (FUSED) {
+        const int nl = el->fix_cnt, nr = er->fix_cnt;  // <= PB_TILE_FAIL_LIMIT each (a pixel listed by both eyes is written twice)
+        if (nl + nr > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own stores to these pixels have completed
+            for (int base = 0; base < nl + nr; base += 64) {
+                const int n = base + C.lane;
+                if (n < nl + nr) {
+                    const unsigned p = (unsigned)fix_px[n < nl ? el->fix_off + n : er->fix_off + (n - nl)];
+                    const int i = (int)(p / (unsigned)C.W), j = (int)(p - (unsigned)i * (unsigned)C.W);
+                    pb_double_exact_px(P, i, j, src, dst, 1, src_stride, dst_stride);
+                }
+            }
         }
     }
 }

@@ -163,6 +163,20 @@ __device__ __forceinline__ void pb_model_px_raw(const PbRowModel& R, int xh, int
     c = R.anchor_c + (int)floorf(f.y);
 }
 
+// The reference converts a fisheye source's coordinates to pixels by TRUNCATION (astype(int), projection.py:254-259):
+// anything in (-1, 0) becomes pixel 0 and is sampled, where the floor of the model says -1.  (An exact -1.0
+// differs the other way; such pixels end on the plan's fix list like every other model miss.)
+template <int SRC_KIND>
+__device__ __forceinline__ void pb_model_trunc_edge(const PbParams& P, int& r, int& c) {
+    if (SRC_KIND == PB_KIND_PANO) return;
+    if (r == -1) r = 0;
+    if (SRC_KIND == PB_KIND_EYE_R) {
+        if (c == P.src.width) c = P.src.width - 1;  // the mirrored column of x in (-1, 0)
+    } else if (c == -1) {
+        c = 0;
+    }
+}
+
 // Source (row, col) of pixel x = xh + k packed as (r << 16 | c), or -1 = black.  Needs src dims < 32768.
 template <int SRC_KIND>
 __device__ __forceinline__ int pb_model_px_rc(const PbParams& P, const PbRowModel& R, int xh, int k) {
@@ -174,6 +188,7 @@ __device__ __forceinline__ int pb_model_px_rc(const PbParams& P, const PbRowMode
         if (r >= h) r -= h;  // lat = pi wraps to row 0
         if (c >= w) c -= w;
     }
+    pb_model_trunc_edge<SRC_KIND>(P, r, c);
     int cmin, cmax;
     pb_src_col_range<SRC_KIND>(P, cmin, cmax);
     int id = ((unsigned)r < (unsigned)h && c >= cmin && c < cmax) ? ((r << 16) | c) : -1;
@@ -192,6 +207,7 @@ __device__ __forceinline__ int pb_model_px(const PbParams& P, const PbRowModel& 
         if (r >= h) r -= h;
         if (c >= w) c -= w;
     }
+    pb_model_trunc_edge<SRC_KIND>(P, r, c);
     int cmin, cmax;
     pb_src_col_range<SRC_KIND>(P, cmin, cmax);
     int id = ((unsigned)r < (unsigned)h && c >= cmin && c < cmax) ? (int)__umul24(r, w) + c : -1;

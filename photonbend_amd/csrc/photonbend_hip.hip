@@ -380,14 +380,19 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
     const bool windowable = ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;  // LDS-DMA row segments
     if (plan->dbl_ready && plan->mode != PB_MODE_FAITHFUL && plan->mode != PB_MODE_FAST_DIRECT && windowable) {
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
-        if (plan->sep_ready)
-            hipLaunchKernelGGL(pb_hot_double_kernel<true>, grid, block, 0, st, P, plan->table, plan->table_r, plan->sep_rows, src_dev, dst_dev,
-                               n_frames, src_frame_stride, dst_frame_stride);
-        else
-            hipLaunchKernelGGL(pb_hot_double_kernel<false>, grid, block, 0, st, P, plan->table, plan->table_r, nullptr, src_dev, dst_dev,
-                               n_frames, src_frame_stride, dst_frame_stride);
+        // the hot waves take a short fix list along (single frame, no failed tiles); otherwise a second launch
+        const bool fused = n_frames == 1 && plan->n_fail_tiles == 0 && plan->n_fix_px <= 2048;
+        const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
+#define PB_LAUNCH_DOUBLE(ROWS, FUSED)                                                                                              \
+    hipLaunchKernelGGL((pb_hot_double_kernel<ROWS, FUSED>), grid, block, 0, st, P, plan->table, plan->table_r, rows, plan->fix_px, \
+                       src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride)
+        if (rows && fused) PB_LAUNCH_DOUBLE(true, true);
+        else if (rows) PB_LAUNCH_DOUBLE(true, false);
+        else if (fused) PB_LAUNCH_DOUBLE(false, true);
+        else PB_LAUNCH_DOUBLE(false, false);
+#undef PB_LAUNCH_DOUBLE
         const unsigned fix_blocks = 4u * plan->n_fail_tiles + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
-        if (fix_blocks)
+        if (!fused && fix_blocks)
             hipLaunchKernelGGL(pb_fix_double_kernel, dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, plan->fail_tiles, (int)plan->n_fail_tiles,
                                plan->fix_px, (int)plan->n_fix_px, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
     } else if (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL) {
