@@ -12,7 +12,10 @@
 //   UNIT  every pixel of the tile has fl == fr == 1.0 exactly: the blend is the integer l + r (mod 256);
 //   ROW   unrotated panorama destination: the factors depend on the output row only and come from the
 //         separable path's row table (exact float64, pb_kernels_sep.hpp);
-//   else  the tile is listed as failed and recomputed by the faithful chain (merge band under a rotation).
+//   LAT   any other tile that touches the merge band (rotated chains, fisheye destinations): the plan stores the
+//         faithful float64 latitude of each of its pixels (8 KiB per tile); the factors are the reference's own
+//         function of that latitude, evaluated per pixel - exact;
+//   (a tile beyond the latitude table's capacity is listed as failed and recomputed by the faithful chain).
 // pb_hot_double_kernel: one wave per 32x32 tile; both eyes' windows are pulled into the wave's LDS by
 // LDS-DMA while the two models are evaluated, pixels are gathered from LDS (or straight from the frame for
 // sparse windows), blended and stored.  pb_fix_double_kernel: faithful chain for failed tiles + fix pixels.
@@ -23,6 +26,8 @@
 
 #define PB_TILE_W_UNIT 64   // (left-eye entry) blend factors are exactly 1.0 for every pixel of the tile
 #define PB_TILE_W_ROW 128   // (left-eye entry) blend factors come from the row table
+#define PB_TILE_W_LAT 256   // (left-eye entry) blend factors from the stored per-pixel latitudes (slot aux_off)
+#define PB_LAT_TILE_DOUBLES (PB_TILE * PB_TILE)
 
 struct PbTileCtx {
     unsigned rowbytes, frame_bytes, safe_len;
@@ -166,12 +171,14 @@ __device__ __forceinline__ void pb_d_gather(const PbDesc& D, const PbTileCtx& C,
 __device__ __forceinline__ void pb_double_exact_px(const PbParams& P, int i, int j, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                    int n_frames, unsigned long long src_stride, unsigned long long dst_stride);
 
-// ROWS: a row table exists (unrotated panorama destination).  FUSED (single frame, no failed tiles, short fix
-// list): the wave also recomputes its tile's fix pixels, after its own stores - no second launch.
-template <bool ROWS, bool FUSED>
+// WMODE 0: every tile is UNIT; 1: a row table exists (unrotated panorama destination); 2: a latitude table exists.
+// FUSED (single frame, no failed tiles, short fix list): the wave also recomputes its tile's fix pixels, after
+// its own stores - no second launch.
+template <int WMODE, bool FUSED>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
                                                                             const PbTileEntry* __restrict__ table_r,
                                                                             const PbSepRow* __restrict__ rows,
+                                                                            const double* __restrict__ lat_tab,
                                                                             const int32_t* __restrict__ fix_px,
                                                                             const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                             int n_frames, unsigned long long src_stride,
@@ -187,7 +194,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     const PbTileEntry* __restrict__ er = table_r + tile;
     const PbDesc DL = pb_load_desc(el), DR = pb_load_desc(er);
     if ((DL.flags | DR.flags) & PB_TILE_FAILED) return;  // the fix kernel owns this tile
-    const bool by_row = ROWS && (DL.flags & PB_TILE_W_ROW) != 0;
+    const bool by_row = WMODE == 1 && (DL.flags & PB_TILE_W_ROW) != 0;
+    const bool by_lat = WMODE == 2 && (DL.flags & PB_TILE_W_LAT) != 0;
     C.rowbytes = 3u * (unsigned)P.src.width;
     C.frame_bytes = C.rowbytes * (unsigned)P.src.height;  // < 2^31 (host check)
     C.safe_len = C.frame_bytes & ~15u;
@@ -212,6 +220,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     if (DL.flags & PB_TILE_DIRECT) pb_d_direct_loads(ql, src, al);
     pb_d_math<PB_KIND_EYE_R>(P, DR, C, er, qr);
     if (DR.flags & PB_TILE_DIRECT) pb_d_direct_loads(qr, src, ar);
+    // blend factors: per row group (UNIT / ROW), or per pixel from the stored latitudes (LAT; the loads fly with
+    // the window loads, the factors are evaluated at the blend)
     double fl[4], fr[4];
 #pragma unroll
     for (int jr = 0; jr < 4; ++jr) fl[jr] = fr[jr] = 1.0;
@@ -222,6 +232,14 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
             fl[jr] = R.f_l;
             fr[jr] = R.f_r;
         }
+    }
+    double lat[WMODE == 2 ? 16 : 1];
+    if (by_lat) {
+        const double* __restrict__ lt = lat_tab + (size_t)el->aux_off * PB_LAT_TILE_DOUBLES;
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lat[WMODE == 2 ? jr * 4 + k : 0] = lt[(C.yb + 8 * jr) * PB_TILE + 4 * C.xg + k];
     }
     const int x = C.X0 + 4 * C.xg;
     const bool inside = C.X0 + PB_TILE <= C.W && C.Y0 + PB_TILE <= C.H;
@@ -235,6 +253,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
         for (int n = 0; n < 16; ++n) {
             asm volatile("" : "+v"(ql[n]));
             asm volatile("" : "+v"(qr[n]));
+            if (WMODE == 2) asm volatile("" : "+v"(lat[WMODE == 2 ? n : 0]));
         }
         if (f > 0) {
             pb_d_issue(DL, C, budget_l, s, win_l);
@@ -250,7 +269,15 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
         for (int jr = 0; jr < 4; ++jr) {
             unsigned a[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = pb_sep_blend(al[jr * 4 + k], ar[jr * 4 + k], fl[jr], fr[jr]);
+            for (int k = 0; k < 4; ++k) {
+                double wl = fl[jr], wr = fr[jr];
+                if (WMODE == 2 && by_lat) {
+                    const double t = lat[WMODE == 2 ? jr * 4 + k : 0];
+                    wl = pb_merge_factor(P, t);
+                    wr = pb_merge_factor(P, (t * -1.0) + PB_PI);  // the right eye's latitude, projection.py:426-427
+                }
+                a[k] = pb_sep_blend(al[jr * 4 + k], ar[jr * 4 + k], wl, wr);
+            }
             const int y = C.Y0 + C.yb + 8 * jr;
             if (!inside && y >= C.H) continue;
             const unsigned long long off = 3ull * ((unsigned long long)y * C.W + x);
@@ -337,13 +364,14 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_fix_double_kernel(const PbParams 
 //  * a tile failed for one eye is failed for both (the hot kernel skips it, the fix kernel owns it);
 //  * two LEAN windows that do not fit the wave's LDS together: the larger one becomes DIRECT;
 //  * the weight class: the faithful factors of EVERY pixel of the tile are compared with 1.0 (UNIT) and, when
-//    a row table is given, with the table's entries (ROW); a tile that is neither goes to the fail list.
-// counters: [1] failed tiles (shared with pb_certify_kernel), [7] tiles whose factors are taken per row.
+//    a row table is given, with the table's entries (ROW); a tile that is neither gets a slot of the latitude
+//    table (LAT, filled by pb_double_lat_kernel) or, beyond lat_capacity slots, goes to the fail list.
+// counters: [1] failed tiles (shared with pb_certify_kernel), [7] ROW tiles, [8] LAT tiles (= slots handed out).
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_double_pair_kernel(const PbParams P, PbTileEntry* __restrict__ table_l,
                                                                              PbTileEntry* __restrict__ table_r,
                                                                              const PbSepRow* __restrict__ rows,
                                                                              int32_t* __restrict__ fail_tiles,
-                                                                             unsigned* __restrict__ counters) {
+                                                                             unsigned* __restrict__ counters, unsigned lat_capacity) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int tx, ty;
     if (!pb_tile_of_wave(P, wave, tx, ty)) return;
@@ -374,11 +402,17 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_double_pair_kernel(cons
     const bool all_unit = __builtin_amdgcn_ballot_w64(!unit) == 0;
     const bool all_row = rows != nullptr && __builtin_amdgcn_ballot_w64(!row_ok) == 0;
     if (lane != 0) return;
+    int wclass = all_unit ? PB_TILE_W_UNIT : PB_TILE_W_ROW;
     if (!all_unit && !all_row) {
-        el->flags = PB_TILE_FAILED;
-        er->flags = PB_TILE_FAILED;
-        fail_tiles[atomicAdd(&counters[1], 1u)] = tile;
-        return;
+        const unsigned slot = atomicAdd(&counters[8], 1u);
+        if (slot >= lat_capacity) {
+            el->flags = PB_TILE_FAILED;
+            er->flags = PB_TILE_FAILED;
+            fail_tiles[atomicAdd(&counters[1], 1u)] = tile;
+            return;
+        }
+        el->aux_off = (int)slot;
+        wclass = PB_TILE_W_LAT;
     }
     int nl = fl0, nr = fr0;
     const int need_l = (nl & PB_TILE_LEAN) ? el->win_rows * 16 * el->win_n16 : 0;
@@ -387,8 +421,26 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_double_pair_kernel(cons
         if (need_l >= need_r) nl = (nl & ~PB_TILE_LEAN) | PB_TILE_DIRECT;
         else nr = (nr & ~PB_TILE_LEAN) | PB_TILE_DIRECT;
     }
-    nl |= all_unit ? PB_TILE_W_UNIT : PB_TILE_W_ROW;
-    if (!all_unit) atomicAdd(&counters[7], 1u);
+    nl |= wclass;
+    if (wclass == PB_TILE_W_ROW) atomicAdd(&counters[7], 1u);
     el->flags = nl;
     er->flags = nr;
+}
+
+// Fills the latitude table: the faithful (rotated) latitude of every pixel of every LAT tile, tile-major.
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_double_lat_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
+                                                                            double* __restrict__ lat_tab) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int tx, ty;
+    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
+    const PbTileEntry* el = table_l + ((size_t)ty * pb_tiles_x(P) + tx);
+    if ((el->flags & PB_TILE_FAILED) || !(el->flags & PB_TILE_W_LAT)) return;
+    double* __restrict__ lt = lat_tab + (size_t)el->aux_off * PB_LAT_TILE_DOUBLES;
+    const int y = lane & 31, xh = (lane >> 5) * 16;
+    for (int k = 0; k < 16; ++k) {
+        const int i = min(ty * PB_TILE + y, P.dst.height - 1), j = min(tx * PB_TILE + xh + k, P.dst.width - 1);
+        PbCoord c = pb_dst_coord(P, i, j);
+        for (int r = 0; r < P.n_rot; ++r) c = pb_rotate(P.R[r], c);
+        lt[y * PB_TILE + xh + k] = c.lat;
+    }
 }

@@ -47,7 +47,8 @@ struct __attribute__((aligned(256))) PbTileEntry {
     int32_t win_r0, win_c0, win_cols;
     int32_t win_n16, win_a0;     // LEAN: 16-byte chunks per row, byte offset of column win_c0 in its first chunk
     int32_t fix_off, fix_cnt;    // this tile's slice of the plan's fix-pixel list (<= PB_TILE_FAIL_LIMIT entries)
-    int32_t pad1[3];
+    int32_t aux_off;             // double sources, left-eye entry: the tile's slot in the plan's latitude table (PB_TILE_W_LAT)
+    int32_t pad1[2];
 };
 static_assert(sizeof(PbTileEntry) == 256, "PbTileEntry must be 256 bytes");
 

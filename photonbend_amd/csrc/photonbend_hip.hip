@@ -39,7 +39,8 @@ struct pb_plan {
     // double-fisheye source: one certified tile table per eye (pb_kernels_double.hpp); `table` is the left eye's
     int dbl_ready = 0;
     PbTileEntry* table_r = nullptr;
-    unsigned n_row_weight_tiles = 0;
+    double* lat_tab = nullptr;   // faithful latitudes of the pixels of merge-band tiles (PB_TILE_W_LAT), 8 KiB per tile
+    unsigned n_row_weight_tiles = 0, n_lat_tiles = 0;
 };
 
 static thread_local std::string g_err;
@@ -121,7 +122,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
     PbParams& P = pl->P;
     long long* scratch = nullptr;
     PB_HIP(hipGetDevice(&pl->device));
-    PB_HIP(hipMalloc((void**)&scratch, 12 * sizeof(long long)));
+    PB_HIP(hipMalloc((void**)&scratch, 16 * sizeof(long long)));
     int rc = PB_OK;
     do {
         if (P.dst.kind != PB_KIND_PANO) {
@@ -157,7 +158,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                 hipMalloc((void**)&pl->fail_tiles, (size_t)2 * ntiles * sizeof(int32_t)) != hipSuccess ||
                 hipMalloc((void**)&pl->fix_px, (size_t)cap * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
             unsigned* counters = reinterpret_cast<unsigned*>(scratch + 4);
-            if (hipMemset(counters, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            if (hipMemset(counters, 0, 12 * sizeof(unsigned)) != hipSuccess) { rc = PB_ERR_HIP; break; }
             const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table);
@@ -165,10 +166,17 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r);
             hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r, pl->fail_tiles, pl->fix_px, cap, counters);
+            const unsigned lat_capacity = ntiles < 65536u ? ntiles : 65536u;  // <= 512 MiB of latitudes
             hipLaunchKernelGGL(pb_double_pair_kernel, grid, block, 0, 0, P, pl->table, pl->table_r, pl->sep_ready ? pl->sep_rows : nullptr,
-                               pl->fail_tiles, counters);
-            unsigned res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                               pl->fail_tiles, counters, lat_capacity);
+            unsigned res[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            pl->n_lat_tiles = res[8] < lat_capacity ? res[8] : lat_capacity;
+            if (pl->n_lat_tiles) {
+                if (hipMalloc((void**)&pl->lat_tab, (size_t)pl->n_lat_tiles * PB_LAT_TILE_DOUBLES * sizeof(double)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+                hipLaunchKernelGGL(pb_double_lat_kernel, grid, block, 0, 0, P, pl->table, pl->lat_tab);
+                if (hipDeviceSynchronize() != hipSuccess) { rc = PB_ERR_HIP; break; }
+            }
             pl->n_lean_tiles = res[4];
             pl->n_black_tiles = res[5];
             pl->n_direct_tiles = res[6];
@@ -212,8 +220,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
     if (rc != PB_OK) {
         g_err = std::string("plan preparation on device failed: ") + hipGetErrorString(hipGetLastError());
         (void)hipFree(pl->table); (void)hipFree(pl->fail_tiles); (void)hipFree(pl->fix_px);
-        (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols); (void)hipFree(pl->table_r);
-        pl->table_r = nullptr; pl->sep_ready = 0; pl->dbl_ready = 0;
+        (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols); (void)hipFree(pl->table_r); (void)hipFree(pl->lat_tab);
+        pl->table_r = nullptr; pl->lat_tab = nullptr; pl->sep_ready = 0; pl->dbl_ready = 0;
         pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr; pl->sep_rows = nullptr; pl->sep_cols = nullptr;
     }
     (void)hipFree(scratch);
@@ -345,6 +353,7 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->sep_rows);
     (void)hipFree(plan->sep_cols);
     (void)hipFree(plan->table_r);
+    (void)hipFree(plan->lat_tab);
     delete plan;
 }
 
@@ -380,16 +389,21 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
     const bool windowable = ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;  // LDS-DMA row segments
     if (plan->dbl_ready && plan->mode != PB_MODE_FAITHFUL && plan->mode != PB_MODE_FAST_DIRECT && windowable) {
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
-        // the hot waves take a short fix list along (single frame, no failed tiles); otherwise a second launch
+        // the hot waves take a short fix list along (single frame, no failed tiles); otherwise ONE second launch
+        // recomputes failed tiles and fix pixels together (a dependent launch costs ~6 us on this stack, and a fork /
+        // join onto a second stream costs more than the overlap returns: measured, experiments/README.md)
         const bool fused = n_frames == 1 && plan->n_fail_tiles == 0 && plan->n_fix_px <= 2048;
         const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
-#define PB_LAUNCH_DOUBLE(ROWS, FUSED)                                                                                              \
-    hipLaunchKernelGGL((pb_hot_double_kernel<ROWS, FUSED>), grid, block, 0, st, P, plan->table, plan->table_r, rows, plan->fix_px, \
-                       src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride)
-        if (rows && fused) PB_LAUNCH_DOUBLE(true, true);
-        else if (rows) PB_LAUNCH_DOUBLE(true, false);
-        else if (fused) PB_LAUNCH_DOUBLE(false, true);
-        else PB_LAUNCH_DOUBLE(false, false);
+#define PB_LAUNCH_DOUBLE(WMODE, FUSED)                                                                                            \
+    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, FUSED>), grid, block, 0, st, P, plan->table, plan->table_r, rows, plan->lat_tab, \
+                       plan->fix_px, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride)
+        const int wmode = rows ? 1 : (plan->n_lat_tiles ? 2 : 0);
+        if (wmode == 1 && fused) PB_LAUNCH_DOUBLE(1, true);
+        else if (wmode == 1) PB_LAUNCH_DOUBLE(1, false);
+        else if (wmode == 2 && fused) PB_LAUNCH_DOUBLE(2, true);
+        else if (wmode == 2) PB_LAUNCH_DOUBLE(2, false);
+        else if (fused) PB_LAUNCH_DOUBLE(0, true);
+        else PB_LAUNCH_DOUBLE(0, false);
 #undef PB_LAUNCH_DOUBLE
         const unsigned fix_blocks = 4u * plan->n_fail_tiles + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
         if (!fused && fix_blocks)
