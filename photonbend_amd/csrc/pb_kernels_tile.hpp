@@ -1,6 +1,6 @@
 // pb_kernels_tile.hpp - the fast path for pano / camera sources.
 //
-//   per frame (pb_remap_u8):   pb_hot_kernel  -> pb_fix_kernel          (same stream)
+//   per frame (pb_remap_u8):   pb_hot_win_kernel alone (16-byte aligned frames), else pb_hot_kernel -> pb_fix_kernel
 //   per plan  (pb_plan_create): pb_threshold_kernel -> pb_model_kernel -> pb_window_kernel -> pb_certify_kernel
 //
 // pb_hot_kernel: one WAVE per 32x32 output tile, 4 tiles (a 64x64 block) per workgroup,
@@ -400,42 +400,74 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
     }
 }
 
+// Exact-index tables (built once per plan by pb_fix_tables_kernel from the faithful chain): what the tile models
+// cannot reproduce is not recomputed per frame but LOOKED UP -
+//   idx_tab  the int32 source index (-1 = black) of every pixel of every failed tile, 4 KiB per tile, slot
+//            PbTileEntry::aux_off;
+//   fix_idx  the source index of every pixel of the fix list (parallel to fix_px).
+// With them the hot launch is the only launch of a frame: a failed tile is gathered by its own wave through its
+// index slot, a tile's fix pixels are re-copied by its wave after its stores; no float64 in the kernel.
 template <int SRC_KIND>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
                                                                          const uint8_t* __restrict__ src,
                                                                          uint8_t* __restrict__ dst, int n_frames,
                                                                          unsigned long long src_stride,
-                                                                         unsigned long long dst_stride, unsigned fail_blocks,
-                                                                         const int32_t* __restrict__ fail_tiles,
-                                                                         const int32_t* __restrict__ fix_px) {
+                                                                         unsigned long long dst_stride,
+                                                                         const int32_t* __restrict__ idx_tab,
+                                                                         const int32_t* __restrict__ fix_px,
+                                                                         const int32_t* __restrict__ fix_idx) {
     __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 4];
-    if (blockIdx.x < fail_blocks) {
-        // leading blocks: the plan's failed tiles, 256 pixels per block, faithful chain (slow, so they are
-        // dispatched first).  They write pixels no hot wave touches and run next to the hot blocks.
-        const unsigned b = blockIdx.x;
-        const int t = fail_tiles[b >> 2];
-        const int fty = t / pb_tiles_x(P), ftx = t - fty * pb_tiles_x(P);
-        const int local = (int)(b & 3u) * 256 + (int)threadIdx.x;
-        const int i = fty * PB_TILE + (local >> 5), j = ftx * PB_TILE + (local & 31);
-        if (i >= P.dst.height || j >= P.dst.width) return;
-        const int id = pb_exact_index<SRC_KIND>(P, i, j);
-        const size_t p = (size_t)i * P.dst.width + j;
-        for (int f = 0; f < n_frames; ++f) {
-            const unsigned v = pb_load_px(src + (unsigned long long)f * src_stride, id);
-            uint8_t* o = dst + (unsigned long long)f * dst_stride + 3 * p;
-            o[0] = (uint8_t)(v & 0xFF);
-            o[1] = (uint8_t)((v >> 8) & 0xFF);
-            o[2] = (uint8_t)((v >> 16) & 0xFF);
-        }
-        return;
-    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tx, ty;
-    if (!pb_tile_of_wave(P, wave, tx, ty, blockIdx.x - fail_blocks)) return;
+    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
     const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
     const int flags = e->flags;
-    if (flags & PB_TILE_FAILED) return;
+    if (flags & PB_TILE_FAILED) {
+        // failed tile: gather through the plan's exact indices (lane = 4 consecutive pixels x 4 rows)
+        const int xg = lane & 7, yb = lane >> 3;
+        const int W = P.dst.width, H = P.dst.height;
+        const int x = tx * PB_TILE + 4 * xg;
+        const int32_t* __restrict__ slot = idx_tab + (size_t)e->aux_off * (PB_TILE * PB_TILE);
+        int id[4][4];
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const int4 v = *reinterpret_cast<const int4*>(slot + (yb + 8 * jr) * PB_TILE + 4 * xg);
+            id[jr][0] = v.x; id[jr][1] = v.y; id[jr][2] = v.z; id[jr][3] = v.w;
+        }
+        const unsigned last_px = (unsigned)P.src.height * (unsigned)P.src.width - 1u;
+        for (int f = 0; f < n_frames; ++f) {
+            const uint8_t* s = src + (unsigned long long)f * src_stride;
+            uint8_t* d = dst + (unsigned long long)f * dst_stride;
+            unsigned a[4][4];
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int v = id[jr][k];
+                    // a 4-byte read of the frame's very last pixel would touch one byte past the buffer
+                    a[jr][k] = ((unsigned)v == last_px) ? pb_load_px(s, v) : pb_load_px32(s, v);
+                }
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                const int y = ty * PB_TILE + yb + 8 * jr;
+                if (y >= H) continue;
+                const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+                if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
+                    __builtin_nontemporal_store(pb_pack_px4(a[jr][0], a[jr][1], a[jr][2], a[jr][3]), reinterpret_cast<pb_u32x3*>(d + off));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (x + k < W) {
+                            d[off + 3 * k + 0] = (uint8_t)(a[jr][k] & 0xFF);
+                            d[off + 3 * k + 1] = (uint8_t)((a[jr][k] >> 8) & 0xFF);
+                            d[off + 3 * k + 2] = (uint8_t)((a[jr][k] >> 16) & 0xFF);
+                        }
+                }
+            }
+        }
+        return;
+    }
 #ifdef PB_STAMPS
     unsigned long long tw0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tw0) :: "memory");
@@ -450,15 +482,14 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
         if (lane == 0) pb_stamp_acc[(size_t)(ty * pb_tiles_x(P) + tx) * 8 + cls] += tw1 - tw0;
     }
 #endif
-    // this tile's fix pixels (where the model's truncation differs from the faithful one): one faithful
-    // evaluation per listed pixel, stored after the wave's own stores have completed
-    const int n_fix = fix_px ? e->fix_cnt : 0;  // null list: the fix kernel takes the pixels
+    // this tile's fix pixels (where the model's truncation differs from the faithful one): re-copied through
+    // their exact indices after the wave's own stores have completed
+    const int n_fix = e->fix_cnt;
     if (n_fix > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane < n_fix) {
             const unsigned p = (unsigned)fix_px[e->fix_off + lane];
-            const int i = (int)(p / (unsigned)P.dst.width), j = (int)(p - (unsigned)i * (unsigned)P.dst.width);
-            const int id = pb_exact_index<SRC_KIND>(P, i, j);
+            const int id = fix_idx[e->fix_off + lane];
             for (int f = 0; f < n_frames; ++f) {
                 const unsigned v = pb_load_px(src + (unsigned long long)f * src_stride, id);
                 uint8_t* o = dst + (unsigned long long)f * dst_stride + 3ull * p;
@@ -468,6 +499,30 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
             }
         }
     }
+}
+
+// Plan creation: the exact-index tables of the hot kernel above.  Blocks [0, 4 * n_fail_tiles) take the failed
+// tiles (256 px each; the tile's slot = its position in fail_tiles, recorded in its entry), the remaining blocks
+// the fix list.
+template <int SRC_KIND>
+__global__ __launch_bounds__(PB_BLOCK) void pb_fix_tables_kernel(const PbParams P, PbTileEntry* __restrict__ table,
+                                                                 const int32_t* __restrict__ fail_tiles, int n_fail_tiles,
+                                                                 const int32_t* __restrict__ fix_px, int n_fix_px,
+                                                                 int32_t* __restrict__ idx_tab, int32_t* __restrict__ fix_idx) {
+    if ((int)blockIdx.x < 4 * n_fail_tiles) {
+        const int s = blockIdx.x >> 2, t = fail_tiles[s];
+        const int ty = t / pb_tiles_x(P), tx = t - ty * pb_tiles_x(P);
+        const int local = (blockIdx.x & 3) * 256 + threadIdx.x;
+        const int i = ty * PB_TILE + (local >> 5), j = tx * PB_TILE + (local & 31);
+        idx_tab[(size_t)s * (PB_TILE * PB_TILE) + local] = (i < P.dst.height && j < P.dst.width) ? pb_exact_index<SRC_KIND>(P, i, j) : -1;
+        if (local == 0) table[t].aux_off = s;
+        return;
+    }
+    const unsigned item = (blockIdx.x - 4u * n_fail_tiles) * PB_BLOCK + threadIdx.x;
+    if (item >= (unsigned)n_fix_px) return;
+    const unsigned p = (unsigned)fix_px[item];
+    const int i = (int)(p / (unsigned)P.dst.width), j = (int)(p - (unsigned)i * (unsigned)P.dst.width);
+    fix_idx[item] = pb_exact_index<SRC_KIND>(P, i, j);
 }
 
 // The plan's fix list: blocks [0, 4 * n_fail_tiles) take the failed tiles (256 px each), the

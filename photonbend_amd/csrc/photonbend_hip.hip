@@ -30,6 +30,8 @@ struct pb_plan {
     PbTileEntry* table = nullptr;
     int32_t* fail_tiles = nullptr;
     int32_t* fix_px = nullptr;
+    int32_t* idx_tab = nullptr;  // exact source indices of the pixels of failed tiles (4 KiB per tile) ...
+    int32_t* fix_idx = nullptr;  // ... and of the fix list's pixels: looked up per frame instead of recomputed
     unsigned n_tiles = 0, n_fail_tiles = 0, n_fix_px = 0, n_lean_tiles = 0, n_black_tiles = 0, n_direct_tiles = 0;
     long long diff_pixels = -1;  // pixels (outside failed tiles) where model and faithful index differed
     // separable path (double source, unrotated pano destination): row / column tables
@@ -215,11 +217,27 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         pl->n_fail_tiles = res[1];
         pl->diff_pixels = res[2];
         pl->n_tiles = ntiles;
+        {   // exact-index tables for the windowed hot kernel
+            const unsigned nf = pl->n_fail_tiles, np = pl->n_fix_px;
+            if (hipMalloc((void**)&pl->idx_tab, (size_t)(nf ? nf : 1) * PB_TILE * PB_TILE * sizeof(int32_t)) != hipSuccess ||
+                hipMalloc((void**)&pl->fix_idx, (size_t)(np ? np : 1) * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            const unsigned blocks = 4u * nf + (np + PB_BLOCK - 1) / PB_BLOCK;
+            if (blocks) {
+                if (P.src.kind == PB_KIND_PANO)
+                    hipLaunchKernelGGL(pb_fix_tables_kernel<PB_KIND_PANO>, dim3(blocks), dim3(PB_BLOCK), 0, 0, P, pl->table, pl->fail_tiles, (int)nf,
+                                       pl->fix_px, (int)np, pl->idx_tab, pl->fix_idx);
+                else
+                    hipLaunchKernelGGL(pb_fix_tables_kernel<PB_KIND_CAMERA>, dim3(blocks), dim3(PB_BLOCK), 0, 0, P, pl->table, pl->fail_tiles, (int)nf,
+                                       pl->fix_px, (int)np, pl->idx_tab, pl->fix_idx);
+                if (hipDeviceSynchronize() != hipSuccess) { rc = PB_ERR_HIP; break; }
+            }
+        }
         pl->fast_ready = 1;
     } while (0);
     if (rc != PB_OK) {
         g_err = std::string("plan preparation on device failed: ") + hipGetErrorString(hipGetLastError());
-        (void)hipFree(pl->table); (void)hipFree(pl->fail_tiles); (void)hipFree(pl->fix_px);
+        (void)hipFree(pl->table); (void)hipFree(pl->fail_tiles); (void)hipFree(pl->fix_px); (void)hipFree(pl->idx_tab); (void)hipFree(pl->fix_idx);
+        pl->idx_tab = nullptr; pl->fix_idx = nullptr;
         (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols); (void)hipFree(pl->table_r); (void)hipFree(pl->lat_tab);
         pl->table_r = nullptr; pl->lat_tab = nullptr; pl->sep_ready = 0; pl->dbl_ready = 0;
         pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr; pl->sep_rows = nullptr; pl->sep_cols = nullptr;
@@ -242,27 +260,14 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
     const bool windowed = OUT == 0 && pl->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
                           ((((uintptr_t)src) | ss) & 15u) == 0;
     if (windowed) {
-        // hot blocks apply their own tiles' fix pixels; a handful of failed tiles ride along as leading
-        // blocks of the same launch, many failed tiles get their own (high-occupancy) launch afterwards
-        // (a faithful evaluation costs microseconds of latency: worth hiding inside the hot launch only
-        // when few waves have to do it)
-        const bool fused = pl->n_fail_tiles <= 64 && pl->n_fix_px <= 2048;
-        const unsigned lead = fused ? 4u * pl->n_fail_tiles : 0u;
-        const unsigned fix_blocks_w = 4u * pl->n_fail_tiles + (pl->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
-        const dim3 wgrid(grid.x + lead);
-        if (P.src.kind == PB_KIND_PANO) {
-            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_PANO>, wgrid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds,
-                               lead, pl->fail_tiles, fused ? pl->fix_px : nullptr);
-            if (!fused && fix_blocks_w)
-                hipLaunchKernelGGL((pb_fix_kernel<PB_KIND_PANO, 0>), dim3(fix_blocks_w), dim3(PB_BLOCK), 0, st, P, pl->fail_tiles,
-                                   (int)pl->n_fail_tiles, pl->fix_px, (int)pl->n_fix_px, src, dst, n_frames, ss, ds, idx_out);
-        } else {
-            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_CAMERA>, wgrid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds,
-                               lead, pl->fail_tiles, fused ? pl->fix_px : nullptr);
-            if (!fused && fix_blocks_w)
-                hipLaunchKernelGGL((pb_fix_kernel<PB_KIND_CAMERA, 0>), dim3(fix_blocks_w), dim3(PB_BLOCK), 0, st, P, pl->fail_tiles,
-                                   (int)pl->n_fail_tiles, pl->fix_px, (int)pl->n_fix_px, src, dst, n_frames, ss, ds, idx_out);
-        }
+        // one launch per frame: failed tiles and fix pixels are looked up in the plan's exact-index tables by the
+        // hot waves themselves (pb_kernels_tile.hpp)
+        if (P.src.kind == PB_KIND_PANO)
+            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_PANO>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, pl->idx_tab,
+                               pl->fix_px, pl->fix_idx);
+        else
+            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_CAMERA>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, pl->idx_tab,
+                               pl->fix_px, pl->fix_idx);
         return;
     }
     const bool staged = windowed;
@@ -350,6 +355,8 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->table);
     (void)hipFree(plan->fail_tiles);
     (void)hipFree(plan->fix_px);
+    (void)hipFree(plan->idx_tab);
+    (void)hipFree(plan->fix_idx);
     (void)hipFree(plan->sep_rows);
     (void)hipFree(plan->sep_cols);
     (void)hipFree(plan->table_r);
