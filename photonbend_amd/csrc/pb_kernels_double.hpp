@@ -18,8 +18,10 @@
 //   (a tile beyond the latitude table's capacity is listed as failed and recomputed by the faithful chain).
 // pb_hot_double_kernel: one wave per 32x32 tile; both eyes' windows are pulled into the wave's LDS by
 // LDS-DMA while the two models are evaluated, pixels are gathered from LDS (or straight from the frame for
-// sparse windows), blended and stored.  pb_fix_double_kernel: faithful chain for failed tiles + fix pixels.
-// The union is bit-identical to the faithful kernel for every pixel, by construction.
+// sparse windows), blended and stored.  What the models miss is looked up, not recomputed: the plan stores the
+// faithful taps and factors of every fix-list pixel and of every pixel of a failed tile (PbDoubleFix,
+// pb_double_tables_kernel), and the hot waves copy through them.  One launch per frame; the union is
+// bit-identical to the faithful kernel for every pixel, by construction.
 #pragma once
 #include "pb_kernels_sep.hpp"
 #include "pb_kernels_tile.hpp"
@@ -167,23 +169,34 @@ __device__ __forceinline__ void pb_d_gather(const PbDesc& D, const PbTileCtx& C,
     }
 }
 
-// forward: the faithful double-source pixel (below)
-__device__ __forceinline__ void pb_double_exact_px(const PbParams& P, int i, int j, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                   int n_frames, unsigned long long src_stride, unsigned long long dst_stride);
+// the faithful taps and blend factors of one output pixel, stored once per plan
+struct PbDoubleFix {
+    int32_t il, ir;  // indices into the side-by-side frame, or -1 (an invalid destination pixel has both -1: black)
+    double fl, fr;
+};
+
+__device__ __forceinline__ unsigned pb_double_fix_px(const PbDoubleFix& t, const uint8_t* __restrict__ s) {
+    const unsigned l = pb_load_px(s, t.il), r = pb_load_px(s, t.ir);
+    return pb_blend_u8(l & 0xFF, r & 0xFF, t.fl, t.fr) | (pb_blend_u8((l >> 8) & 0xFF, (r >> 8) & 0xFF, t.fl, t.fr) << 8) |
+           (pb_blend_u8((l >> 16) & 0xFF, (r >> 16) & 0xFF, t.fl, t.fr) << 16);
+}
 
 // WMODE 0: every tile is UNIT; 1: a row table exists (unrotated panorama destination); 2: a latitude table exists.
-// FUSED (single frame, no failed tiles, short fix list): the wave also recomputes its tile's fix pixels, after
-// its own stores - no second launch.
-template <int WMODE, bool FUSED>
+// tile_fix: faithful taps of failed tiles (1024 per tile, slot = right-eye entry's aux_off); px_fix: of the fix list.
+// ONE: single-frame launch (the frame loop and everything that keeps its invariants alive disappear).
+template <int WMODE, bool ONE>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
                                                                             const PbTileEntry* __restrict__ table_r,
                                                                             const PbSepRow* __restrict__ rows,
                                                                             const double* __restrict__ lat_tab,
                                                                             const int32_t* __restrict__ fix_px,
+                                                                            const PbDoubleFix* __restrict__ px_fix,
+                                                                            const PbDoubleFix* __restrict__ tile_fix,
                                                                             const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                             int n_frames, unsigned long long src_stride,
                                                                             unsigned long long dst_stride) {
     __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 8];
+    const int frames = ONE ? 1 : n_frames;
     PbTileCtx C;
     C.lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -193,7 +206,35 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     const PbTileEntry* __restrict__ el = table_l + tile;
     const PbTileEntry* __restrict__ er = table_r + tile;
     const PbDesc DL = pb_load_desc(el), DR = pb_load_desc(er);
-    if ((DL.flags | DR.flags) & PB_TILE_FAILED) return;  // the fix kernel owns this tile
+    if ((DL.flags | DR.flags) & PB_TILE_FAILED) {
+        // failed tile: every pixel through its stored faithful taps and factors (lane = 4 consecutive pixels x 4 rows)
+        const PbDoubleFix* __restrict__ slot = tile_fix + (size_t)er->aux_off * (PB_TILE * PB_TILE);
+        const int xg = C.lane & 7, yb = C.lane >> 3, W = P.dst.width, H = P.dst.height;
+        for (int f = 0; f < frames; ++f) {
+            const uint8_t* s = src + (unsigned long long)f * src_stride;
+            uint8_t* d = dst + (unsigned long long)f * dst_stride;
+            for (int jr = 0; jr < 4; ++jr) {
+                const int y = ty * PB_TILE + yb + 8 * jr, x = tx * PB_TILE + 4 * xg;
+                if (y >= H) continue;
+                unsigned a[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = pb_double_fix_px(slot[(yb + 8 * jr) * PB_TILE + 4 * xg + k], s);
+                const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+                if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
+                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (x + k < W) {
+                            d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+                            d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+                            d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+                        }
+                }
+            }
+        }
+        return;
+    }
     const bool by_row = WMODE == 1 && (DL.flags & PB_TILE_W_ROW) != 0;
     const bool by_lat = WMODE == 2 && (DL.flags & PB_TILE_W_LAT) != 0;
     C.rowbytes = 3u * (unsigned)P.src.width;
@@ -243,14 +284,13 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     }
     const int x = C.X0 + 4 * C.xg;
     const bool inside = C.X0 + PB_TILE <= C.W && C.Y0 + PB_TILE <= C.H;
-    const int frames = FUSED ? 1 : n_frames;
     for (int f = 0; f < frames; ++f) {
         const uint8_t* s = src + (unsigned long long)f * src_stride;
         uint8_t* d = dst + (unsigned long long)f * dst_stride;
         // the addresses are loop-invariant; keep the compiler from hoisting everything derived from them out of
         // the frame loop (hundreds of live registers for nothing)
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
+        for (int n = 0; n < 16 && !ONE; ++n) {
             asm volatile("" : "+v"(ql[n]));
             asm volatile("" : "+v"(qr[n]));
             if (WMODE == 2) asm volatile("" : "+v"(lat[WMODE == 2 ? n : 0]));
@@ -298,66 +338,62 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
             pb_wave_sync();
         }
     }
-    if (FUSED) {
-        const int nl = el->fix_cnt, nr = er->fix_cnt;  // <= PB_TILE_FAIL_LIMIT each (a pixel listed by both eyes is written twice)
-        if (nl + nr > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own stores to these pixels have completed
-            for (int base = 0; base < nl + nr; base += 64) {
-                const int n = base + C.lane;
-                if (n < nl + nr) {
-                    const unsigned p = (unsigned)fix_px[n < nl ? el->fix_off + n : er->fix_off + (n - nl)];
-                    const int i = (int)(p / (unsigned)C.W), j = (int)(p - (unsigned)i * (unsigned)C.W);
-                    pb_double_exact_px(P, i, j, src, dst, 1, src_stride, dst_stride);
+    // the tile's fix pixels (either eye's list; a pixel listed by both is written twice): through their stored taps,
+    // after the wave's own stores have completed
+    const int nl = el->fix_cnt, nr = er->fix_cnt;  // <= PB_TILE_FAIL_LIMIT each
+    if (nl + nr > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int base = 0; base < nl + nr; base += 64) {
+            const int n = base + C.lane;
+            if (n < nl + nr) {
+                const int item = n < nl ? el->fix_off + n : er->fix_off + (n - nl);
+                const unsigned p = (unsigned)fix_px[item];
+                const PbDoubleFix t = px_fix[item];
+                for (int f = 0; f < frames; ++f) {
+                    const unsigned v = pb_double_fix_px(t, src + (unsigned long long)f * src_stride);
+                    uint8_t* o = dst + (unsigned long long)f * dst_stride + 3ull * p;
+                    o[0] = (uint8_t)(v & 0xFF);
+                    o[1] = (uint8_t)((v >> 8) & 0xFF);
+                    o[2] = (uint8_t)((v >> 16) & 0xFF);
                 }
             }
         }
     }
 }
 
-// The faithful double-source pixel (the per-pixel body of pb_remap_kernel<PB_KIND_DOUBLE>).
-__device__ __forceinline__ void pb_double_exact_px(const PbParams& P, int i, int j, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                   int n_frames, unsigned long long src_stride, unsigned long long dst_stride) {
-    PbCoord c = pb_dst_coord(P, i, j);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
-    const PbDoubleTap t = pb_src_double_taps(P, c);
-    const size_t p = (size_t)i * P.dst.width + j;
-    for (int f = 0; f < n_frames; ++f) {
-        const uint8_t* s = src + (unsigned long long)f * src_stride;
-        const unsigned l = pb_load_px(s, t.il), r = pb_load_px(s, t.ir);
-        unsigned v = 0;
-        if (!c.inv)  // final_image[invalid_map] = 0, projection.py:460
-            v = pb_blend_u8(l & 0xFF, r & 0xFF, t.fl, t.fr) | (pb_blend_u8((l >> 8) & 0xFF, (r >> 8) & 0xFF, t.fl, t.fr) << 8) |
-                (pb_blend_u8((l >> 16) & 0xFF, (r >> 16) & 0xFF, t.fl, t.fr) << 16);
-        uint8_t* o = dst + (unsigned long long)f * dst_stride + 3 * p;
-        o[0] = (uint8_t)(v & 0xFF);
-        o[1] = (uint8_t)((v >> 8) & 0xFF);
-        o[2] = (uint8_t)((v >> 16) & 0xFF);
-    }
-}
-
-// The plan's fix list for a double source: blocks [0, 4 * n_fail_tiles) take failed tiles (256 px each), the
-// remaining blocks single pixels (a tile or pixel may be listed by both eyes: it is then written twice with
-// the same bytes).
-__global__ __launch_bounds__(PB_BLOCK) void pb_fix_double_kernel(const PbParams P, const int32_t* __restrict__ fail_tiles, int n_fail_tiles,
-                                                                 const int32_t* __restrict__ fix_px, int n_fix_px,
-                                                                 const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n_frames,
-                                                                 unsigned long long src_stride, unsigned long long dst_stride) {
+// Plan creation: the faithful taps and factors of the failed tiles' pixels (blocks [0, 4 * n_fail_tiles), 256 px
+// each; slot = position in fail_tiles, recorded in the right-eye entry) and of the fix list (remaining blocks).
+__global__ __launch_bounds__(PB_BLOCK) void pb_double_tables_kernel(const PbParams P, PbTileEntry* __restrict__ table_r,
+                                                                    const int32_t* __restrict__ fail_tiles, int n_fail_tiles,
+                                                                    const int32_t* __restrict__ fix_px, int n_fix_px,
+                                                                    PbDoubleFix* __restrict__ tile_fix, PbDoubleFix* __restrict__ px_fix) {
     int i, j;
+    PbDoubleFix* out;
     if ((int)blockIdx.x < 4 * n_fail_tiles) {
-        const int t = fail_tiles[blockIdx.x >> 2];
+        const int s = blockIdx.x >> 2, t = fail_tiles[s];
         const int ty = t / pb_tiles_x(P), tx = t - ty * pb_tiles_x(P);
         const int local = (blockIdx.x & 3) * 256 + threadIdx.x;
-        i = ty * PB_TILE + (local >> 5);
-        j = tx * PB_TILE + (local & 31);
-        if (i >= P.dst.height || j >= P.dst.width) return;
+        i = min(ty * PB_TILE + (local >> 5), P.dst.height - 1);  // pixels beyond the image are never stored
+        j = min(tx * PB_TILE + (local & 31), P.dst.width - 1);
+        out = tile_fix + (size_t)s * (PB_TILE * PB_TILE) + local;
+        if (local == 0) table_r[t].aux_off = s;
     } else {
         const unsigned item = (blockIdx.x - 4u * n_fail_tiles) * PB_BLOCK + threadIdx.x;
         if (item >= (unsigned)n_fix_px) return;
         const unsigned p = (unsigned)fix_px[item];
-        i = p / (unsigned)P.dst.width;
-        j = p - (unsigned)i * (unsigned)P.dst.width;
+        i = (int)(p / (unsigned)P.dst.width);
+        j = (int)(p - (unsigned)i * (unsigned)P.dst.width);
+        out = px_fix + item;
     }
-    pb_double_exact_px(P, i, j, src, dst, n_frames, src_stride, dst_stride);
+    PbCoord c = pb_dst_coord(P, i, j);
+    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    const PbDoubleTap t = pb_src_double_taps(P, c);
+    PbDoubleFix r;
+    r.il = t.il;  // both -1 for an invalid destination pixel: black (final_image[invalid_map] = 0, projection.py:460)
+    r.ir = t.ir;
+    r.fl = t.fl;
+    r.fr = t.fr;
+    *out = r;
 }
 
 // Plan creation, after both eyes' tables are built and certified.  One wave per tile:

@@ -407,16 +407,18 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
 //   fix_idx  the source index of every pixel of the fix list (parallel to fix_px).
 // With them the hot launch is the only launch of a frame: a failed tile is gathered by its own wave through its
 // index slot, a tile's fix pixels are re-copied by its wave after its stores; no float64 in the kernel.
-template <int SRC_KIND>
+// ONE: single-frame launch - the frame loops (and the registers that keep their invariants alive) disappear.
+template <int SRC_KIND, bool ONE>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
                                                                          const uint8_t* __restrict__ src,
-                                                                         uint8_t* __restrict__ dst, int n_frames,
+                                                                         uint8_t* __restrict__ dst, int n_frames_arg,
                                                                          unsigned long long src_stride,
                                                                          unsigned long long dst_stride,
                                                                          const int32_t* __restrict__ idx_tab,
                                                                          const int32_t* __restrict__ fix_px,
                                                                          const int32_t* __restrict__ fix_idx) {
     __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 4];
+    const int n_frames = ONE ? 1 : n_frames_arg;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tx, ty;
@@ -439,14 +441,20 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
         for (int f = 0; f < n_frames; ++f) {
             const uint8_t* s = src + (unsigned long long)f * src_stride;
             uint8_t* d = dst + (unsigned long long)f * dst_stride;
+            // branch-free, so that the 16 gathers of a lane are in flight together: a black pixel (-1) reads pixel 0
+            // and is masked; the frame's very last pixel is read one byte early (a 4-byte read at its own address
+            // would touch one byte past the buffer) and shifted
             unsigned a[4][4];
 #pragma unroll
             for (int jr = 0; jr < 4; ++jr)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int v = id[jr][k];
-                    // a 4-byte read of the frame's very last pixel would touch one byte past the buffer
-                    a[jr][k] = ((unsigned)v == last_px) ? pb_load_px(s, v) : pb_load_px32(s, v);
+                    const bool last = (unsigned)v == last_px;
+                    const unsigned off = v < 0 ? 0u : 3u * (unsigned)v - (last ? 1u : 0u);
+                    unsigned t;
+                    __builtin_memcpy(&t, s + off, 4);
+                    a[jr][k] = v < 0 ? 0u : (last ? t >> 8 : t);
                 }
 #pragma unroll
             for (int jr = 0; jr < 4; ++jr) {

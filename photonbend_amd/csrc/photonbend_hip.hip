@@ -41,6 +41,8 @@ struct pb_plan {
     // double-fisheye source: one certified tile table per eye (pb_kernels_double.hpp); `table` is the left eye's
     int dbl_ready = 0;
     PbTileEntry* table_r = nullptr;
+    PbDoubleFix* dbl_tile_fix = nullptr;  // faithful taps + factors of failed tiles' pixels / of the fix list's pixels
+    PbDoubleFix* dbl_px_fix = nullptr;
     double* lat_tab = nullptr;   // faithful latitudes of the pixels of merge-band tiles (PB_TILE_W_LAT), 8 KiB per tile
     unsigned n_row_weight_tiles = 0, n_lat_tiles = 0;
 };
@@ -179,6 +181,19 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                 hipLaunchKernelGGL(pb_double_lat_kernel, grid, block, 0, 0, P, pl->table, pl->lat_tab);
                 if (hipDeviceSynchronize() != hipSuccess) { rc = PB_ERR_HIP; break; }
             }
+            {   // faithful taps of failed tiles and fix pixels, looked up per frame
+                const unsigned nf = res[1], np = res[0] > cap ? cap : res[0];
+                // a geometry the models mostly cannot follow is not worth gigabytes of stored taps: faithful kernel
+                if ((size_t)nf * PB_TILE * PB_TILE * sizeof(PbDoubleFix) > ((size_t)1 << 30)) break;
+                if (hipMalloc((void**)&pl->dbl_tile_fix, (size_t)(nf ? nf : 1) * PB_TILE * PB_TILE * sizeof(PbDoubleFix)) != hipSuccess ||
+                    hipMalloc((void**)&pl->dbl_px_fix, (size_t)(np ? np : 1) * sizeof(PbDoubleFix)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+                const unsigned blocks = 4u * nf + (np + PB_BLOCK - 1) / PB_BLOCK;
+                if (blocks) {
+                    hipLaunchKernelGGL(pb_double_tables_kernel, dim3(blocks), dim3(PB_BLOCK), 0, 0, P, pl->table_r, pl->fail_tiles, (int)nf, pl->fix_px,
+                                       (int)np, pl->dbl_tile_fix, pl->dbl_px_fix);
+                    if (hipDeviceSynchronize() != hipSuccess) { rc = PB_ERR_HIP; break; }
+                }
+            }
             pl->n_lean_tiles = res[4];
             pl->n_black_tiles = res[5];
             pl->n_direct_tiles = res[6];
@@ -239,6 +254,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         (void)hipFree(pl->table); (void)hipFree(pl->fail_tiles); (void)hipFree(pl->fix_px); (void)hipFree(pl->idx_tab); (void)hipFree(pl->fix_idx);
         pl->idx_tab = nullptr; pl->fix_idx = nullptr;
         (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols); (void)hipFree(pl->table_r); (void)hipFree(pl->lat_tab);
+        (void)hipFree(pl->dbl_tile_fix); (void)hipFree(pl->dbl_px_fix);
+        pl->dbl_tile_fix = nullptr; pl->dbl_px_fix = nullptr;
         pl->table_r = nullptr; pl->lat_tab = nullptr; pl->sep_ready = 0; pl->dbl_ready = 0;
         pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr; pl->sep_rows = nullptr; pl->sep_cols = nullptr;
     }
@@ -262,12 +279,18 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
     if (windowed) {
         // one launch per frame: failed tiles and fix pixels are looked up in the plan's exact-index tables by the
         // hot waves themselves (pb_kernels_tile.hpp)
-        if (P.src.kind == PB_KIND_PANO)
-            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_PANO>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, pl->idx_tab,
-                               pl->fix_px, pl->fix_idx);
-        else
-            hipLaunchKernelGGL(pb_hot_win_kernel<PB_KIND_CAMERA>, grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, pl->idx_tab,
-                               pl->fix_px, pl->fix_idx);
+#define PB_LAUNCH_WIN(KIND, ONE)                                                                                               \
+    hipLaunchKernelGGL((pb_hot_win_kernel<KIND, ONE>), grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, pl->idx_tab, \
+                       pl->fix_px, pl->fix_idx)
+        if (P.src.kind == PB_KIND_PANO) {
+            // (measured on c2, same box: the loop build is ~2 % faster than the single-frame build for panorama
+            // sources, the single-frame build 2-3 % faster for fisheye sources)
+            PB_LAUNCH_WIN(PB_KIND_PANO, false);
+        } else {
+            if (n_frames == 1) PB_LAUNCH_WIN(PB_KIND_CAMERA, true);
+            else PB_LAUNCH_WIN(PB_KIND_CAMERA, false);
+        }
+#undef PB_LAUNCH_WIN
         return;
     }
     const bool staged = windowed;
@@ -361,6 +384,8 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->sep_cols);
     (void)hipFree(plan->table_r);
     (void)hipFree(plan->lat_tab);
+    (void)hipFree(plan->dbl_tile_fix);
+    (void)hipFree(plan->dbl_px_fix);
     delete plan;
 }
 
@@ -396,26 +421,20 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
     const bool windowable = ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;  // LDS-DMA row segments
     if (plan->dbl_ready && plan->mode != PB_MODE_FAITHFUL && plan->mode != PB_MODE_FAST_DIRECT && windowable) {
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
-        // the hot waves take a short fix list along (single frame, no failed tiles); otherwise ONE second launch
-        // recomputes failed tiles and fix pixels together (a dependent launch costs ~6 us on this stack, and a fork /
-        // join onto a second stream costs more than the overlap returns: measured, experiments/README.md)
-        const bool fused = n_frames == 1 && plan->n_fail_tiles == 0 && plan->n_fix_px <= 2048;
+        // one launch per frame: failed tiles and fix pixels go through the plan's stored faithful taps
         const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
-#define PB_LAUNCH_DOUBLE(WMODE, FUSED)                                                                                            \
-    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, FUSED>), grid, block, 0, st, P, plan->table, plan->table_r, rows, plan->lat_tab, \
-                       plan->fix_px, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride)
-        const int wmode = rows ? 1 : (plan->n_lat_tiles ? 2 : 0);
-        if (wmode == 1 && fused) PB_LAUNCH_DOUBLE(1, true);
-        else if (wmode == 1) PB_LAUNCH_DOUBLE(1, false);
-        else if (wmode == 2 && fused) PB_LAUNCH_DOUBLE(2, true);
-        else if (wmode == 2) PB_LAUNCH_DOUBLE(2, false);
-        else if (fused) PB_LAUNCH_DOUBLE(0, true);
+#define PB_LAUNCH_DOUBLE(WMODE, ONE)                                                                                              \
+    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, ONE>), grid, block, 0, st, P, plan->table, plan->table_r, rows, plan->lat_tab, \
+                       plan->fix_px, plan->dbl_px_fix, plan->dbl_tile_fix, src_dev, dst_dev, n_frames, src_frame_stride,           \
+                       dst_frame_stride)
+        const bool one = n_frames == 1;
+        if (rows && one) PB_LAUNCH_DOUBLE(1, true);
+        else if (rows) PB_LAUNCH_DOUBLE(1, false);
+        else if (plan->n_lat_tiles && one) PB_LAUNCH_DOUBLE(2, true);
+        else if (plan->n_lat_tiles) PB_LAUNCH_DOUBLE(2, false);
+        else if (one) PB_LAUNCH_DOUBLE(0, true);
         else PB_LAUNCH_DOUBLE(0, false);
 #undef PB_LAUNCH_DOUBLE
-        const unsigned fix_blocks = 4u * plan->n_fail_tiles + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
-        if (!fused && fix_blocks)
-            hipLaunchKernelGGL(pb_fix_double_kernel, dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, plan->fail_tiles, (int)plan->n_fail_tiles,
-                               plan->fix_px, (int)plan->n_fix_px, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
     } else if (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL) {
         hipLaunchKernelGGL(pb_sep_double_kernel, dim3(pb_hot_blocks(P)), dim3(64 * PB_TILE_WAVES), 0, st, P, plan->sep_rows, plan->sep_cols,
                            src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
