@@ -400,6 +400,27 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
     }
 }
 
+// The whole 256-byte tile entry in ONE scalar round trip (four s_load_dwordx16 in flight together), instead of
+// flags -> window fields -> coefficients as the uses come up: the wave's first source load is issued one memory
+// latency earlier.  The copy lives in SGPRs (every access below has a constant index).
+typedef int pb_i32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void pb_load_entry(const PbTileEntry* __restrict__ e, PbTileEntry& L) {
+    pb_i32x16 q0, q1, q2, q3;
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\t"
+                 "s_load_dwordx16 %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(q0), "=&s"(q1), "=&s"(q2), "=&s"(q3)
+                 : "s"(e)
+                 : "memory");
+    int* w = reinterpret_cast<int*>(&L);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        w[i] = q0[i];
+        w[16 + i] = q1[i];
+        w[32 + i] = q2[i];
+        w[48 + i] = q3[i];
+    }
+}
+
 // Exact-index tables (built once per plan by pb_fix_tables_kernel from the faithful chain): what the tile models
 // cannot reproduce is not recomputed per frame but LOOKED UP -
 //   idx_tab  the int32 source index (-1 = black) of every pixel of every failed tile, 4 KiB per tile, slot
@@ -423,7 +444,9 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tx, ty;
     if (!pb_tile_of_wave(P, wave, tx, ty)) return;
-    const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
+    PbTileEntry entry;
+    pb_load_entry(table + ((size_t)ty * pb_tiles_x(P) + tx), entry);
+    const PbTileEntry* __restrict__ e = &entry;
     const int flags = e->flags;
     if (flags & PB_TILE_FAILED) {
         // failed tile: gather through the plan's exact indices (lane = 4 consecutive pixels x 4 rows)

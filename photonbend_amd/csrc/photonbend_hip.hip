@@ -283,9 +283,8 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
     hipLaunchKernelGGL((pb_hot_win_kernel<KIND, ONE>), grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, pl->idx_tab, \
                        pl->fix_px, pl->fix_idx)
         if (P.src.kind == PB_KIND_PANO) {
-            // (measured on c2, same box: the loop build is ~2 % faster than the single-frame build for panorama
-            // sources, the single-frame build 2-3 % faster for fisheye sources)
-            PB_LAUNCH_WIN(PB_KIND_PANO, false);
+            if (n_frames == 1) PB_LAUNCH_WIN(PB_KIND_PANO, true);
+            else PB_LAUNCH_WIN(PB_KIND_PANO, false);
         } else {
             if (n_frames == 1) PB_LAUNCH_WIN(PB_KIND_CAMERA, true);
             else PB_LAUNCH_WIN(PB_KIND_CAMERA, false);
