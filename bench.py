@@ -254,7 +254,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 tile models + f64 plan/fix chain",
+            "dtype": "f32 (per-tile coordinate models, u8 samples; float64 only at plan creation)",
             "data": "synthetic",
             "config": {
                 "workload": "c2: one 8192x4096 equirectangular frame -> 4096x4096 equidistant-360 inscribed per step",
