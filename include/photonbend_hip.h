@@ -90,25 +90,29 @@ int pb_device_name(char* buf, size_t buflen);
 /* rot3x3: n_rot row-major 3x3 float64 matrices = Rotation.rotation_matrix
  * (core/rotation.py:100), applied in order; n_rot in [0, PB_MAX_ROTATIONS].
  * When a HIP device is visible, creation prepares the plan on the CURRENT device (synchronously,
- * about the cost of two faithful frames): destination-validity thresholds, per-tile models, and the
- * exhaustive comparison that yields the fix list.  The plan then owns device memory on that device
- * (256 B per 32x32 output tile + the fix list) until pb_plan_destroy. */
+ * about the cost of two faithful frames): destination-validity thresholds, per-tile models (one
+ * table per eye for a double-fisheye source), the exhaustive comparison with the faithful chain, and
+ * the exact lookup tables for everything the models miss (source indices of failed tiles and fix
+ * pixels; for double sources also their blend factors and the latitudes of merge-band tiles).  The
+ * plan then owns device memory on that device (256 B per 32x32 output tile and eye + the tables)
+ * until pb_plan_destroy. */
 int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, pb_plan** out);
 void pb_plan_destroy(pb_plan* plan);
-/* Execution mode of a plan.  AUTO (default) and FAST: the hot kernel (per-tile float32 polynomial
- * models of the coordinate field) followed by the fix kernel (faithful float64 chain on the plan's
- * fix list), when the plan was prepared on a device; otherwise, and under FAITHFUL, the per-pixel
- * float64 chain for every pixel.  Both produce identical bytes: the fix list is, by construction at
- * plan creation, every pixel whose model index differs from the faithful one. */
+/* Execution mode of a plan.  AUTO (default) and FAST: ONE launch of the hot kernel per call (per-tile
+ * float32 polynomial models of the coordinate field; what the models miss is looked up in the plan's
+ * exact tables), when the plan was prepared on a device; otherwise, and under FAITHFUL, the per-pixel
+ * float64 chain for every pixel.  Both produce identical bytes: the tables hold, by construction at
+ * plan creation, the faithful result for every pixel whose model index differs from the faithful one. */
 #define PB_MODE_AUTO 0
 #define PB_MODE_FAITHFUL 1
 #define PB_MODE_FAST 2
-#define PB_MODE_FAST_DIRECT 3 /* FAST, but always the direct-gather hot kernel + fix kernel (the path of unaligned frames) */
+#define PB_MODE_FAST_DIRECT 3 /* FAST without LDS windows: direct-gather hot kernel + fix kernel, the path of frames that are
+                                 not 16-byte aligned (double sources: the separable / faithful kernels) */
 int pb_plan_set_mode(pb_plan* plan, int mode);
 /* fast_path_enabled: 0/1 under the current mode; stats7: {32x32 tiles, tiles handled whole by the
- * fix kernel, single pixels on the fix list, pixels where model and faithful index differed,
+ * tables ("failed"), single pixels on the fix list, pixels where model and faithful index differed,
  * tiles on the lean LDS-window path, all-black tiles, tiles on the lean direct-gather path} (-1 when the
- * plan has no device state);
+ * plan has no device state; a double-fisheye source counts both eyes' tables in the last four);
  * thresholds4:
  * {invalid_lo, invalid_hi} on (2x)^2+(2y)^2 for the left/single and the right eye of the
  * destination.  Any pointer may be NULL. */
