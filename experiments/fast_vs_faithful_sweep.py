@@ -1,0 +1,45 @@
+"""Random geometry sweep, fast path vs faithful kernel, bytes compared (no oracle: hundreds of cases in seconds).
+python experiments/fast_vs_faithful_sweep.py [n_cases] [seed0]"""
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from photonbend_amd import _native as nat
+from tests import helpers as H
+from tests.test_hip_random import random_case, LENS_MAX_FOV
+from tests.cases import Case, cam, dbl, pano
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # multiplies every image dimension (and magnitude)
+bad = 0
+stats = {}
+for k in range(n):
+    rng = np.random.default_rng(seed0 + k)
+    case = random_case(rng, k)
+    if scale > 1:
+        def up(p):
+            kind, h, w, lens, fov, mag = p
+            return (kind, h * scale, w * scale, lens, fov, None if mag is None else mag * scale)
+        case = Case(case.name, up(case.dst), up(case.src), case.rotations, case.mask)
+    # widen: larger sizes now and then, 16-px-multiple source widths (LDS windows) half the time
+    if rng.random() < 0.5:
+        kind, h, w, lens, fov, mag = case.src
+        w16 = max(32, (w // 16) * 16)
+        case = Case(case.name, case.dst, (kind, h if kind != 'pano' else w16 // 2, w16, lens, fov, mag if kind != 'camera' or mag is None else min(mag, 0.75 * min(h, w16))), case.rotations, case.mask)
+    try:
+        plan = H.pb_plan(case)
+    except Exception as e:
+        print('plan failed', case, e); continue
+    _, h, w, *_ = case.src
+    frames = torch.stack([nat.synth_frame(h, w, frame=f) for f in range(2)])
+    plan.set_mode(nat.MODE_FAITHFUL)
+    want = plan.remap(frames).clone()
+    for mode in (nat.MODE_FAST, nat.MODE_FAST_DIRECT):
+        plan.set_mode(mode)
+        got = plan.remap(frames)
+        one = plan.remap(frames[1])
+        if not torch.equal(got, want) or not torch.equal(one, want[1]):
+            bad += 1
+            print('MISMATCH', mode, case, int((got != want).sum()), int((one != want[1]).sum()), plan.info(), flush=True)
+    key = (case.dst[0], case.src[0], len(case.rotations))
+    stats[key] = stats.get(key, 0) + 1
+print('cases', n, 'mismatching', bad)
+print(sorted(stats.items()))
