@@ -9,7 +9,6 @@ buffers.  Outputs are yielded in order as fresh ndarrays.
 
 from __future__ import annotations
 
-from concurrent.futures import ThreadPoolExecutor
 from typing import Iterable, Iterator
 
 import numpy as np
@@ -26,20 +25,7 @@ def plan_for(dst_image, rotations, src_image) -> nat.Plan:
     return _plan_for(dst_image._proj(), mats, src_image._proj())
 
 
-_POOL = ThreadPoolExecutor(max_workers=4)
-
-
-def _par_copy(dst: np.ndarray, src: np.ndarray, parts: int = 4) -> None:
-    """dst[...] = src split over a few threads (NumPy releases the GIL while copying): a single-threaded
-    memcpy of a 100 MB frame would cost more than its PCIe transfer."""
-    n = dst.shape[0]
-    if n < 4 * parts or dst.nbytes < (8 << 20):
-        dst[...] = src
-        return
-    step = (n + parts - 1) // parts
-    futs = [_POOL.submit(np.copyto, dst[i : i + step], src[i : i + step]) for i in range(0, n, step)]
-    for f in futs:
-        f.result()
+from .utils.hostcopy import par_copy as _par_copy
 
 
 def remap_frames(plan: nat.Plan, frames: Iterable[np.ndarray], depth: int = 3) -> Iterator[np.ndarray]:

@@ -23,6 +23,8 @@ from typing import Protocol, Union
 import numpy as np
 import torch
 
+from ..utils.hostcopy import par_copy, row_chunks
+
 from .. import _native as nat
 from ._coordmap import CoordinateMap
 from .lens import Lens, lens_id
@@ -63,11 +65,35 @@ def _pinned(shape, dtype, slot: str) -> torch.Tensor:
 
 
 def _to_host(t: torch.Tensor) -> np.ndarray:
-    """Device tensor -> fresh ndarray (the reference returns freshly allocated arrays) via pinned staging."""
+    """Device tensor -> fresh ndarray (the reference returns freshly allocated arrays) via pinned staging,
+    in row chunks: a chunk is copied out of the staging buffer (a few threads) while the next crosses PCIe."""
     stage = _pinned(t.shape, t.dtype, "d2h")
-    stage.copy_(t, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
-    return stage.numpy().copy()
+    chunks = row_chunks(t.shape[0], t.numel() * t.element_size()) if t.dim() >= 2 else [(0, t.shape[0])]
+    events = []
+    for a, b in chunks:
+        stage[a:b].copy_(t[a:b], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        events.append(ev)
+    out = np.empty(tuple(t.shape), stage.numpy().dtype)
+    sn = stage.numpy()
+    for (a, b), ev in zip(chunks, events):
+        ev.synchronize()
+        par_copy(out[a:b], sn[a:b])
+    return out
+
+
+def _upload(a: np.ndarray) -> torch.Tensor:
+    """uint8 ndarray -> CUDA tensor via pinned staging, in row chunks (copy of chunk k overlaps the PCIe
+    transfer of chunk k - 1)."""
+    stage = _pinned(a.shape, torch.uint8, "h2d")
+    torch.cuda.current_stream().synchronize()  # the staging buffer may still feed an earlier transfer
+    dev = torch.empty(tuple(a.shape), dtype=torch.uint8, device="cuda")
+    sn = stage.numpy()
+    for lo, hi in row_chunks(a.shape[0], a.nbytes):
+        par_copy(sn[lo:hi], a[lo:hi])
+        dev[lo:hi].copy_(stage[lo:hi], non_blocking=True)
+    return dev
 
 
 def _device_image(image, height: int, width: int) -> torch.Tensor:
@@ -85,9 +111,7 @@ def _device_image(image, height: int, width: int) -> torch.Tensor:
             raise TypeError(f"images are uint8 (H, W, 3) RGB arrays (core/__init__.py:31-36), got {a.dtype}")
         if tuple(a.shape) != (height, width, 3):
             raise ValueError(f"image must have shape ({height}, {width}, 3), got {tuple(a.shape)}")
-        stage = _pinned(a.shape, torch.uint8, "h2d")
-        stage.numpy()[...] = a
-        t = stage.to("cuda", non_blocking=True)
+        t = _upload(a)
     if tuple(t.shape) != (height, width, 3):
         raise ValueError(f"image must have shape ({height}, {width}, 3), got {tuple(t.shape)}")
     return t.contiguous()
