@@ -7,7 +7,7 @@ import torch
 
 from photonbend_amd import _native as nat
 from tests import helpers as H
-from tests.cases import Case, cam, case_by_name, inscribed, pano, small_cases
+from tests.cases import Case, cam, case_by_name, dbl, inscribed, pano, small_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -104,13 +104,24 @@ def test_streaming_batch_overlaps_and_matches():
     assert list(batch.remap_frames(plan, iter([]))) == []
 
 
-def test_remap_is_graph_capturable():
-    """Launch functions neither allocate nor synchronise: a burst of pb_remap_u8 calls captures into a HIP
-    graph (torch.cuda.CUDAGraph) and replays with the same bytes."""
-    case = Case("g", cam(256, 256, "equidistant", 360, inscribed(256)), pano(256, 512), [(5, 10, 15)])
+GRAPH_CASES = [
+    Case("g_pano", cam(256, 256, "equidistant", 360, inscribed(256)), pano(256, 512), [(5, 10, 15)]),
+    # a rim of failed tiles (360-degree equisolid destination): served from the plan's exact-index tables
+    Case("g_rim", cam(256, 256, "equisolid", 360, inscribed(256)), cam(256, 256, "equidistant", 360, inscribed(256)), [(30, 45, 10)]),
+    # double-fisheye source under a rotation: per-eye tables + latitude table
+    Case("g_double", pano(192, 384), dbl(256, 512, "equidistant", 195), [(3, 90, -7)]),
+]
+
+
+@pytest.mark.parametrize("case", GRAPH_CASES, ids=[c.name for c in GRAPH_CASES])
+def test_remap_is_graph_capturable(case):
+    """Launch functions neither allocate nor synchronise, and a frame is ONE launch whatever the geometry: a
+    burst of pb_remap_u8 calls captures into a HIP graph (torch.cuda.CUDAGraph) and replays with the same bytes."""
     plan = H.pb_plan(case)
-    frames = [nat.synth_frame(256, 512, frame=f) for f in range(4)]
-    outs = [torch.zeros((256, 256, 3), dtype=torch.uint8, device="cuda") for _ in range(4)]
+    sh, sw = case.src[1], case.src[2]
+    dh, dw = case.dst[1], case.dst[2]
+    frames = [nat.synth_frame(sh, sw, frame=f) for f in range(4)]
+    outs = [torch.zeros((dh, dw, 3), dtype=torch.uint8, device="cuda") for _ in range(4)]
     want = [plan.remap(f).clone() for f in frames]
     lib = nat.load()
     g = torch.cuda.CUDAGraph()
@@ -129,7 +140,7 @@ def test_remap_is_graph_capturable():
         assert torch.equal(outs[f], want[f])
     # new pixels in the same buffers, replay again
     for f in range(4):
-        frames[f].copy_(nat.synth_frame(256, 512, frame=10 + f))
+        frames[f].copy_(nat.synth_frame(sh, sw, frame=10 + f))
     want2 = [plan.remap(f).clone() for f in frames]
     g.replay()
     torch.cuda.synchronize()
