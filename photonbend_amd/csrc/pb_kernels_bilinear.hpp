@@ -9,7 +9,8 @@
 // outside [0, h) x [0, w)) stay black.  Double-fisheye sources are not supported in this mode.
 //
 //   pb_bilinear_hot_kernel   modelled tiles: float32 tile models give f (error ~1e-5 px, no fix list needed: there
-//                            is no truncation to protect), exact integer validity thresholds, four direct gathers
+//                            is no truncation to protect), exact integer validity thresholds; LEAN tiles read their
+//                            four taps from the LDS window of the nearest mode, other tiles gather them directly
 //   pb_bilinear_fix_kernel   failed tiles (seam, pole, centre, no model): float64 faithful chain per pixel
 #pragma once
 #include "pb_kernels_tile.hpp"
@@ -49,27 +50,159 @@ __device__ __forceinline__ unsigned pb_bilinear_taps(const PbParams& P, const ui
     return out;
 }
 
-template <int SRC_KIND>
+// one bilinear pixel from the wave's LDS window: the four taps around (sy, sx) = f - 0.5 in WINDOW coordinates
+// (LEAN tiles carry one texel of margin on every side - exactly the taps' reach - and lie strictly inside the
+// image, so nothing is clamped or wrapped)
+__device__ __forceinline__ unsigned pb_bilinear_lds(const unsigned* win, float sy, float sx, unsigned pitch, unsigned a0) {
+    const float fy0 = floorf(sy), fx0 = floorf(sx);
+    const float ty = sy - fy0, tx = sx - fx0;
+    const unsigned l00 = __umul24((unsigned)(int)fy0, pitch) + __umul24((unsigned)(int)fx0, 3u) + a0;
+    const unsigned l10 = l00 + pitch;
+    // two horizontally adjacent taps = 6 consecutive bytes: three aligned dwords cover them
+    const unsigned w0 = win[l00 >> 2], w1 = win[(l00 >> 2) + 1], w2 = win[(l00 >> 2) + 2];
+    const unsigned v0 = win[l10 >> 2], v1 = win[(l10 >> 2) + 1], v2 = win[(l10 >> 2) + 2];
+    // the right-hand tap starts 3 bytes on: in the same dword pair only when the left tap is dword-aligned
+    const bool c0 = (l00 & 3u) != 0, c1 = (l10 & 3u) != 0;
+    const unsigned p00 = __builtin_amdgcn_alignbyte(w1, w0, l00);
+    const unsigned p01 = __builtin_amdgcn_alignbyte(c0 ? w2 : w1, c0 ? w1 : w0, l00 + 3u);
+    const unsigned p10 = __builtin_amdgcn_alignbyte(v1, v0, l10);
+    const unsigned p11 = __builtin_amdgcn_alignbyte(c1 ? v2 : v1, c1 ? v1 : v0, l10 + 3u);
+    unsigned out = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float a = (float)((p00 >> (8 * ch)) & 0xFF), b = (float)((p01 >> (8 * ch)) & 0xFF);
+        const float c = (float)((p10 >> (8 * ch)) & 0xFF), d = (float)((p11 >> (8 * ch)) & 0xFF);
+        const float top = fmaf(tx, b - a, a), bot = fmaf(tx, d - c, c);
+        const float v = fmaf(ty, bot - top, top);
+        out |= ((unsigned)(int)rintf(fminf(fmaxf(v, 0.0f), 255.0f))) << (8 * ch);
+    }
+    return out;
+}
+
+// ONE: single-frame launch (no frame loop).  LEAN tiles take their taps from the LDS window the nearest mode
+// stages (same plan, same LDS-DMA loads); other tiles gather the taps from the frame.
+template <int SRC_KIND, bool ONE>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
                                                                               const uint8_t* __restrict__ src,
-                                                                              uint8_t* __restrict__ dst, int n_frames,
+                                                                              uint8_t* __restrict__ dst, int n_frames_arg,
                                                                               unsigned long long src_stride,
-                                                                              unsigned long long dst_stride) {
+                                                                              unsigned long long dst_stride, int windows) {
+    __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 4];
+    const int n_frames = ONE ? 1 : n_frames_arg;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tx, ty;
     if (!pb_tile_of_wave(P, wave, tx, ty)) return;
-    const PbTileEntry* __restrict__ e = table + ((size_t)ty * pb_tiles_x(P) + tx);
+    PbTileEntry entry;
+    pb_load_entry(table + ((size_t)ty * pb_tiles_x(P) + tx), entry);
+    const PbTileEntry* __restrict__ e = &entry;
     const int flags = e->flags;
     if (flags & PB_TILE_FAILED) return;
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
-    const int xg = lane & 7, yb = lane >> 3;
+    int xg = lane & 7, yb = lane >> 3;
     const int W = P.dst.width, H = P.dst.height;
-    const int x = X0 + 4 * xg;
     const int h = P.src.height, w = P.src.width;
+    unsigned* win = win_all[wave];
+    const unsigned rowbytes = 3u * (unsigned)w;
+    const unsigned safe_len = (rowbytes * (unsigned)h) & ~15u;
     for (int f = 0; f < n_frames; ++f) {
         const uint8_t* s = src + (unsigned long long)f * src_stride;
         uint8_t* d = dst + (unsigned long long)f * dst_stride;
+        if (!ONE) {  // keep the per-pixel work inside the frame loop (hoisting it costs hundreds of registers)
+            asm volatile("" : "+v"(xg));
+            asm volatile("" : "+v"(yb));
+        }
+        const int x = X0 + 4 * xg;
+        if ((flags & PB_TILE_LEAN) && windows) {  // (windows == 0: frames LDS-DMA cannot address)
+            const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
+            const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+            pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
+            pb_f2 fv[4][4];
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                pb_f2 a[5];
+                pb_collapse_row(e, yb + 8 * jr, a);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fv[jr][k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pb_wave_sync();
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                unsigned a[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = pb_bilinear_lds(win, fv[jr][k].x - 0.5f, fv[jr][k].y - 0.5f, pitch, a0);
+                // LEAN tiles lie fully inside the image
+                const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
+                if ((((uintptr_t)d + off) & 3u) == 0) {
+                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+                        d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+                        d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+                    }
+                }
+            }
+            if (f + 1 < n_frames) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                pb_wave_sync();  // the window is refilled by the next frame's loads
+            }
+            continue;
+        }
+        if (flags & PB_TILE_DIRECT) {
+            // sparse window: the four taps straight from the frame, unguarded unaligned dword loads (the tile's
+            // bounding box, margin included, lies inside the frame with room for the last 4-byte read), one row
+            // group's 16 loads in flight together
+            const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                pb_f2 c[5];
+                pb_collapse_row(e, yb + 8 * jr, c);
+                unsigned t[4][4];
+                float wy[4], wx[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const pb_f2 fv = pb_eval_row(c, pb_tile_coord(4 * xg + k));
+                    const float sy = fv.x - 0.5f, sx = fv.y - 0.5f;
+                    const float fy0 = floorf(sy), fx0 = floorf(sx);
+                    wy[k] = sy - fy0;
+                    wx[k] = sx - fx0;
+                    const unsigned g = gbase + (unsigned)(int)fy0 * rowbytes + __umul24((unsigned)(int)fx0, 3u);
+                    __builtin_memcpy(&t[k][0], s + g, 4);
+                    __builtin_memcpy(&t[k][1], s + g + 3u, 4);
+                    __builtin_memcpy(&t[k][2], s + g + rowbytes, 4);
+                    __builtin_memcpy(&t[k][3], s + g + rowbytes + 3u, 4);
+                }
+                unsigned a[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    unsigned out = 0;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float p = (float)((t[k][0] >> (8 * ch)) & 0xFF), q = (float)((t[k][1] >> (8 * ch)) & 0xFF);
+                        const float r = (float)((t[k][2] >> (8 * ch)) & 0xFF), u = (float)((t[k][3] >> (8 * ch)) & 0xFF);
+                        const float top = fmaf(wx[k], q - p, p), bot = fmaf(wx[k], u - r, r);
+                        const float v = fmaf(wy[k], bot - top, top);
+                        out |= ((unsigned)(int)rintf(fminf(fmaxf(v, 0.0f), 255.0f))) << (8 * ch);
+                    }
+                    a[k] = out;
+                }
+                const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
+                if ((((uintptr_t)d + off) & 3u) == 0) {
+                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+                        d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+                        d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
             const int y = Y0 + yb + 8 * jr;

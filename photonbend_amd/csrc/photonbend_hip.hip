@@ -469,19 +469,25 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
     hipStream_t st = (hipStream_t)stream;
     if (pb_use_fast(plan)) {
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
-        if (P.src.kind == PB_KIND_PANO) {
-            hipLaunchKernelGGL(pb_bilinear_hot_kernel<PB_KIND_PANO>, grid, block, 0, st, P, plan->table, src_dev, dst_dev, n_frames,
-                               src_frame_stride, dst_frame_stride);
-            if (plan->n_fail_tiles)
-                hipLaunchKernelGGL(pb_bilinear_fix_kernel<PB_KIND_PANO>, dim3(4u * plan->n_fail_tiles), dim3(PB_BLOCK), 0, st, P,
-                                   plan->fail_tiles, 0, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
-        } else {
-            hipLaunchKernelGGL(pb_bilinear_hot_kernel<PB_KIND_CAMERA>, grid, block, 0, st, P, plan->table, src_dev, dst_dev, n_frames,
-                               src_frame_stride, dst_frame_stride);
-            if (plan->n_fail_tiles)
-                hipLaunchKernelGGL(pb_bilinear_fix_kernel<PB_KIND_CAMERA>, dim3(4u * plan->n_fail_tiles), dim3(PB_BLOCK), 0, st, P,
-                                   plan->fail_tiles, 0, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
-        }
+        // LEAN tiles take their taps from LDS windows, except for frames LDS-DMA cannot address (not 16-byte aligned)
+        const bool one = n_frames == 1;
+        const int windows = plan->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
+                            ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
+#define PB_LAUNCH_BILINEAR(KIND)                                                                                                     \
+    do {                                                                                                                             \
+        if (one)                                                                                                                     \
+            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, true>), grid, block, 0, st, P, plan->table, src_dev, dst_dev, n_frames, \
+                               src_frame_stride, dst_frame_stride, windows);                                                         \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, false>), grid, block, 0, st, P, plan->table, src_dev, dst_dev, n_frames, \
+                               src_frame_stride, dst_frame_stride, windows);                                                         \
+        if (plan->n_fail_tiles)                                                                                                      \
+            hipLaunchKernelGGL(pb_bilinear_fix_kernel<KIND>, dim3(4u * plan->n_fail_tiles), dim3(PB_BLOCK), 0, st, P,                \
+                               plan->fail_tiles, 0, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);                 \
+    } while (0)
+        if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_BILINEAR(PB_KIND_PANO);
+        else PB_LAUNCH_BILINEAR(PB_KIND_CAMERA);
+#undef PB_LAUNCH_BILINEAR
     } else {
         if (P.src.kind == PB_KIND_PANO)
             hipLaunchKernelGGL(pb_bilinear_fix_kernel<PB_KIND_PANO>, dim3(pb_blocks(npx)), dim3(PB_BLOCK), 0, st, P, nullptr, 1, src_dev,
