@@ -158,10 +158,10 @@ __device__ __forceinline__ pb_u32x3 pb_pack_px4(unsigned a0, unsigned a1, unsign
 }
 
 // ---- hot kernel with prefetched LDS windows ---------------------------------------------------------
-// The plan entry carries the bounding box of the tile's source samples.  The wave first issues the whole
-// box as LDS-DMA loads (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, one row segment =
-// n16 consecutive lanes, no VGPRs), evaluates the tile model while the loads fly, then gathers every pixel
-// from LDS (aligned dword pair + v_alignbyte) and stores 12 packed bytes per 4 pixels.
+// The plan entry carries the bounding box of the tile's source samples.  The wave evaluates the tile model,
+// issues the whole box as LDS-DMA loads (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, one row
+// segment = n16 consecutive lanes, no VGPRs), then gathers every pixel from LDS (aligned dword pair +
+// v_alignbyte) and stores 12 packed bytes per 4 pixels; the CU's other waves fill the memory pipeline meanwhile.
 //   LEAN tiles (the common case, flagged by the plan builder): the model is anchored at the window
 //   origin, so (int)f IS the window row / column: ~11 VALU instructions per pixel, no validity, bounds,
 //   wrap or fallback code.
@@ -280,8 +280,6 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
         for (int f = 0; f < n_frames; ++f) {
             const uint8_t* s = src + (unsigned long long)f * src_stride;
             uint8_t* d = dst + (unsigned long long)f * dst_stride;
-            pb_issue_window_loads(s, win, lane, gbase, rowbytes, nrows, n16, safe_len);
-            PB_STAMP(0);
             unsigned la[4][4];
 #pragma unroll
             for (int jr = 0; jr < 4; ++jr) {
@@ -294,6 +292,11 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
                     la[jr][k] = __umul24(dr, pitch) + (__umul24(dc, 3u) + a0);
                 }
             }
+            // the window loads are issued AFTER the model math: measured 2 % faster on c2 than issuing them first
+            // and computing while they fly (the other waves of the CU keep the memory pipeline busy anyway)
+            asm volatile("" ::: "memory");
+            pb_issue_window_loads(s, win, lane, gbase, rowbytes, nrows, n16, safe_len);
+            PB_STAMP(0);
             PB_STAMP(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pb_wave_sync();
