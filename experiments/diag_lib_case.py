@@ -20,4 +20,4 @@ N = 24
 e0.record()
 for i in range(N): plan.remap(frames[i % 4], outs[i % 4])
 e1.record(); torch.cuda.synchronize()
-print(os.path.basename(lib), case.name, '%.1f us/frame' % (e0.elapsed_time(e1) * 1e3 / N))
+print(os.path.basename(lib), case.name, '%.1f us/frame' % (e0.elapsed_time(e1) * 1e3 / N), 'budget', plan.info().get('window_budget'))

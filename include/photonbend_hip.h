@@ -119,6 +119,9 @@ int pb_plan_set_mode(pb_plan* plan, int mode);
 int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats7, long long* thresholds4);
 int pb_plan_dst_shape(const pb_plan* plan, int* height, int* width);
 int pb_plan_src_shape(const pb_plan* plan, int* height, int* width);
+/* bytes of LDS window per wave the plan's hot launches use: picked per plan at creation by timing the
+ * candidates on scratch frames (it decides which path a tile takes, never its pixels); 0 without device state */
+int pb_plan_window_budget(const pb_plan* plan);
 
 /* Remap n_frames frames that share the plan's geometry.  Frame f is read at
  * src_dev + f * src_frame_stride and written at dst_dev + f * dst_frame_stride

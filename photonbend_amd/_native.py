@@ -64,6 +64,7 @@ SIGNATURES = {
     "pb_plan_info": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "pb_plan_dst_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_plan_src_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pb_plan_window_budget": (C.c_int, [_VP]),
     "pb_remap_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
     "pb_remap_bilinear_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
     "pb_index_map_i32": (C.c_int, [_VP, _VP, _VP, _VP]),
@@ -167,6 +168,7 @@ class Plan:
             "black_tiles": int(st[5]),
             "direct_tiles": int(st[6]),
             "thresholds": [int(t) for t in thr],
+            "window_budget": int(load().pb_plan_window_budget(self._h)),
         }
 
     def __del__(self):

@@ -87,7 +87,6 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(con
                                                                               uint8_t* __restrict__ dst, int n_frames_arg,
                                                                               unsigned long long src_stride,
                                                                               unsigned long long dst_stride, int windows) {
-    __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 4];
     const int n_frames = ONE ? 1 : n_frames_arg;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(con
     int xg = lane & 7, yb = lane >> 3;
     const int W = P.dst.width, H = P.dst.height;
     const int h = P.src.height, w = P.src.width;
-    unsigned* win = win_all[wave];
+    unsigned* win = pb_wave_window(P, wave);
     const unsigned rowbytes = 3u * (unsigned)w;
     const unsigned safe_len = (rowbytes * (unsigned)h) & ~15u;
     for (int f = 0; f < n_frames; ++f) {

@@ -55,9 +55,9 @@ __device__ __forceinline__ int pb_d_lean_bytes(const PbDesc& D) { return (D.flag
 
 // The wave's LDS window is shared by the two eyes: LEAN windows take what they need (the plan made sure
 // they fit together), generic windows share the rest.
-__device__ __forceinline__ void pb_d_budgets(const PbDesc& L, const PbDesc& R, int& budget_l, int& budget_r) {
+__device__ __forceinline__ void pb_d_budgets(const PbParams& P, const PbDesc& L, const PbDesc& R, int& budget_l, int& budget_r) {
     const int need_l = pb_d_lean_bytes(L), need_r = pb_d_lean_bytes(R);
-    const int rest = PB_WINLDS_BYTES - need_l - need_r;
+    const int rest = P.win_budget - need_l - need_r;
     const bool gen_l = PB_D_GENERIC(L.flags), gen_r = PB_D_GENERIC(R.flags);
     const int share = ((gen_l && gen_r) ? rest / 2 : rest) & ~15;
     budget_l = (L.flags & PB_TILE_LEAN) ? need_l : (gen_l ? share : 0);
@@ -195,7 +195,6 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
                                                                             const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                             int n_frames, unsigned long long src_stride,
                                                                             unsigned long long dst_stride) {
-    __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 8];
     const int frames = ONE ? 1 : n_frames;
     PbTileCtx C;
     C.lane = threadIdx.x & 63;
@@ -249,9 +248,9 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
 #pragma unroll
     for (int k = 0; k < 4; ++k) C.u[k] = pb_tile_coord(4 * C.xg + k);
     int budget_l, budget_r;
-    pb_d_budgets(DL, DR, budget_l, budget_r);
-    unsigned* win_l = win_all[wave];
-    unsigned* win_r = win_all[wave] + (budget_l >> 2);
+    pb_d_budgets(P, DL, DR, budget_l, budget_r);
+    unsigned* win_l = pb_wave_window(P, wave, 8);
+    unsigned* win_r = win_l + (budget_l >> 2);
     unsigned ql[16], qr[16], al[16], ar[16];
 #pragma unroll
     for (int n = 0; n < 16; ++n) ql[n] = qr[n] = al[n] = ar[n] = 0u;
@@ -479,4 +478,26 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_double_lat_kernel(const
         for (int r = 0; r < P.n_rot; ++r) c = pb_rotate(P.R[r], c);
         lt[y * PB_TILE + xh + k] = c.lat;
     }
+}
+
+// Plan creation: applies an LDS budget to a double plan (see pb_budget_kernel): an eye's LEAN window larger than the
+// budget goes direct; two LEAN windows that do not fit together: the larger one goes direct.
+__global__ void pb_budget_double_kernel(PbTileEntry* __restrict__ table_l, PbTileEntry* __restrict__ table_r,
+                                        const int32_t* __restrict__ saved_l, const int32_t* __restrict__ saved_r, unsigned n_tiles,
+                                        int budget, unsigned* __restrict__ counters) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    int fl = saved_l[t], fr = saved_r[t];
+    int need_l = (fl & PB_TILE_LEAN) ? table_l[t].win_rows * 16 * table_l[t].win_n16 : 0;
+    int need_r = (fr & PB_TILE_LEAN) ? table_r[t].win_rows * 16 * table_r[t].win_n16 : 0;
+    if (need_l > budget) { fl = (fl & ~PB_TILE_LEAN) | PB_TILE_DIRECT; need_l = 0; }
+    if (need_r > budget) { fr = (fr & ~PB_TILE_LEAN) | PB_TILE_DIRECT; need_r = 0; }
+    if (need_l + need_r > budget) {
+        if (need_l >= need_r) fl = (fl & ~PB_TILE_LEAN) | PB_TILE_DIRECT;
+        else fr = (fr & ~PB_TILE_LEAN) | PB_TILE_DIRECT;
+    }
+    table_l[t].flags = fl;
+    table_r[t].flags = fr;
+    atomicAdd(&counters[0], (unsigned)((fl & PB_TILE_LEAN) != 0) + (unsigned)((fr & PB_TILE_LEAN) != 0));
+    atomicAdd(&counters[1], (unsigned)((fl & PB_TILE_DIRECT) != 0) + (unsigned)((fr & PB_TILE_DIRECT) != 0));
 }

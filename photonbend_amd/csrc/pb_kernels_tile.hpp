@@ -168,7 +168,18 @@ __device__ __forceinline__ pb_u32x3 pb_pack_px4(unsigned a0, unsigned a1, unsign
 //   Other tiles: generic path - validity thresholds, wrap, per-pixel "inside the window" test with an
 //   unaligned global load as fallback.
 // Requires frame pointers and strides that are multiples of 16 bytes (else pb_hot_kernel is used).
-#define PB_WINLDS_BYTES 12288
+// LDS window per wave: the plan builder classifies with the largest budget and then picks, per plan, the budget
+// that runs fastest (smaller windows = more workgroups per CU, but more tiles on the direct-gather path);
+// the hot kernels take it from PbParams::win_budget and use dynamic LDS.
+#define PB_WINLDS_MAX 12288
+#define PB_WINLDS_BYTES PB_WINLDS_MAX  // classification budget of the plan builder
+extern __shared__ __attribute__((aligned(16))) unsigned pb_dyn_lds[];
+__device__ __forceinline__ unsigned* pb_wave_window(const PbParams& P, int wave, int pad_dwords = 4) {
+    return pb_dyn_lds + (size_t)wave * ((P.win_budget >> 2) + pad_dwords);
+}
+static inline size_t pb_window_lds_bytes(const PbParams& P, int pad_dwords = 4) {
+    return (size_t)PB_TILE_WAVES * ((size_t)P.win_budget + 4u * pad_dwords);
+}
 #ifdef PB_STAMPS
 __device__ unsigned long long pb_stamp_acc[65536 * 8];
 #define PB_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) pb_stamp_acc[(size_t)(ty * pb_tiles_x(P) + tx) * 8 + i] += t_ - t_prev; t_prev = t_; } while (0)
@@ -339,7 +350,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
     if (nrows > 0) {
         n16 = (3 * e->win_cols + 15 + 1 + 15) >> 4;  // + worst-case alignment slack + 1 byte for the dword reads
         if (n16 > 64) n16 = 64;
-        const int cap = PB_WINLDS_BYTES / (16 * n16);
+        const int cap = P.win_budget / (16 * n16);
         if (nrows > cap) nrows = cap;
     }
     const unsigned pitch = 16u * (unsigned)n16;
@@ -441,7 +452,6 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
                                                                          const int32_t* __restrict__ idx_tab,
                                                                          const int32_t* __restrict__ fix_px,
                                                                          const int32_t* __restrict__ fix_idx) {
-    __shared__ __attribute__((aligned(16))) unsigned win_all[PB_TILE_WAVES][PB_WINLDS_BYTES / 4 + 4];
     const int n_frames = ONE ? 1 : n_frames_arg;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
     unsigned long long tw0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tw0) :: "memory");
 #endif
-    pb_win_tile<SRC_KIND>(P, e, flags, tx, ty, lane, win_all[wave], src, dst, n_frames, src_stride, dst_stride);
+    pb_win_tile<SRC_KIND>(P, e, flags, tx, ty, lane, pb_wave_window(P, wave), src, dst, n_frames, src_stride, dst_stride);
 #ifdef PB_STAMPS
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -533,6 +543,24 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
             }
         }
     }
+}
+
+// Plan creation: applies an LDS budget to the classification made with PB_WINLDS_MAX.  saved = the flags as
+// classified (and certified); a LEAN tile whose window exceeds the budget takes the direct-gather path (same model,
+// same anchors, same pixels).  counters[0] = LEAN tiles, [1] = DIRECT tiles after the change.
+__global__ void pb_budget_kernel(PbTileEntry* __restrict__ table, const int32_t* __restrict__ saved, unsigned n_tiles, int budget,
+                                 unsigned* __restrict__ counters) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    int flags = saved[t];
+    if ((flags & PB_TILE_LEAN) && table[t].win_rows * 16 * table[t].win_n16 > budget) flags = (flags & ~PB_TILE_LEAN) | PB_TILE_DIRECT;
+    table[t].flags = flags;
+    if (flags & PB_TILE_LEAN) atomicAdd(&counters[0], 1u);
+    if (flags & PB_TILE_DIRECT) atomicAdd(&counters[1], 1u);
+}
+__global__ void pb_save_flags_kernel(const PbTileEntry* __restrict__ table, int32_t* __restrict__ saved, unsigned n_tiles) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tiles) saved[t] = table[t].flags;
 }
 
 // Plan creation: the exact-index tables of the hot kernel above.  Blocks [0, 4 * n_fail_tiles) take the failed

@@ -19,7 +19,7 @@ struct PbEnd {
 struct PbParams {
     PbEnd dst, src;
     int32_t n_rot;
-    int32_t pad0;
+    int32_t win_budget;  // bytes of LDS window per wave (hot kernels; chosen per plan, multiple of 16, <= PB_WINLDS_MAX)
     double R[PB_MAX_ROTATIONS][9];
 
     // ---- destination side -------------------------------------------------

@@ -280,7 +280,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
         // one launch per frame: failed tiles and fix pixels are looked up in the plan's exact-index tables by the
         // hot waves themselves (pb_kernels_tile.hpp)
 #define PB_LAUNCH_WIN(KIND, ONE)                                                                                               \
-    hipLaunchKernelGGL((pb_hot_win_kernel<KIND, ONE>), grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, pl->idx_tab, \
+    hipLaunchKernelGGL((pb_hot_win_kernel<KIND, ONE>), grid, block, pb_window_lds_bytes(P), st, P, pl->table, src, dst, n_frames, ss, ds, pl->idx_tab, \
                        pl->fix_px, pl->fix_idx)
         if (P.src.kind == PB_KIND_PANO) {
             if (n_frames == 1) PB_LAUNCH_WIN(PB_KIND_PANO, true);
@@ -315,6 +315,83 @@ static void pb_launch_faithful_remap(const PbParams& P, const uint8_t* src, uint
     const int aligned = (((uintptr_t)dst | ds) & 3u) == 0;
     hipLaunchKernelGGL(pb_remap_kernel<KIND>, dim3(pb_blocks((npx + PB_PX - 1) / PB_PX)), dim3(PB_BLOCK), 0, st, P, src, dst,
                        n_frames, ss, ds, aligned);
+}
+
+static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames, size_t src_frame_stride,
+                           size_t dst_frame_stride, hipStream_t st);
+
+// Picks the plan's LDS window budget by measurement: smaller windows let more workgroups share a CU (the hot
+// kernels are latency x concurrency bound) but push tiles with larger windows onto the direct-gather path; which
+// side wins depends on the geometry (c2 is fastest with 12 KiB windows, c1 / c3 / c5 with 7-8 KiB).  The
+// classification only decides the PATH a tile takes, never its pixels, so the choice cannot change a byte.
+// Three candidate budgets x a few launches on scratch frames, once per plan; small outputs are not worth it.
+static void pb_tune_window_budget(pb_plan* pl) {
+    PbParams& P = pl->P;
+    if (!(pl->fast_ready || pl->dbl_ready)) return;
+    const char* forced = getenv("PB_WIN_BUDGET");
+    const size_t sb = 3ull * P.src.height * P.src.width, db = 3ull * P.dst.height * P.dst.width;
+    const bool worth = (unsigned long long)P.dst.height * P.dst.width >= (1ull << 21) && sb + db <= (3ull << 30);
+    if (!forced && !worth) return;
+    const unsigned nt = pl->n_tiles;
+    int32_t *saved_l = nullptr, *saved_r = nullptr;
+    unsigned* counters = nullptr;
+    uint8_t *src = nullptr, *dst = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const dim3 g((nt + 255) / 256), b(256);
+    auto apply = [&](int budget) {
+        (void)hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
+        if (pl->dbl_ready)
+            hipLaunchKernelGGL(pb_budget_double_kernel, g, b, 0, 0, pl->table, pl->table_r, saved_l, saved_r, nt, budget, counters);
+        else
+            hipLaunchKernelGGL(pb_budget_kernel, g, b, 0, 0, pl->table, saved_l, nt, budget, counters);
+        P.win_budget = budget;
+    };
+    do {
+        if (hipMalloc((void**)&saved_l, (size_t)nt * sizeof(int32_t)) != hipSuccess) break;
+        if (pl->dbl_ready && hipMalloc((void**)&saved_r, (size_t)nt * sizeof(int32_t)) != hipSuccess) break;
+        if (hipMalloc((void**)&counters, 2 * sizeof(unsigned)) != hipSuccess) break;
+        hipLaunchKernelGGL(pb_save_flags_kernel, g, b, 0, 0, pl->table, saved_l, nt);
+        if (pl->dbl_ready) hipLaunchKernelGGL(pb_save_flags_kernel, g, b, 0, 0, pl->table_r, saved_r, nt);
+        int best = PB_WINLDS_MAX;
+        if (forced) {
+            best = atoi(forced) & ~15;
+            if (best < 1024 || best > PB_WINLDS_MAX) best = PB_WINLDS_MAX;
+        } else {
+            if (hipMalloc((void**)&src, sb + 16) != hipSuccess || hipMalloc((void**)&dst, db + 16) != hipSuccess) break;
+            if (hipMemsetAsync(src, 0x55, sb, 0) != hipSuccess) break;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+            const int cand[3] = {PB_WINLDS_MAX, 8176, 7168};  // 3, 5 and 5 workgroups per CU
+            float best_ms = 1e30f;
+            bool failed = false;
+            for (int c = 0; c < 3 && !failed; ++c) {
+                apply(cand[c]);
+                float ms_min = 1e30f;
+                for (int rep = 0; rep < 4; ++rep) {  // the first launch warms caches and is not counted
+                    (void)hipEventRecord(e0, 0);
+                    if (pb_remap_launch(pl, src, dst, 1, 0, 0, 0) != PB_OK) { failed = true; break; }
+                    (void)hipEventRecord(e1, 0);
+                    if (hipEventSynchronize(e1) != hipSuccess) { failed = true; break; }
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, e0, e1);
+                    if (rep > 0 && ms < ms_min) ms_min = ms;
+                }
+                // a smaller budget has to win by a clear margin (timing noise must not flip the choice)
+                if (!failed && ms_min < best_ms * (c == 0 ? 1.0f : 0.97f)) { best_ms = ms_min; best = cand[c]; }
+            }
+            if (failed) best = PB_WINLDS_MAX;
+        }
+        apply(best);
+        unsigned res[2] = {0, 0};
+        if (hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost) == hipSuccess) {
+            pl->n_lean_tiles = res[0];
+            pl->n_direct_tiles = res[1];
+        }
+    } while (0);
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(src); (void)hipFree(dst); (void)hipFree(saved_l); (void)hipFree(saved_r); (void)hipFree(counters);
 }
 
 extern "C" {
@@ -357,6 +434,7 @@ int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb
     for (int k = 0; k < n_rot; ++k)
         for (int e = 0; e < 9; ++e) pl->P.R[k][e] = rot3x3[9 * k + e];
     pb_derive(pl->P);
+    pl->P.win_budget = PB_WINLDS_MAX;
     pl->mode = PB_MODE_AUTO;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
@@ -367,6 +445,7 @@ int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb
             delete pl;
             return rc;
         }
+        pb_tune_window_budget(pl);
     }
     *out = pl;
     return PB_OK;
@@ -394,6 +473,9 @@ int pb_plan_dst_shape(const pb_plan* plan, int* height, int* width) {
     *width = plan->P.dst.width;
     return PB_OK;
 }
+int pb_plan_window_budget(const pb_plan* plan) {
+    return (plan && (plan->fast_ready || plan->dbl_ready)) ? plan->P.win_budget : 0;
+}
 int pb_plan_src_shape(const pb_plan* plan, int* height, int* width) {
     if (!plan || !height || !width) return pb_fail(PB_ERR_INVALID, "null argument");
     *height = plan->P.src.height;
@@ -416,14 +498,23 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
     if (!src_frame_stride) src_frame_stride = 3ull * P.src.height * P.src.width;
     if (!dst_frame_stride) dst_frame_stride = 3ull * npx;
     if (dst_frame_stride < 3ull * npx) return pb_fail(PB_ERR_INVALID, "dst_frame_stride smaller than a frame");
-    hipStream_t st = (hipStream_t)stream;
+    return pb_remap_launch(plan, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride, (hipStream_t)stream);
+}
+}  // extern "C"
+
+static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames, size_t src_frame_stride,
+                           size_t dst_frame_stride, hipStream_t st) {
+    const PbParams& P = plan->P;
+    const unsigned long long npx = (unsigned long long)P.dst.height * P.dst.width;
+    if (!src_frame_stride) src_frame_stride = 3ull * P.src.height * P.src.width;
+    if (!dst_frame_stride) dst_frame_stride = 3ull * npx;
     const bool windowable = ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;  // LDS-DMA row segments
     if (plan->dbl_ready && plan->mode != PB_MODE_FAITHFUL && plan->mode != PB_MODE_FAST_DIRECT && windowable) {
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
         // one launch per frame: failed tiles and fix pixels go through the plan's stored faithful taps
         const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
 #define PB_LAUNCH_DOUBLE(WMODE, ONE)                                                                                              \
-    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, ONE>), grid, block, 0, st, P, plan->table, plan->table_r, rows, plan->lat_tab, \
+    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, ONE>), grid, block, pb_window_lds_bytes(P, 8), st, P, plan->table, plan->table_r, rows, plan->lat_tab, \
                        plan->fix_px, plan->dbl_px_fix, plan->dbl_tile_fix, src_dev, dst_dev, n_frames, src_frame_stride,           \
                        dst_frame_stride)
         const bool one = n_frames == 1;
@@ -449,6 +540,8 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
+
+extern "C" {
 
 int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames, size_t src_frame_stride,
                          size_t dst_frame_stride, void* stream) {
@@ -476,10 +569,10 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
 #define PB_LAUNCH_BILINEAR(KIND)                                                                                                     \
     do {                                                                                                                             \
         if (one)                                                                                                                     \
-            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, true>), grid, block, 0, st, P, plan->table, src_dev, dst_dev, n_frames, \
+            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, true>), grid, block, pb_window_lds_bytes(P), st, P, plan->table, src_dev, dst_dev, n_frames, \
                                src_frame_stride, dst_frame_stride, windows);                                                         \
         else                                                                                                                         \
-            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, false>), grid, block, 0, st, P, plan->table, src_dev, dst_dev, n_frames, \
+            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, false>), grid, block, pb_window_lds_bytes(P), st, P, plan->table, src_dev, dst_dev, n_frames, \
                                src_frame_stride, dst_frame_stride, windows);                                                         \
         if (plan->n_fail_tiles)                                                                                                      \
             hipLaunchKernelGGL(pb_bilinear_fix_kernel<KIND>, dim3(4u * plan->n_fail_tiles), dim3(PB_BLOCK), 0, st, P,                \
