@@ -163,3 +163,43 @@ def test_remap_batch_sharded_single_process():
         frame = nat.synth_frame(64, 128, frame=i).cpu().numpy()
         want = pb.PanoramaImage(frame).process_coordinate_map(rot.rotate_coordinate_map(dst.get_coordinate_map()))
         assert np.array_equal(outs[i].cpu().numpy(), want)
+
+
+BUDGET_CASES = [
+    Case("b_pano", cam(768, 768, "equidistant", 360, inscribed(768)), pano(512, 1024), [(10, 20, 30)]),
+    Case("b_cam", pano(512, 1024), cam(768, 768, "equidistant", 360, inscribed(768))),
+    Case("b_double", pano(512, 1024), dbl(480, 960, "equidistant", 195), [(3, 90, -7)]),
+]
+
+
+@pytest.mark.parametrize("case", BUDGET_CASES, ids=[c.name for c in BUDGET_CASES])
+def test_window_budget_only_moves_tiles_between_paths(case, monkeypatch):
+    """The per-plan LDS window budget (normally picked by timing at plan creation) decides which PATH a tile takes
+    - LDS window or direct gather - never its pixels: every budget reproduces the faithful bytes, in the nearest
+    and (where supported) the bilinear mode."""
+    from photonbend_amd.core.projection import _PLAN_CACHE
+
+    frames = torch.stack([nat.synth_frame(case.src[1], case.src[2], frame=f) for f in range(2)])
+    want = None
+    b0 = None
+    leans = []
+    for budget in (12288, 8176, 4096, 1024):
+        monkeypatch.setenv("PB_WIN_BUDGET", str(budget))
+        _PLAN_CACHE.clear()
+        plan = H.pb_plan(case)
+        info = plan.info()
+        assert info["window_budget"] == budget
+        leans.append(info["lean_tiles"])
+        if want is None:
+            plan.set_mode(nat.MODE_FAITHFUL)
+            want = plan.remap(frames).clone()
+            plan.set_mode(nat.MODE_AUTO)
+        assert torch.equal(plan.remap(frames), want), budget
+        assert torch.equal(plan.remap(frames[1]), want[1]), budget
+        if case.src[0] != "double":
+            got = plan.remap(frames[0], interpolation="bilinear")
+            if b0 is None:
+                b0 = got.clone()
+            assert torch.equal(got, b0), budget
+    _PLAN_CACHE.clear()
+    assert leans == sorted(leans, reverse=True) and leans[0] > leans[-1]  # smaller windows: fewer LEAN tiles
