@@ -1,15 +1,17 @@
 // pb_kernels_tile.hpp - the fast path for pano / camera sources.
 //
-//   per frame (pb_remap_u8):   pb_hot_win_kernel alone (16-byte aligned frames), else pb_hot_kernel -> pb_fix_kernel
+//   per frame (pb_remap_u8):    pb_hot_win_kernel, ONE launch (16-byte aligned frames: LDS-DMA windows)
+//                               else pb_hot_kernel -> pb_fix_kernel (direct gathers; also the int32 index-map output)
 //   per plan  (pb_plan_create): pb_threshold_kernel -> pb_model_kernel -> pb_window_kernel -> pb_certify_kernel
+//                               -> pb_fix_tables_kernel (exact lookup tables) -> pb_budget_kernel (LDS budget, tuned)
 //
-// pb_hot_kernel: one WAVE per 32x32 output tile, 4 tiles (a 64x64 block) per workgroup,
-// no workgroup barrier.  Math phase: lane = (row, half-row), 16 pixels each, float32 model
-// evaluation (pb_tile.hpp), indices into a wave-private LDS tile.  Gather phase: lane = 4
-// consecutive pixels x 4 rows, so that one load instruction of the wave covers a compact
-// 32x8-pixel patch; unaligned dword loads; one 12-byte store per 4 pixels.
-// pb_fix_kernel: the faithful float64 chain for the plan's fix list (whole failed tiles
-// and single pixels), overwriting what the hot kernel wrote there.
+// pb_hot_win_kernel (below, "hot kernel with prefetched LDS windows"): one WAVE per 32x32 output tile, 4 tiles (a
+// 64x64 block) per workgroup, no workgroup barrier; tile classes LEAN / DIRECT / BLACK / generic / failed.
+// pb_hot_kernel: the same models without windows - math phase: lane = (row, half-row), 16 pixels each, float32
+// model evaluation (pb_tile.hpp), indices into a wave-private LDS tile; gather phase: lane = 4 consecutive pixels
+// x 4 rows, unaligned dword loads, one 12-byte store per 4 pixels.
+// pb_fix_kernel: the faithful float64 chain for the plan's fix list (whole failed tiles and single pixels),
+// overwriting what pb_hot_kernel wrote there (pb_hot_win_kernel looks those pixels up instead).
 #pragma once
 #include "pb_kernels_faithful.hpp"
 #include "pb_tile.hpp"

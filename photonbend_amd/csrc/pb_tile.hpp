@@ -14,9 +14,10 @@
 // function (bit-reproducible: no contraction, explicit fmaf) next to the faithful
 // chain for EVERY output pixel and records each pixel whose truncated index differs in
 // the plan's fix list (tiles with many such pixels - a seam, a pole, the fisheye
-// centre, a steep lens edge - are listed whole).  Every frame the hot kernel is
-// followed by the fix kernel, which recomputes exactly those pixels with the faithful
-// chain.  The union is bit-identical to the faithful path for every pixel.
+// centre, a steep lens edge - are listed whole).  For exactly those pixels the plan
+// stores the faithful result (source indices; for double sources taps and factors) and
+// the hot kernel looks it up.  The union is bit-identical to the faithful path for every
+// pixel, and no frame runs the float64 chain.
 #pragma once
 #include "pb_stages.hpp"
 

@@ -1,7 +1,11 @@
 // photonbend_hip.hip - the C ABI declared in include/photonbend_hip.h over the HIP kernels
 // (gfx950 / CDNA4):
-//   pb_kernels_faithful.hpp  per-pixel float64 chain (reference semantics, double sources, map API)
-//   pb_kernels_tile.hpp      hot kernel (per-tile float32 models + gather) and fix kernel; plan builders
+//   pb_kernels_faithful.hpp  per-pixel float64 chain (the reference semantics on the device; map API; PB_MODE_FAITHFUL)
+//   pb_kernels_tile.hpp      hot kernel for pano / camera sources (per-tile float32 models, LDS windows, exact
+//                            lookup tables), plan builders
+//   pb_kernels_double.hpp    hot kernel for double-fisheye sources (one tile table per eye, weight classes)
+//   pb_kernels_sep.hpp       separable tables for the unrotated stitch (row factors; unaligned-frame fallback)
+//   pb_kernels_bilinear.hpp  opt-in bilinear sampling
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared ...
 // (-ffp-contract=off is REQUIRED: the reference rounds every multiply and add
