@@ -359,7 +359,7 @@ static void pb_tune_window_budget(pb_plan* pl) {
         int best = PB_WINLDS_MAX;
         if (forced) {
             best = atoi(forced) & ~15;
-            if (best < 1024 || best > PB_WINLDS_MAX) best = PB_WINLDS_MAX;
+            if (best < PB_DIRECT_LDS_BYTES || best > PB_WINLDS_MAX) best = PB_WINLDS_MAX;
         } else {
             if (hipMalloc((void**)&src, sb + 16) != hipSuccess || hipMalloc((void**)&dst, db + 16) != hipSuccess) break;
             if (hipMemsetAsync(src, 0x55, sb, 0) != hipSuccess) break;

@@ -183,7 +183,7 @@ def test_window_budget_only_moves_tiles_between_paths(case, monkeypatch):
     want = None
     b0 = None
     leans = []
-    for budget in (12288, 8176, 4096, 1024):
+    for budget in (12288, 8176, 6144, 4224):
         monkeypatch.setenv("PB_WIN_BUDGET", str(budget))
         _PLAN_CACHE.clear()
         plan = H.pb_plan(case)
