@@ -267,6 +267,39 @@ __global__ __launch_bounds__(256) void k_exchange(const Args A) {
     }
 }
 
+// "direct" variants: every tile gathers its 1024 samples straight from the frame (no LDS window), 16 unaligned
+// dword loads per lane; lane mapping A = 4 consecutive pixels x 4 rows per lane, mapping C = one pixel column
+// per lane (32 consecutive pixels of a row per half-wave, 2 rows per load instruction).  Same stores.
+template <int MAPPING>
+__global__ __launch_bounds__(256) void k_direct(const Args A) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= A.n_tiles) return;
+    const int R = A.R, n16 = A.n16;
+    const unsigned pitch = 16u * n16;
+    const unsigned wr = (unsigned)w / A.wins_per_row, wc = (unsigned)w % A.wins_per_row;
+    const unsigned gbase = wr * A.rstride * A.rowbytes + wc * n16 * 16u;
+    unsigned px[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        unsigned x, y;
+        if (MAPPING == 0) { x = 4u * (lane & 7) + (n & 3); y = (lane >> 3) + 8u * (n >> 2); }
+        else { x = lane & 31; y = (lane >> 5) + 2u * n; }
+        const unsigned dr = (y * (unsigned)R) >> 5, dc = (x * (pitch - 4u) / 3u) >> 5;
+        __builtin_memcpy(&px[n], A.src + gbase + dr * A.rowbytes + dc * 3u, 4);
+    }
+    const int tx = w & 127, ty = w >> 7;
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+        u32x3 o;
+        o.x = __builtin_amdgcn_perm(px[jr * 4 + 1], px[jr * 4 + 0], 0x04020100u);
+        o.y = __builtin_amdgcn_perm(px[jr * 4 + 2], px[jr * 4 + 1], 0x05040201u);
+        o.z = __builtin_amdgcn_perm(px[jr * 4 + 3], px[jr * 4 + 2], 0x06050402u);
+        const size_t off = 3ull * ((size_t)(ty * 32 + (lane >> 3) + 8 * jr) * A.dst_w + tx * 32 + 4 * (lane & 7));
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x3*>(A.dst + off));
+    }
+}
+
 int main() {
     const unsigned rowbytes = 24576, H = 4096;
     const size_t bytes = (size_t)rowbytes * H;  // 100 MB
@@ -303,5 +336,30 @@ int main() {
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
                 printf("window %2d x %3d B, quad-padded lanes %d, stage %d: %5d tiles %7.2f us  (%.2f ns/tile)\n", sh[0], sh[1] * 16, mis, stage, A.n_tiles, ms * 1e3 / N, ms * 1e6 / N / A.n_tiles);
             }
+    // all-direct, lane mapping A vs C (MI355X: 64 rows x 192 B footprint 28.0 vs 24.2 us, 64 x 384 B 18.3 vs 16.4 us
+    // for half the tiles, 32 x 192 B 30.9 vs 29.8 us): what decided the orientation-adaptive direct gathers
+    const int fp[][2] = {{64, 12}, {64, 24}, {32, 12}};
+    for (auto& sh : fp)
+        for (int mapping = 0; mapping < 2; ++mapping) {
+            Args A;
+            A.R = sh[0]; A.n16 = sh[1]; A.rowbytes = rowbytes; A.wins_per_row = rowbytes / (A.n16 * 16);
+            A.n_tiles = 16384; A.stage = 4; A.dst_w = 4096; A.sink = sink; A.spat = 0; A.misalign = 0; A.lpr = A.n16;
+            if (A.n_tiles / A.wins_per_row * 32 + A.R + 2 > (int)H + 70) A.n_tiles = ((int)H + 60 - A.R) / 32 * A.wins_per_row;
+            A.rstride = 32;
+            auto launch = [&](int p) {
+                A.src = srcs[p]; A.dst = dsts[p];
+                if (mapping == 0) k_direct<0><<<(A.n_tiles + 3) / 4, 256>>>(A);
+                else k_direct<1><<<(A.n_tiles + 3) / 4, 256>>>(A);
+            };
+            for (int i = 0; i < 5; i++) launch(i % POOL);
+            CK(hipDeviceSynchronize());
+            const int N = 40;
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < N; i++) launch(i % POOL);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("all-direct, footprint %2d rows x %3d B, lane mapping %s: %5d tiles %7.2f us\n", sh[0], sh[1] * 16, mapping ? "C (pixel column per lane)" : "A (4 px x 4 rows per lane)", A.n_tiles, ms * 1e3 / N);
+        }
     return 0;
 }
