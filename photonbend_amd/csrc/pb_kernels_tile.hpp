@@ -249,13 +249,18 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
         const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
         const bool along_x = fabsf(e->c[1][0]) <= fabsf(e->c[5][0]);  // |d row / du| <= |d row / dv|
         const int p = lane & 31, hh = lane >> 5;
+        // shear: the 32 lanes of a half-wave follow the line of constant source row through the tile (the pixel
+        // of lane p in pass n is (p, (2n + hh + shift(p)) mod 32), a bijection of the tile): c3 -7 %, c2 unchanged
+        const float num = along_x ? e->c[1][0] : e->c[5][0], den = along_x ? e->c[5][0] : e->c[1][0];
+        const float slope = (den != 0.0f) ? -num / den : 0.0f;
+        const int shift = (int)rintf(slope * ((float)p - 15.5f));
         unsigned go[16];
         if (along_x) {
             const float ux = pb_tile_coord(p);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
                 pb_f2 a[5];
-                pb_collapse_row(e, 2 * n + hh, a);
+                pb_collapse_row(e, (2 * n + hh + shift) & 31, a);
                 const pb_f2 fv = pb_eval_row(a, ux);
                 go[n] = gbase + (unsigned)(int)fv.x * rowbytes + __umul24((unsigned)(int)fv.y, 3u);
             }
@@ -264,7 +269,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             pb_collapse_row(e, p, a);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
-                const pb_f2 fv = pb_eval_row(a, pb_tile_coord(2 * n + hh));
+                const pb_f2 fv = pb_eval_row(a, pb_tile_coord((2 * n + hh + shift) & 31));
                 go[n] = gbase + (unsigned)(int)fv.x * rowbytes + __umul24((unsigned)(int)fv.y, 3u);
             }
         }
@@ -277,7 +282,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             // park as [y][x] with a 33-dword pitch, read back as 4 consecutive pixels x 4 rows per lane
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
-                const int q = 2 * n + hh;
+                const int q = (2 * n + hh + shift) & 31;
                 win[along_x ? q * 33 + p : p * 33 + q] = t[n];
             }
             pb_wave_sync();
