@@ -328,7 +328,7 @@ static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t*
 // kernels are latency x concurrency bound) but push tiles with larger windows onto the direct-gather path; which
 // side wins depends on the geometry (c2 is fastest with 12 KiB windows, c1 / c3 / c5 with 7-8 KiB).  The
 // classification only decides the PATH a tile takes, never its pixels, so the choice cannot change a byte.
-// Three candidate budgets x a few launches on scratch frames, once per plan; small outputs are not worth it.
+// Four candidate budgets x a few launches on scratch frames, once per plan; small outputs are not worth it.
 static void pb_tune_window_budget(pb_plan* pl) {
     PbParams& P = pl->P;
     if (!(pl->fast_ready || pl->dbl_ready)) return;
@@ -364,24 +364,27 @@ static void pb_tune_window_budget(pb_plan* pl) {
             if (hipMalloc((void**)&src, sb + 16) != hipSuccess || hipMalloc((void**)&dst, db + 16) != hipSuccess) break;
             if (hipMemsetAsync(src, 0x55, sb, 0) != hipSuccess) break;
             if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
-            const int cand[3] = {PB_WINLDS_MAX, 8176, 7168};  // 3, 5 and 5 workgroups per CU
-            float best_ms = 1e30f;
+            const int cand[4] = {PB_WINLDS_MAX, 10224, 8176, 7168};  // 3, 4, 5 and 5 workgroups per CU (LDS-wise)
+            float t_min[4] = {1e30f, 1e30f, 1e30f, 1e30f};
             bool failed = false;
-            for (int c = 0; c < 3 && !failed; ++c) {
-                apply(cand[c]);
-                float ms_min = 1e30f;
-                for (int rep = 0; rep < 4; ++rep) {  // the first launch warms caches and is not counted
-                    (void)hipEventRecord(e0, 0);
-                    if (pb_remap_launch(pl, src, dst, 1, 0, 0, 0) != PB_OK) { failed = true; break; }
-                    (void)hipEventRecord(e1, 0);
-                    if (hipEventSynchronize(e1) != hipSuccess) { failed = true; break; }
-                    float ms = 0.f;
-                    (void)hipEventElapsedTime(&ms, e0, e1);
-                    if (rep > 0 && ms < ms_min) ms_min = ms;
+            for (int pass = 0; pass < 2 && !failed; ++pass)  // two interleaved passes: clock ramps and noise hit all alike
+                for (int c = 0; c < 4 && !failed; ++c) {
+                    apply(cand[c]);
+                    for (int rep = 0; rep < 4; ++rep) {  // the first launch after a reclassification is not counted
+                        (void)hipEventRecord(e0, 0);
+                        if (pb_remap_launch(pl, src, dst, 1, 0, 0, 0) != PB_OK) { failed = true; break; }
+                        (void)hipEventRecord(e1, 0);
+                        if (hipEventSynchronize(e1) != hipSuccess) { failed = true; break; }
+                        float ms = 0.f;
+                        (void)hipEventElapsedTime(&ms, e0, e1);
+                        if (rep > 0 && ms < t_min[c]) t_min[c] = ms;
+                    }
                 }
-                // a smaller budget has to win by a clear margin (timing noise must not flip the choice)
-                if (!failed && ms_min < best_ms * (c == 0 ? 1.0f : 0.97f)) { best_ms = ms_min; best = cand[c]; }
-            }
+            // the fastest candidate; ties within 1 % go to the larger windows
+            int bi = 0;
+            for (int c = 1; c < 4; ++c)
+                if (t_min[c] < t_min[bi] * 0.99f) bi = c;
+            best = cand[bi];
             if (failed) best = PB_WINLDS_MAX;
         }
         apply(best);
