@@ -10,8 +10,8 @@
 // pb_hot_kernel: the same models without windows - math phase: lane = (row, half-row), 16 pixels each, float32
 // model evaluation (pb_tile.hpp), indices into a wave-private LDS tile; gather phase: lane = 4 consecutive pixels
 // x 4 rows, unaligned dword loads, one 12-byte store per 4 pixels.
-// pb_fix_kernel: the faithful float64 chain for the plan's fix list (whole failed tiles and single pixels),
-// overwriting what pb_hot_kernel wrote there (pb_hot_win_kernel looks those pixels up instead).
+// pb_fix_kernel: the plan's fix list (whole failed tiles and single pixels) behind pb_hot_kernel, served from the
+// exact-index tables like everything else the models miss; no per-frame kernel runs the float64 chain.
 #pragma once
 #include "pb_kernels_faithful.hpp"
 #include "pb_tile.hpp"
@@ -615,32 +615,33 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_fix_tables_kernel(const PbParams 
     fix_idx[item] = pb_exact_index<SRC_KIND>(P, i, j);
 }
 
-// The plan's fix list: blocks [0, 4 * n_fail_tiles) take the failed tiles (256 px each), the
-// remaining blocks take single pixels (linear output positions).
-template <int SRC_KIND, int OUT>
+// The plan's fix list behind pb_hot_kernel (frames LDS-DMA cannot address, and the int32 index-map output): blocks
+// [0, 4 * n_fail_tiles) take the failed tiles (256 px each), the remaining blocks single pixels; the faithful
+// results come from the plan's exact-index tables (pb_fix_tables_kernel), nothing is recomputed.
+template <int OUT>
 __global__ __launch_bounds__(PB_BLOCK) void pb_fix_kernel(const PbParams P, const int32_t* __restrict__ fail_tiles,
                                                           int n_fail_tiles, const int32_t* __restrict__ fix_px,
-                                                          int n_fix_px, const uint8_t* __restrict__ src,
+                                                          int n_fix_px, const int32_t* __restrict__ idx_tab,
+                                                          const int32_t* __restrict__ fix_idx, const uint8_t* __restrict__ src,
                                                           uint8_t* __restrict__ dst, int n_frames,
                                                           unsigned long long src_stride, unsigned long long dst_stride,
                                                           int32_t* __restrict__ idx_out) {
-    int i, j;
+    int id;
+    size_t p;
     if ((int)blockIdx.x < 4 * n_fail_tiles) {
-        const int t = fail_tiles[blockIdx.x >> 2];
+        const int s = blockIdx.x >> 2, t = fail_tiles[s];
         const int ty = t / pb_tiles_x(P), tx = t - ty * pb_tiles_x(P);
         const int local = (blockIdx.x & 3) * 256 + threadIdx.x;
-        i = ty * PB_TILE + (local >> 5);
-        j = tx * PB_TILE + (local & 31);
+        const int i = ty * PB_TILE + (local >> 5), j = tx * PB_TILE + (local & 31);
         if (i >= P.dst.height || j >= P.dst.width) return;
+        id = idx_tab[(size_t)s * (PB_TILE * PB_TILE) + local];
+        p = (size_t)i * P.dst.width + j;
     } else {
         const unsigned item = (blockIdx.x - 4u * n_fail_tiles) * PB_BLOCK + threadIdx.x;
         if (item >= (unsigned)n_fix_px) return;
-        const unsigned p = (unsigned)fix_px[item];
-        i = p / (unsigned)P.dst.width;
-        j = p - (unsigned)i * (unsigned)P.dst.width;
+        id = fix_idx[item];
+        p = (size_t)(unsigned)fix_px[item];
     }
-    const int id = pb_exact_index<SRC_KIND>(P, i, j);
-    const size_t p = (size_t)i * P.dst.width + j;
     if (OUT == 1) {
         idx_out[p] = id;
         return;
