@@ -244,8 +244,8 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
         // (or row), 16 loads down the other direction - so that one load instruction touches few 64-byte lines
         // whatever the tile's orientation in the source; the samples are then regrouped for the 12-byte stores
         // (4 consecutive pixels x 4 rows per lane) through the wave's LDS window, which a DIRECT tile does not
-        // otherwise use (PB_DIRECT_LDS_BYTES of it).  Measured -6 % on c2.  The model is evaluated exactly as
-        // certified: collapse along v for the pixel's row, then Horner in u.
+        // otherwise use (PB_DIRECT_LDS_BYTES of it).  Measured -6 % on c2.  The model is evaluated in one of the two
+        // certified orders: row-first (collapse along v, Horner in u) or column-first.
         const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
         const bool along_x = fabsf(e->c[1][0]) <= fabsf(e->c[5][0]);  // |d row / du| <= |d row / dv|
         const int p = lane & 31, hh = lane >> 5;
@@ -256,12 +256,13 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
         const int shift = (int)rintf(slope * ((float)p - 15.5f));
         unsigned go[16];
         if (along_x) {
-            const float ux = pb_tile_coord(p);
+            // column-first evaluation (one collapse per lane instead of one per pixel; certified by pb_certify_kernel
+            // alongside the row-first order)
+            pb_f2 bcol[5];
+            pb_collapse_col(e, p, bcol);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
-                pb_f2 a[5];
-                pb_collapse_row(e, (2 * n + hh + shift) & 31, a);
-                const pb_f2 fv = pb_eval_row(a, ux);
+                const pb_f2 fv = pb_eval_row(bcol, pb_tile_coord((2 * n + hh + shift) & 31));
                 go[n] = gbase + (unsigned)(int)fv.x * rowbytes + __umul24((unsigned)(int)fv.y, 3u);
             }
         } else {
@@ -844,6 +845,15 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const Pb
                 if (lean) {
                     const pb_f2 f = pb_eval_row(R.a, pb_tile_coord(xh + k));
                     lean_ok = lean_ok && f.x >= 0.0f && f.y >= 0.0f && (int)f.x < e->win_rows && (int)f.y < e->win_cols;
+                    // plain tiles may also be evaluated column-first by the hot kernel (a DIRECT tile whose gathers run
+                    // down the columns collapses the model along u once per lane): same polynomial, another rounding
+                    // order - certified as well, a pixel either order gets wrong goes on the fix list
+                    pb_f2 bcol[5];
+                    pb_collapse_col(e, xh + k, bcol);
+                    const pb_f2 g = pb_eval_row(bcol, pb_tile_coord(y));
+                    lean_ok = lean_ok && g.x >= 0.0f && g.y >= 0.0f && (int)g.x < e->win_rows && (int)g.y < e->win_cols;
+                    const int fast_col = (e->anchor_r + (int)g.x) * P.src.width + e->anchor_c + (int)g.y;
+                    diff |= (unsigned)(fast_col != exact) << k;
                 }
             }
         }

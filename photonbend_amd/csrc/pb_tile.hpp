@@ -123,6 +123,21 @@ __device__ __forceinline__ void pb_collapse_row(const PbTileEntry* __restrict__ 
     }
 }
 
+// collapse the tile model along u for column x (0..31): 5 float2 coefficients of the column polynomial in v
+__device__ __forceinline__ void pb_collapse_col(const PbTileEntry* __restrict__ e, int x, pb_f2 b[5]) {
+    const float u = pb_tile_coord(x);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+        pb_f2 s = {e->c[m * 5 + 4][0], e->c[m * 5 + 4][1]};
+#pragma unroll
+        for (int n = 3; n >= 0; --n) {
+            const pb_f2 cn = {e->c[m * 5 + n][0], e->c[m * 5 + n][1]};
+            s = pb_fma2(s, u, cn);
+        }
+        b[m] = s;
+    }
+}
+
 __device__ __forceinline__ pb_f2 pb_eval_row(const pb_f2 a[5], float u) {
     pb_f2 f = a[4];
 #pragma unroll
