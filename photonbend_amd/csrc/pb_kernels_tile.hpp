@@ -39,14 +39,16 @@ __device__ __forceinline__ bool pb_tile_of_wave(const PbParams& P, int wave, int
     // XCD-aware order (speed only): blocks with equal id % 8 share an XCD and its L2 (observed round-robin
     // dispatch), and neighbouring tiles share source lines - so each XCD gets whole 4x4-block super-tiles
     // (256x256 px), super-tiles dealt round-robin over the XCDs to keep them balanced.
+    const bool pow2 = (gx & (gx - 1)) == 0;  // the common frame sizes: shifts instead of two integer divisions
+    const int lg = 31 - __builtin_clz((unsigned)gx);
     if ((gx & 3) == 0 && (gy & 3) == 0 && ((gx * gy) & 127) == 0) {
         const unsigned xcd = block & 7u, slot = block >> 3;
         const unsigned S = (slot >> 4) * 8u + xcd, inner = slot & 15u;   // super-tile id, block inside it
         const unsigned sgx = (unsigned)gx >> 2;
-        const unsigned sy = S / sgx, sx = S - sy * sgx;
+        const unsigned sy = pow2 ? S >> (lg - 2) : S / sgx, sx = S - sy * sgx;
         block = (sy * 4u + (inner >> 2)) * (unsigned)gx + sx * 4u + (inner & 3u);
     }
-    const int by = (int)block / gx, bx = (int)block - by * gx;
+    const int by = pow2 ? (int)(block >> lg) : (int)block / gx, bx = (int)block - by * gx;
     tx = 2 * bx + (wave & 1);
     ty = 2 * by + (wave >> 1);
     return tx < pb_tiles_x(P) && ty < pb_tiles_y(P);
@@ -482,6 +484,9 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
                                                                          const int32_t* __restrict__ fix_px,
                                                                          const int32_t* __restrict__ fix_idx) {
     const int n_frames = ONE ? 1 : n_frames_arg;
+    // every kernel argument the tile prologue needs, in one scalar round trip (the compiler would otherwise fetch
+    // the table pointer only after the tile index is known: a second dependent trip per wave)
+    asm volatile("" ::"s"(table), "s"(P.dst.width), "s"(P.dst.height), "s"(P.src.width), "s"(P.src.height), "s"(P.win_budget));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tx, ty;
