@@ -196,9 +196,6 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
                                                                             int n_frames, unsigned long long src_stride,
                                                                             unsigned long long dst_stride) {
     const int frames = ONE ? 1 : n_frames;
-    // every kernel argument the tile prologue needs, in one scalar round trip
-    asm volatile("" ::"s"(table_l), "s"(table_r), "s"(P.dst.width), "s"(P.dst.height), "s"(P.src.width), "s"(P.src.height),
-                 "s"(P.win_budget));
     PbTileCtx C;
     C.lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
