@@ -334,13 +334,15 @@ static void pb_tune_window_budget(pb_plan* pl) {
     if (!(pl->fast_ready || pl->dbl_ready)) return;
     const char* forced = getenv("PB_WIN_BUDGET");
     const size_t sb = 3ull * P.src.height * P.src.width, db = 3ull * P.dst.height * P.dst.width;
-    const bool worth = (unsigned long long)P.dst.height * P.dst.width >= (1ull << 21) && sb + db <= (3ull << 30);
+    const bool worth = (unsigned long long)P.dst.height * P.dst.width >= (1ull << 21) && sb + db <= (1ull << 30);
     if (!forced && !worth) return;
     const unsigned nt = pl->n_tiles;
     int32_t *saved_l = nullptr, *saved_r = nullptr;
     unsigned* counters = nullptr;
     uint8_t *src = nullptr, *dst = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    int n_scratch = 1, launch_no = 0;
+    size_t src_step = 0, dst_step = 0;
     const dim3 g((nt + 255) / 256), b(256);
     auto apply = [&](int budget) {
         (void)hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
@@ -361,8 +363,16 @@ static void pb_tune_window_budget(pb_plan* pl) {
             best = atoi(forced) & ~15;
             if (best < PB_DIRECT_LDS_BYTES || best > PB_WINLDS_MAX) best = PB_WINLDS_MAX;
         } else {
-            if (hipMalloc((void**)&src, sb + 16) != hipSuccess || hipMalloc((void**)&dst, db + 16) != hipSuccess) break;
-            if (hipMemsetAsync(src, 0x55, sb, 0) != hipSuccess) break;
+            // scratch frames in rotation, more than the 256 MiB Infinity Cache in total: the launches being timed
+            // must stream from HBM like real frames do, not hit a cache-resident copy
+            const size_t sb16 = (sb + 255) & ~(size_t)255, db16 = (db + 255) & ~(size_t)255;
+            n_scratch = (int)(((size_t)320 << 20) / (sb16 + db16)) + 1;
+            if (n_scratch < 2) n_scratch = 2;
+            if (n_scratch > 8) n_scratch = 8;
+            if (hipMalloc((void**)&src, n_scratch * sb16) != hipSuccess || hipMalloc((void**)&dst, n_scratch * db16) != hipSuccess) break;
+            if (hipMemsetAsync(src, 0x55, n_scratch * sb16, 0) != hipSuccess) break;
+            src_step = sb16;
+            dst_step = db16;
             if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
             const int cand[4] = {PB_WINLDS_MAX, 10224, 8176, 7168};  // 3, 4, 5 and 5 workgroups per CU (LDS-wise)
             float t_min[4] = {1e30f, 1e30f, 1e30f, 1e30f};
@@ -372,7 +382,8 @@ static void pb_tune_window_budget(pb_plan* pl) {
                     apply(cand[c]);
                     for (int rep = 0; rep < 4; ++rep) {  // the first launch after a reclassification is not counted
                         (void)hipEventRecord(e0, 0);
-                        if (pb_remap_launch(pl, src, dst, 1, 0, 0, 0) != PB_OK) { failed = true; break; }
+                        const int slot = launch_no++ % n_scratch;
+                        if (pb_remap_launch(pl, src + slot * src_step, dst + slot * dst_step, 1, 0, 0, 0) != PB_OK) { failed = true; break; }
                         (void)hipEventRecord(e1, 0);
                         if (hipEventSynchronize(e1) != hipSuccess) { failed = true; break; }
                         float ms = 0.f;
