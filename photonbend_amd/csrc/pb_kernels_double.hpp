@@ -315,7 +315,12 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
                     wl = pb_merge_factor(P, t);
                     wr = pb_merge_factor(P, (t * -1.0) + PB_PI);  // the right eye's latitude, projection.py:426-427
                 }
-                a[k] = pb_sep_blend(al[jr * 4 + k], ar[jr * 4 + k], wl, wr);
+                if (!by_row && !(WMODE == 2 && by_lat)) {  // UNIT tile: the integer sum, no float64 compare per pixel
+                    const unsigned l = al[jr * 4 + k], r = ar[jr * 4 + k];
+                    a[k] = (((l & 0x00FF00FFu) + (r & 0x00FF00FFu)) & 0x00FF00FFu) | (((l & 0x0000FF00u) + (r & 0x0000FF00u)) & 0x0000FF00u);
+                } else {
+                    a[k] = pb_sep_blend(al[jr * 4 + k], ar[jr * 4 + k], wl, wr);
+                }
             }
             const int y = C.Y0 + C.yb + 8 * jr;
             if (!inside && y >= C.H) continue;
