@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py - Mpixels/s of the fused remap on BASELINE.json's headline config.
+"""bench.py - Mpixels/s of the fused remap on BASELINE.json's configs, with the roofline of its kernel.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c1|c3|c5|c4shard|c5shard] [--batch B]
 
-A *step* is one pass of the hot path over one frame of config c2: an 8192x4096
-equirectangular panorama remapped to a 4096x4096 equidistant-360 inscribed
-fisheye (16.78 Mpx out).  Every rank owns a pool of distinct synthetic frames
-resident in HBM and cycles through them, so the timed launches stream from HBM
-rather than re-reading one frame out of the 256 MiB Infinity Cache.  Ranks are
-independent (frames shard, nothing pixel-sized crosses xGMI); the only
-collective is the RCCL broadcast of the ~200-byte parameter block from rank 0 and
-the barriers / max-reduce that bracket the timed region.  Rank 0 prints ONE JSON
-line.  `roofline` prices the remap kernel's ALGORITHMIC bytes (3 B written per
-output pixel + 3 B read per in-bounds source sample = 89 842 104 B per c2 frame,
-SURVEY 8d) against the 8 TB/s HBM3E peak, using per-launch HIP-event durations
-taken on the launch stream inside the timed region.  `cpu_baseline` times the
-NumPy oracle (the pinned restatement of the reference path) on this host.
+``--gpus N`` with N > 1 and no RANK in the environment makes this script START the N ranks itself
+(``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...``) before
+anything touches a GPU, wait for them and exit with their return code; under an external launcher it joins
+the group it is given (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  A rank count that differs from --gpus is an
+error, never a silent 1-GPU line.
+
+A *step* is one launch of the hot path (``pb_remap_u8``) over B frames (B = 1 unless --batch or a *shard*
+config says otherwise).  Configs (BASELINE.json):
+    c2       (default, the headline) one 8192x4096 equirect frame -> 4096x4096 equidistant-360 inscribed
+    c1       3072x3072 equidistant-360 fisheye -> 4096x2048 equirect
+    c3       4096x4096 equidistant-360 -> equisolid-360 with rotation (30, 45, 10) degrees
+    c5       7776x3888 double fisheye (2 x 180 degrees) -> 8192x4096 equirect stitch
+    c4shard  one GPU's share of BASELINE config 4: 64 distinct c2 frames resident, B frames per launch (default 8)
+    c5shard  one GPU's share of BASELINE config 5: 32 distinct c5 frames resident, B frames per launch (default 8)
+Every rank owns a pool of distinct synthetic frames resident in HBM and cycles through it, so the timed
+launches stream from HBM rather than re-reading one frame out of the 256 MiB Infinity Cache.  Ranks are
+independent (frames shard, nothing pixel-sized crosses xGMI); the only collective is the RCCL broadcast of the
+parameter block from rank 0 and the barriers / max-reduce that bracket the timed region.  Rank 0 prints ONE
+JSON line.
+
+``roofline`` prices the kernel's ALGORITHMIC bytes (3 B written per output pixel + 3 B read per in-bounds source
+sample; recomputed here from the plan's own index map and checked against tests/golden/full.json, which holds
+the reference's figure) against the 8 TB/s HBM3E peak, using per-launch HIP-event durations taken on the launch
+stream inside the timed region.  Next to it: ``copy_ceiling_gbs`` (a plain device copy measured in this run),
+``attainable_frac`` (algorithmic bytes / the bytes that MUST cross HBM: every 64-byte source sector that holds a
+sample + the output), p10 / p90 of the per-launch durations, ``plan_create_ms`` and ``first_frame_ms`` (the
+once-per-geometry cost that precedes the timed region).  ``cpu_baseline`` times the NumPy oracle (the pinned
+restatement of the reference path) on this host, whole path and gather-only (coordinate map cached).
 """
 
 from __future__ import annotations
@@ -26,115 +39,258 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import photonbend_amd as pb  # noqa: E402
-from photonbend_amd import _native as nat  # noqa: E402
-from photonbend_amd import parallel  # noqa: E402
-
-DST = 4096
-SRC_H, SRC_W = 4096, 8192
-MPX_PER_FRAME = DST * DST / 1e6
-ALGORITHMIC_BYTES = 89_842_104  # tests/golden/full.json c2.algorithmic_bytes (from the reference's own index map)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+# name -> geometry (degrees; magnitude as the CLI computes it), pool = frames resident per GPU,
+# pin = the entry of tests/golden/full.json that holds the reference's algorithmic bytes for the geometry
+CONFIGS = {
+    "c1": dict(dst=("pano", 2048, 4096), src=("camera", 3072, 3072, "equidistant", 360.0, 1535.5), rot=[], mask=1, pool=8, batch=1, pin="c1",
+               text="c1: one 3072x3072 equidistant-360 fisheye frame -> 4096x2048 equirectangular per step"),
+    "c2": dict(dst=("camera", 4096, 4096, "equidistant", 360.0, 2047.5), src=("pano", 4096, 8192), rot=[], mask=0, pool=6, batch=1, pin="c2",
+               text="c2: one 8192x4096 equirectangular frame -> 4096x4096 equidistant-360 inscribed per step"),
+    "c3": dict(dst=("camera", 4096, 4096, "equisolid", 360.0, 2047.5), src=("camera", 4096, 4096, "equidistant", 360.0, 2047.5),
+               rot=[(30.0, 45.0, 10.0)], mask=0, pool=8, batch=1, pin="c3",
+               text="c3: one 4096x4096 equidistant-360 frame -> equisolid-360, rotation pitch 30 yaw 45 roll 10, per step"),
+    "c5": dict(dst=("pano", 4096, 8192), src=("double", 3888, 7776, "equidistant", 180.0, None), rot=[], mask=2, pool=6, batch=1, pin="c5_180",
+               text="c5: one 7776x3888 double-fisheye (2 x 180 degrees) frame -> 8192x4096 equirectangular stitch per step"),
+}
+CONFIGS["c4shard"] = dict(CONFIGS["c2"], pool=64, batch=8,
+                          text="c4shard: one GPU's share of BASELINE config 4 - 64 distinct 8192x4096 panoramas resident, B frames per launch")
+CONFIGS["c5shard"] = dict(CONFIGS["c5"], pool=32, batch=8,
+                          text="c5shard: one GPU's share of BASELINE config 5 - 32 distinct 7776x3888 double-fisheye frames resident, B frames per launch")
+# the LDS window budget each config is benchmarked (and profiled: profiles/traffic_<config>_<budget>.json) with
+BENCH_BUDGET = {"c1": 7168, "c2": 12288, "c3": 7168, "c5": 7168, "c4shard": 12288, "c5shard": 7168}
 
-def c2_objects():
-    fov = pb.utils.to_radians(360)
-    dst = pb.CameraImage(np.zeros((DST, DST, 3), np.uint8), fov, pb.equidistant(), magnitude=DST / 2 - 0.5)
-    src = pb.PanoramaImage(np.zeros((1, 1, 3), np.uint8))
-    src_proj = nat.make_proj(nat.KIND_PANO, SRC_H, SRC_W)
-    return dst._proj(), src_proj
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
-def cpu_baseline(min_seconds: float = 12.0, max_frames: int = 40):
-    """The oracle (kind 'port') on this host's cores: full c2 frames until about
-    `min_seconds` of CPU work have been timed (a bounded sample of the workload)."""
+def self_launch(args) -> int:
+    """Start args.gpus ranks of this script (one per GPU) and return their exit code.  Runs BEFORE any GPU call
+    of this process: a process that has initialised HIP must not be replaced or forked into ranks."""
+    import torch
+
+    backend = os.environ.get("PB_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count()  # counting devices does not initialise the runtime
+    if backend == "nccl" and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible (PB_DIST_BACKEND=gloo lets ranks share a GPU for rehearsal)", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--batch", type=int, default=0, help="frames per launch (0 = the config's default)")
+    ap.add_argument("--pool", type=int, default=0, help="distinct frames resident per GPU (0 = the config's default)")
+    ap.add_argument("--budget", type=int, default=0, help="LDS window budget in bytes (0 = the value pinned for the config)")
+    ap.add_argument("--tune", action="store_true", help="let the library pick the budget by timing (opt-in; reported in plan_create_ms)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
+    ap.add_argument("--event-every", type=int, default=4, help="HIP event pairs bracket groups of this many consecutive timed launches")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the (independent) launches are dealt to round-robin")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def build_projs(cfg):
+    """pb_proj pair + rotation matrices of a config, through the host classes (so f_distance has the host's bits)."""
+    import photonbend_amd as pb
+    from photonbend_amd import _native as nat
+
+    def one(p):
+        kind, h, w = p[0], p[1], p[2]
+        img = np.zeros((h, w, 3), np.uint8)
+        if kind == "pano":
+            return pb.PanoramaImage(img)._proj()
+        lens = getattr(pb, p[3])()
+        fov = pb.utils.to_radians(p[4])
+        if kind == "camera":
+            return pb.CameraImage(img, fov, lens, magnitude=p[5])._proj()
+        return pb.DoubleCameraImage(img, fov, lens)._proj()
+
+    rots = [pb.Rotation(*map(pb.utils.to_radians, r)).rotation_matrix for r in cfg["rot"]]
+    return one(cfg["dst"]), rots, one(cfg["src"])
+
+
+def oracle_projs(cfg):
     from oracle import reference_path as orc  # CPU baseline leg only
+
+    def one(p):
+        if p[0] == "pano":
+            return orc.Proj("pano", p[1], p[2])
+        return orc.Proj(p[0], p[1], p[2], p[3], orc.to_radians(p[4]), p[5])
+
+    rots = [tuple(map(orc.to_radians, r)) for r in cfg["rot"]]
+    return one(cfg["dst"]), one(cfg["src"]), rots
+
+
+def cpu_baseline(cfg, mpx_per_frame: float, min_seconds: float = 10.0, max_frames: int = 40):
+    """The oracle (kind 'port') on this host: whole frames of the config until about `min_seconds` of CPU work
+    have been timed (a bounded sample of the workload), then the gather alone with the coordinate map cached
+    (what the GPU side amortises into its plan)."""
+    from oracle import reference_path as orc
     from oracle.synth import synth_frame
 
-    fov = orc.to_radians(360)
-    d = orc.Proj("camera", DST, DST, "equidistant", fov, DST / 2 - 0.5)
-    s = orc.Proj("pano", SRC_H, SRC_W)
-    imgs = [synth_frame(SRC_H, SRC_W, frame=f) for f in range(2)]
+    d, s, rots = oracle_projs(cfg)
+    imgs = [synth_frame(s.height, s.width, frame=f, circle_mask=cfg["mask"]) for f in range(2)]
     frames = 0
     t0 = time.perf_counter()
     while True:
-        out = orc.remap(d, s, imgs[frames % 2])
+        out = orc.remap(d, s, imgs[frames % 2], rots)
         frames += 1
         dt = time.perf_counter() - t0
         if dt >= min_seconds or frames >= max_frames:
             break
-    assert out.shape == (DST, DST, 3)
-    return {
-        "value": round(frames * MPX_PER_FRAME / dt, 3),
+    assert out.shape == (d.height, d.width, 3)
+    res = {
+        "value": round(frames * mpx_per_frame / dt, 3),
         "unit": "Mpx/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{frames} full c2 frames (8192x4096 -> 4096x4096) through oracle/reference_path.py, {dt:.1f} s; host has {os.cpu_count()} logical cores, NumPy runs this path on 1",
+        "sample": f"{frames} full frame(s) of the config through oracle/reference_path.py (coordinate map recomputed per frame, as the reference does), {dt:.1f} s; host has {os.cpu_count()} logical cores, NumPy runs this path on 1",
     }
+    # gather only: the reference's sampling stage with the coordinate map already there
+    cmap = orc.coordinate_map(d)
+    for r in rots:
+        cmap = orc.rotate_map(orc.rotation_matrix(*r), cmap)
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        orc.sample(s, imgs[n % 2], cmap.copy() if s.kind == "pano" else cmap)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= min_seconds / 2 or n >= max_frames:
+            break
+    res["map_cached"] = {"value": round(n * mpx_per_frame / dt, 3), "unit": "Mpx/s", "cores": 1,
+                         "sample": f"{n} frame(s), sampling stage only (process_coordinate_map on a precomputed float64 map), {dt:.1f} s"}
+    return res
 
 
-def _cpu_worker(frame_id: int):
+def _cpu_worker(job):
+    cfg_name, frame_id = job
     from oracle import reference_path as orc
     from oracle.synth import synth_frame
 
-    fov = orc.to_radians(360)
-    d = orc.Proj("camera", DST, DST, "equidistant", fov, DST / 2 - 0.5)
-    s = orc.Proj("pano", SRC_H, SRC_W)
-    img = synth_frame(SRC_H, SRC_W, frame=frame_id)
+    cfg = CONFIGS[cfg_name]
+    d, s, rots = oracle_projs(cfg)
+    img = synth_frame(s.height, s.width, frame=frame_id, circle_mask=cfg["mask"])
     t0 = time.perf_counter()
-    orc.remap(d, s, img)
+    orc.remap(d, s, img, rots)
     return time.perf_counter() - t0
 
 
-def cpu_baseline_all_cores(processes: int = 8):
-    """One independent oracle process per core over distinct frames, capped at
-    `processes` workers and skipped when the host lacks the memory (each worker peaks at a few GB)."""
+def cpu_baseline_all_cores(cfg_name: str, mpx_per_frame: float, processes: int = 8):
+    """One independent oracle process per core over distinct frames, capped at `processes` workers and skipped
+    when the host lacks the memory (each worker peaks at several GB)."""
     try:
         import multiprocessing as mp
 
         import psutil
 
         n = max(1, min(processes, os.cpu_count() or 1))
-        if psutil.virtual_memory().available < n * 6 * (1 << 30):
+        if psutil.virtual_memory().available < n * 8 * (1 << 30):
             return None
         ctx = mp.get_context("spawn")
         t0 = time.perf_counter()
         with ctx.Pool(n) as pool:
-            pool.map(_cpu_worker, range(100, 100 + n))
+            pool.map(_cpu_worker, [(cfg_name, 100 + i) for i in range(n)])
         dt = time.perf_counter() - t0
-        return {"value": round(n * MPX_PER_FRAME / dt, 3), "unit": "Mpx/s", "cores": n,
-                "sample": f"{n} processes x 1 full c2 frame each, {dt:.1f} s wall including process start"}
+        return {"value": round(n * mpx_per_frame / dt, 3), "unit": "Mpx/s", "cores": n,
+                "sample": f"{n} processes x 1 full frame each, {dt:.1f} s wall including process start"}
     except Exception as exc:  # the all-cores figure is optional; never fail the bench over it
         return {"error": repr(exc)}
 
 
+def byte_accounting(plan, src_hw, device):
+    """From the plan's own integer index map: algorithmic bytes per frame (3 B written per output pixel + 3 B read
+    per in-bounds sample) and the bytes that MUST cross HBM (every 64-byte source sector holding a sampled byte,
+    once, + the output)."""
+    import torch
+
+    idx = plan.index_map(device=device).reshape(-1).long()
+    valid = idx[idx >= 0]
+    h, w = src_hw
+    n_sectors = (3 * h * w + 63) // 64
+    touched = torch.zeros(n_sectors, dtype=torch.bool, device=device)
+    touched[(3 * valid) // 64] = True
+    touched[(3 * valid + 2) // 64] = True
+    out_bytes = 3 * plan.dst.height * plan.dst.width
+    return out_bytes + 3 * int(valid.numel()), out_bytes + 64 * int(touched.sum().item())
+
+
+def copy_ceiling_gbs(lib, nat, device, stream) -> float:
+    """A plain 16-byte-per-lane device copy of 512 MiB (beyond the 256 MiB Infinity Cache), read + write bytes per second."""
+    import torch
+
+    n = 512 << 20
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    a.random_(0, 255)
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    nat.check(lib.pb_event_create(ctypes.byref(e0)))
+    nat.check(lib.pb_event_create(ctypes.byref(e1)))
+    for _ in range(3):
+        nat.check(lib.pb_stream_copy(b.data_ptr(), a.data_ptr(), n, stream))
+    best = 1e30
+    ms = ctypes.c_float()
+    for _ in range(5):
+        lib.pb_event_record(e0, stream)
+        nat.check(lib.pb_stream_copy(b.data_ptr(), a.data_ptr(), n, stream))
+        lib.pb_event_record(e1, stream)
+        nat.check(lib.pb_event_sync(e1))
+        nat.check(lib.pb_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+        best = min(best, ms.value)
+    lib.pb_event_destroy(e0)
+    lib.pb_event_destroy(e1)
+    del a, b
+    return 2 * n / (best * 1e-3) / 1e9
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pool", type=int, default=6, help="distinct frames resident per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
-    ap.add_argument("--event-every", type=int, default=8, help="HIP event pairs bracket groups of this many consecutive timed launches")
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the (independent) frames are dealt to round-robin")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
+
+    from photonbend_amd import _native as nat
+    from photonbend_amd import parallel
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    cfg = CONFIGS[args.config]
+    batch = args.batch or cfg["batch"]
+    pool = args.pool or cfg["pool"]
+    pool = max(batch, (pool // batch) * batch)  # launches take `batch` consecutive frames of the pool
+    budget = args.budget or BENCH_BUDGET[args.config]
+
     # one rank per GPU; PB_DIST_BACKEND=gloo + fewer GPUs than ranks is only for rehearsing the multi-rank code
     # path on a one-GPU box (ranks then share a device and the collectives run over gloo on CPU tensors)
     backend = os.environ.get("PB_DIST_BACKEND", "nccl")
@@ -152,28 +308,35 @@ def main():
     # rank 0 owns the parameters; everyone else receives the block over RCCL
     block = None
     if rank == 0:
-        d, s = c2_objects()
-        block = parallel.pack_params(d, [], s)
+        d, rots, s = build_projs(cfg)
+        block = parallel.pack_params(d, rots, s)
     block = parallel.broadcast_params(block, device=coll_device, src=0)
     d, rots, s = parallel.unpack_params(block)
-    plan = nat.Plan(d, rots, s)
+    lib = nat.load()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    plan = nat.Plan(d, rots, s, tune=args.tune, budget=0 if args.tune else budget)
+    torch.cuda.synchronize(device)
+    plan_create_ms = (time.perf_counter() - t0) * 1e3
+    sh, sw, dh, dw = s.height, s.width, d.height, d.width
+    mpx_per_frame = dh * dw / 1e6
 
     # per-rank frame pool, generated on the device (frame ids disjoint across ranks)
-    pool = max(1, args.pool)
-    srcs = [nat.synth_frame(SRC_H, SRC_W, frame=rank * pool + f, seed=0, device=device) for f in range(pool)]
-    dsts = [torch.empty((DST, DST, 3), dtype=torch.uint8, device=device) for _ in range(pool)]
-    lib = nat.load()
+    srcs = torch.empty((pool, sh, sw, 3), dtype=torch.uint8, device=device)
+    for f in range(pool):
+        nat.synth_frame(sh, sw, frame=rank * pool + f, seed=0, circle_mask=cfg["mask"], out=srcs[f])
+    dsts = torch.empty((pool, dh, dw, 3), dtype=torch.uint8, device=device)
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
     sts = [int(x.cuda_stream) for x in streams]
-    st = sts[0]
-    sp = [t.data_ptr() for t in srcs]
-    dp = [t.data_ptr() for t in dsts]
+    sbytes, dbytes = 3 * sh * sw, 3 * dh * dw
+    sp0, dp0 = srcs.data_ptr(), dsts.data_ptr()
     h = plan.handle
+    groups_in_pool = pool // batch
 
     def step(k):
-        i = k % pool
-        rc = lib.pb_remap_u8(h, sp[i], dp[i], 1, 0, 0, sts[k % n_streams])
+        i = (k % groups_in_pool) * batch
+        rc = lib.pb_remap_u8(h, sp0 + i * sbytes, dp0 + i * dbytes, batch, sbytes, dbytes, sts[k % n_streams])
         if rc:
             nat.check(rc)
 
@@ -183,6 +346,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    step(0)
+    torch.cuda.synchronize(device)
+    first_frame_ms = (time.perf_counter() - t0) * 1e3
     for k in range(args.warmup):
         step(k)
     K = args.steps
@@ -220,31 +388,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
-    kern_ms = None
+    durs = []
     if use_events:
         ms = ctypes.c_float()
-        durs = []
         for n, (a, b) in enumerate(groups):
             nat.check(lib.pb_event_elapsed_ms(ev[2 * n], ev[2 * n + 1], ctypes.byref(ms)))
             durs.append(ms.value / (b - a))
         for e in ev:
             lib.pb_event_destroy(e)
-        kern_ms = float(np.mean(durs))
-        kern_med = float(np.median(durs))
 
     if rank == 0:
-        value = world * K * MPX_PER_FRAME / dt_max
-        per_launch_s = (kern_ms / 1e3) if kern_ms else dt_max / K
-        achieved = ALGORITHMIC_BYTES / per_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        frames_total = world * K * batch
+        value = frames_total * mpx_per_frame / dt_max
+        launch_ms = float(np.mean(durs)) if durs else dt_max / K * 1e3
+        alg_frame, must_frame = byte_accounting(plan, (sh, sw), device)
+        pins = json.load(open(os.path.join(ROOT, "tests", "golden", "full.json")))
+        ref_alg = int(pins[cfg["pin"]]["algorithmic_bytes"])
+        if alg_frame != ref_alg:
+            raise SystemExit(f"bench.py: algorithmic bytes from the plan's index map ({alg_frame}) differ from the reference's ({ref_alg})")
+        alg_launch = alg_frame * batch
+        achieved = alg_launch / (launch_ms * 1e-3) / 1e9
+        ceiling = copy_ceiling_gbs(lib, nat, device, sts[0])
+        info = plan.info()
+        traffic = traffic_src = None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}_{info['window_budget']}.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_src = os.path.relpath(tpath, ROOT)
             except Exception:
                 traffic = None
         line = {
-            "metric": "Mpixels/s remapped, 8K equirect->equidistant",
+            "metric": "Mpixels/s remapped, 8K equirect->equidistant" if cfg["pin"] == "c2" else f"Mpixels/s remapped ({args.config})",
             "value": round(value, 1),
             "unit": "Mpx/s",
             "n_gpus": world,
@@ -254,15 +429,20 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (per-tile coordinate models, u8 samples; float64 only at plan creation)",
+            "dtype": "f32 (per-tile coordinate models certified against the float64 chain at plan creation; u8 samples)",
             "data": "synthetic",
             "config": {
-                "workload": "c2: one 8192x4096 equirectangular frame -> 4096x4096 equidistant-360 inscribed per step",
+                "workload": cfg["text"],
+                "name": args.config,
+                "frames_per_launch": batch,
                 "frames_resident_per_gpu": pool,
                 "streams": n_streams,
                 "sampling": "nearest (truncating), the reference's",
                 "parallelism": f"frames sharded over {world} GPU(s); RCCL broadcast of the parameter block only",
             },
+            "plan_create_ms": round(plan_create_ms, 3),
+            "plan_timing": {k: round(v, 3) for k, v in plan.timing().items()},
+            "first_frame_ms": round(first_frame_ms, 3),
             "roofline": {
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
@@ -270,16 +450,26 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "algorithmic_bytes_per_launch": ALGORITHMIC_BYTES,
-                "kernel_ms_mean": round(kern_ms, 5) if kern_ms else None,
-                "kernel_ms_median": round(kern_med, 5) if kern_ms else None,
-                "timing": f"hipEvent pairs around groups of {every} consecutive timed launches on the launch stream ({len(groups)} groups; duration = group time / group size; one pb_remap_u8 call = hot kernel incl. its fix work)" if use_events else "wall / steps",
-                "plan": plan.info(),
+                "traffic_source": traffic_src,
+                "copy_ceiling_gbs": round(ceiling, 1),
+                "frac_of_copy_ceiling": round(achieved / ceiling, 4),
+                "algorithmic_bytes_per_launch": alg_launch,
+                "must_move_bytes_per_launch": must_frame * batch,
+                "attainable_frac": round(alg_frame / must_frame, 4),
+                "attainable_frac_at_copy_ceiling": round(alg_frame / must_frame * ceiling / HBM_PEAK_GBS, 4),
+                "kernel_ms_mean": round(launch_ms, 5),
+                "kernel_ms_median": round(float(np.median(durs)), 5) if durs else None,
+                "kernel_ms_p10": round(float(np.percentile(durs, 10)), 5) if durs else None,
+                "kernel_ms_p90": round(float(np.percentile(durs, 90)), 5) if durs else None,
+                "kernel_ms_per_frame": round(launch_ms / batch, 5),
+                "timing": f"hipEvent pairs around groups of {every} consecutive timed launches on the launch stream ({len(groups)} groups; duration = group time / group size; one pb_remap_u8 call = ONE kernel launch incl. its fix work)" if durs else "wall / steps",
+                "window_budget": info["window_budget"],
+                "plan": info,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-            extra = cpu_baseline_all_cores()
+            line["cpu_baseline"] = cpu_baseline(cfg, mpx_per_frame)
+            extra = cpu_baseline_all_cores(args.config, mpx_per_frame)
             if extra:
                 line["cpu_baseline"]["all_cores"] = extra
         print(json.dumps(line), flush=True)

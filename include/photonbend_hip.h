@@ -36,7 +36,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define PB_ABI_VERSION 1
+#define PB_ABI_VERSION 2
 #define PB_MAX_ROTATIONS 8
 
 typedef enum pb_status {
@@ -98,6 +98,33 @@ int pb_device_name(char* buf, size_t buflen);
  * until pb_plan_destroy. */
 int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, pb_plan** out);
 void pb_plan_destroy(pb_plan* plan);
+
+/* Explicit form of pb_plan_create (which is pb_plan_create_ex(..., 0, 0, out)).
+ *   flags       PB_PLAN_DEFER  no device work at creation: the plan is a parameter block and its launches run the
+ *                              faithful float64 kernel (the cheapest way to remap ONE image of a geometry, the
+ *                              reference CLI's case) until pb_plan_prepare builds the fast path;
+ *               PB_PLAN_TUNE   after preparation, pick the LDS window budget by timing four candidates on scratch
+ *                              frames (allocates frame-sized scratch, tens of frames' worth of GPU time; opt-in).
+ *   win_budget  bytes of LDS window per wave for the hot kernels (multiple of 16 in [4224, 12288]; clamped);
+ *               0 = the library default (8176).  It decides which PATH a tile takes, never its pixels.
+ * Creation never times anything or allocates frame-sized memory unless PB_PLAN_TUNE is given. */
+#define PB_PLAN_DEFER 1u
+#define PB_PLAN_TUNE 2u
+int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, unsigned flags,
+                      int win_budget, pb_plan** out);
+/* Builds the fast path of a deferred plan on the current device (flags: 0 or PB_PLAN_TUNE).  On a prepared plan
+ * it only applies win_budget (when > 0).  Synchronous. */
+int pb_plan_prepare(pb_plan* plan, unsigned flags, int win_budget);
+/* Re-classifies the tiles of a prepared plan under another window budget (synchronous, cheap: one small kernel). */
+int pb_plan_set_window_budget(pb_plan* plan, int win_budget);
+/* Host wall time (ms) of the device preparation and of the optional tuning; either pointer may be NULL. */
+int pb_plan_timing(const pb_plan* plan, double* prepare_ms, double* tune_ms);
+/* A prepared plan as a host blob and back, so that a process (the CLI's one-image case) need not pay the
+ * per-pixel certification again for a geometry it has seen: pass buf = NULL to query the size.  The blob is
+ * valid for this library build only (checked) and carries a checksum; deserialisation uploads the tables to
+ * the CURRENT device. */
+int pb_plan_serialize(const pb_plan* plan, void* buf, size_t capacity, size_t* size_out);
+int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out);
 /* Execution mode of a plan.  AUTO (default) and FAST: ONE launch of the hot kernel per call (per-tile
  * float32 polynomial models of the coordinate field; what the models miss is looked up in the plan's
  * exact tables), when the plan was prepared on a device; otherwise, and under FAITHFUL, the per-pixel
@@ -119,8 +146,8 @@ int pb_plan_set_mode(pb_plan* plan, int mode);
 int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats7, long long* thresholds4);
 int pb_plan_dst_shape(const pb_plan* plan, int* height, int* width);
 int pb_plan_src_shape(const pb_plan* plan, int* height, int* width);
-/* bytes of LDS window per wave the plan's hot launches use: picked per plan at creation by timing the
- * candidates on scratch frames (it decides which path a tile takes, never its pixels); 0 without device state */
+/* bytes of LDS window per wave the plan's hot launches use (it decides which path a tile takes, never its
+ * pixels); 0 without device state */
 int pb_plan_window_budget(const pb_plan* plan);
 
 /* Remap n_frames frames that share the plan's geometry.  Frame f is read at
@@ -182,6 +209,9 @@ int pb_event_destroy(void* event);
 int pb_event_record(void* event, void* stream);
 int pb_event_sync(void* event);
 int pb_event_elapsed_ms(void* start, void* stop, float* ms);
+/* measurement utility: a plain 16-byte-per-lane device copy (pointers and size multiples of 16) - the practical
+ * HBM ceiling bench.py reports next to the remap kernel */
+int pb_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

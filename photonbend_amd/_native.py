@@ -18,7 +18,9 @@ import torch  # noqa: F401  (must precede the CDLL below - see module docstring)
 
 from .build import LIB_PATH
 
+ABI_VERSION = 2
 PB_MAX_ROTATIONS = 8
+PLAN_DEFER, PLAN_TUNE = 1, 2
 MODE_AUTO, MODE_FAITHFUL, MODE_FAST, MODE_FAST_DIRECT = 0, 1, 2, 3
 KIND_CAMERA, KIND_DOUBLE, KIND_PANO = 0, 1, 2
 LENS_IDS = {
@@ -59,6 +61,12 @@ SIGNATURES = {
     "pb_shutdown": (C.c_int, []),
     "pb_device_name": (C.c_int, [C.c_char_p, C.c_size_t]),
     "pb_plan_create": (C.c_int, [C.POINTER(pb_proj), C.POINTER(C.c_double), C.c_int, C.POINTER(pb_proj), C.POINTER(_VP)]),
+    "pb_plan_create_ex": (C.c_int, [C.POINTER(pb_proj), C.POINTER(C.c_double), C.c_int, C.POINTER(pb_proj), C.c_uint, C.c_int, C.POINTER(_VP)]),
+    "pb_plan_prepare": (C.c_int, [_VP, C.c_uint, C.c_int]),
+    "pb_plan_set_window_budget": (C.c_int, [_VP, C.c_int]),
+    "pb_plan_timing": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pb_plan_serialize": (C.c_int, [_VP, _VP, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pb_plan_deserialize": (C.c_int, [_VP, C.c_size_t, C.POINTER(_VP)]),
     "pb_plan_destroy": (None, [_VP]),
     "pb_plan_set_mode": (C.c_int, [_VP, C.c_int]),
     "pb_plan_info": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
@@ -86,6 +94,7 @@ SIGNATURES = {
     "pb_event_record": (C.c_int, [_VP, _VP]),
     "pb_event_sync": (C.c_int, [_VP]),
     "pb_event_elapsed_ms": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
+    "pb_stream_copy": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
 }
 
 _lib = None
@@ -110,8 +119,8 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if lib.pb_abi_version() != 1:
-            raise PbError(f"ABI version mismatch: library says {lib.pb_abi_version()}, binding expects 1")
+        if lib.pb_abi_version() != ABI_VERSION:
+            raise PbError(f"ABI version mismatch: library says {lib.pb_abi_version()}, binding expects {ABI_VERSION}")
         _lib = lib
     return _lib
 
@@ -134,16 +143,62 @@ def require_gpu() -> None:
 class Plan:
     """Owner of one pb_plan (dst projection, rotations, src projection)."""
 
-    def __init__(self, dst: pb_proj, rotations, src: pb_proj):
+    def __init__(self, dst: pb_proj, rotations, src: pb_proj, *, defer: bool = False, tune: bool = False, budget: int = 0):
+        """``defer``: no device work now - launches run the faithful kernel until ``prepare()``;
+        ``tune``: pick the LDS window budget by timing (opt-in, allocates scratch frames);
+        ``budget``: explicit window budget in bytes (0 = library default)."""
         lib = load()
         rots = np.ascontiguousarray(np.asarray(list(rotations), dtype=np.float64).reshape(-1, 9))
         if rots.shape[0] > PB_MAX_ROTATIONS:
             raise PbError(f"at most {PB_MAX_ROTATIONS} chained rotations are supported")
         self._h = _VP()
         rp = rots.ctypes.data_as(C.POINTER(C.c_double)) if rots.shape[0] else None
-        check(lib.pb_plan_create(C.byref(dst), rp, rots.shape[0], C.byref(src), C.byref(self._h)))
+        flags = (PLAN_DEFER if defer else 0) | (PLAN_TUNE if tune else 0)
+        check(lib.pb_plan_create_ex(C.byref(dst), rp, rots.shape[0], C.byref(src), flags, int(budget), C.byref(self._h)))
         self.dst, self.src, self.n_rot = dst, src, rots.shape[0]
         self.double_src = src.kind == KIND_DOUBLE
+
+    @classmethod
+    def _adopt(cls, handle, dst: pb_proj, src: pb_proj, n_rot: int) -> "Plan":
+        self = cls.__new__(cls)
+        self._h = handle
+        self.dst, self.src, self.n_rot = dst, src, n_rot
+        self.double_src = src.kind == KIND_DOUBLE
+        return self
+
+    def prepare(self, tune: bool = False, budget: int = 0) -> None:
+        """Builds the fast path of a deferred plan on the current device (or re-applies ``budget``)."""
+        check(load().pb_plan_prepare(self._h, PLAN_TUNE if tune else 0, int(budget)))
+
+    def set_window_budget(self, budget: int) -> None:
+        check(load().pb_plan_set_window_budget(self._h, int(budget)))
+
+    def timing(self) -> dict:
+        a, b = C.c_double(), C.c_double()
+        check(load().pb_plan_timing(self._h, C.byref(a), C.byref(b)))
+        return {"prepare_ms": a.value, "tune_ms": b.value}
+
+    def serialize(self) -> bytes:
+        """The prepared plan as a blob (``Plan.deserialize`` restores it without re-certifying)."""
+        n = C.c_size_t()
+        check(load().pb_plan_serialize(self._h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        check(load().pb_plan_serialize(self._h, buf, n.value, C.byref(n)))
+        return buf.raw[: n.value]
+
+    @classmethod
+    def deserialize(cls, blob: bytes, dst: pb_proj, src: pb_proj, n_rot: int) -> "Plan":
+        h = _VP()
+        raw = bytes(blob)
+        check(load().pb_plan_deserialize(raw, len(raw), C.byref(h)))
+        plan = cls._adopt(h, dst, src, n_rot)
+        hh, ww = C.c_int(), C.c_int()
+        check(load().pb_plan_dst_shape(h, C.byref(hh), C.byref(ww)))
+        sh, sw = C.c_int(), C.c_int()
+        check(load().pb_plan_src_shape(h, C.byref(sh), C.byref(sw)))
+        if (hh.value, ww.value, sh.value, sw.value) != (dst.height, dst.width, src.height, src.width):
+            raise PbError("the serialized plan belongs to another geometry")
+        return plan
 
     @property
     def handle(self):
@@ -196,6 +251,8 @@ class Plan:
             o = out if out.dim() == 4 else out.unsqueeze(0)
             if o.dtype != torch.uint8 or not o.is_contiguous() or tuple(o.shape) != (n, self.dst.height, self.dst.width, 3):
                 raise PbError("out must be a contiguous uint8 cuda tensor of the destination shape")
+            if not o.is_cuda or o.device != s.device:
+                raise PbError(f"out must live on the source's device ({s.device}), got {o.device}")
         fn = load().pb_remap_u8 if interpolation == "nearest" else load().pb_remap_bilinear_u8
         with torch.cuda.device(s.device):
             check(fn(self._h, s.data_ptr(), o.data_ptr(), n, 0, 0, current_stream()))

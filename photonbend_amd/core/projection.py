@@ -17,7 +17,12 @@ stays on the device and yields a CUDA tensor.
 
 from __future__ import annotations
 
+import contextlib
+import hashlib
+import os
+import threading
 from abc import abstractmethod
+from collections import OrderedDict
 from typing import Protocol, Union
 
 import numpy as np
@@ -29,18 +34,77 @@ from .. import _native as nat
 from ._coordmap import CoordinateMap
 from .lens import Lens, lens_id
 
-_PLAN_CACHE: dict = {}
+_PLAN_CACHE: "OrderedDict" = OrderedDict()  # key -> [plan, uses]; least recently used first
 _PLAN_CACHE_MAX = 64
+_PLAN_LOCK = threading.RLock()
 
 
-def _plan_for(dst: nat.pb_proj, rotations, src: nat.pb_proj) -> nat.Plan:
-    key = (dst.key(), tuple(np.asarray(r, dtype=np.float64).tobytes() for r in rotations), src.key())
-    plan = _PLAN_CACHE.get(key)
-    if plan is None:
-        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
-            _PLAN_CACHE.clear()
-        plan = _PLAN_CACHE[key] = nat.Plan(dst, rotations, src)
+def _plan_key(dst: nat.pb_proj, rotations, src: nat.pb_proj, dev_index: int):
+    return (dev_index, dst.key(), tuple(np.asarray(r, dtype=np.float64).tobytes() for r in rotations), src.key())
+
+
+def _disk_cache_path(key) -> Union[str, None]:
+    """Opt-in persistence of prepared plans (PB_PLAN_CACHE_DIR): a process that has seen a geometry before - the
+    CLI run again on another image - uploads the certified tables instead of rebuilding them."""
+    root = os.environ.get("PB_PLAN_CACHE_DIR")
+    if not root:
+        return None
+    lib_stamp = str(os.path.getmtime(nat.LIB_PATH)) if os.path.exists(nat.LIB_PATH) else "?"
+    digest = hashlib.sha256(repr((key[1:], lib_stamp, nat.ABI_VERSION)).encode()).hexdigest()[:32]
+    return os.path.join(root, f"plan_{digest}.pbplan")
+
+
+def _prepare(plan: nat.Plan, key) -> nat.Plan:
+    """Fast path for `plan` (a deferred plan): from the disk cache when there is one, else built and certified now."""
+    path = _disk_cache_path(key)
+    if path and os.path.exists(path):
+        try:
+            with open(path, "rb") as f:
+                return nat.Plan.deserialize(f.read(), plan.dst, plan.src, plan.n_rot)
+        except (OSError, nat.PbError):
+            pass  # stale or foreign blob: rebuild
+    plan.prepare()
+    if path:
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                f.write(plan.serialize())
+            os.replace(tmp, path)
+        except (OSError, nat.PbError):
+            pass
     return plan
+
+
+def _plan_for(dst: nat.pb_proj, rotations, src: nat.pb_proj, device=None, eager: bool = True) -> nat.Plan:
+    """The cached plan of a geometry on `device` (default: the current device).
+
+    eager=True returns a PREPARED plan (per-tile models built and certified: tens of frames' worth of GPU time,
+    once).  eager=False is what the one-image facade calls use: the FIRST remap of a geometry runs the faithful
+    kernel from a deferred plan (no preparation at all - the reference CLI's case costs one faithful launch), the
+    second use of the same geometry prepares the fast path.  PB_PLAN_EAGER=1 makes every use eager."""
+    rotations = list(rotations)
+    if len(rotations) > nat.PB_MAX_ROTATIONS:
+        raise nat.PbError(f"at most {nat.PB_MAX_ROTATIONS} rotations fit one fused plan")
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    dev_index = dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    eager = eager or os.environ.get("PB_PLAN_EAGER") == "1"
+    key = _plan_key(dst, rotations, src, dev_index)
+    with _PLAN_LOCK:
+        entry = _PLAN_CACHE.get(key)
+        ctx = torch.cuda.device(dev_index) if torch.cuda.is_available() else contextlib.nullcontext()
+        with ctx:
+            if entry is None:
+                plan = nat.Plan(dst, rotations, src, defer=True)
+                entry = _PLAN_CACHE[key] = [plan, 0, False]
+                while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
+                    _PLAN_CACHE.popitem(last=False)  # evict ONE entry, the least recently used
+            entry[1] += 1
+            if not entry[2] and (eager or entry[1] >= 2) and torch.cuda.is_available():
+                entry[0] = _prepare(entry[0], key)
+                entry[2] = True
+        _PLAN_CACHE.move_to_end(key)
+        return entry[0]
 
 
 def _shape_hw(image) -> tuple:
@@ -50,31 +114,43 @@ def _shape_hw(image) -> tuple:
     return int(shp[0]), int(shp[1])
 
 
-_PINNED: dict = {}
+# page-locked staging buffers: per THREAD (two threads remapping at once never share one) and guarded by the event
+# of the last asynchronous copy that used them (a transfer still in flight on any stream is waited for before reuse)
+_TLS = threading.local()
+_PINNED_MAX = 4
 
 
-def _pinned(shape, dtype, slot: str) -> torch.Tensor:
-    """A cached page-locked staging buffer (pageable copies run at a fraction of PCIe speed)."""
+def _pinned(shape, dtype, slot: str):
+    """-> [buffer, event of its last async use or None]"""
+    cache = getattr(_TLS, "pinned", None)
+    if cache is None:
+        cache = _TLS.pinned = OrderedDict()
     key = (tuple(shape), dtype, slot)
-    buf = _PINNED.get(key)
-    if buf is None:
-        if len(_PINNED) >= 8:
-            _PINNED.clear()
-        buf = _PINNED[key] = torch.empty(tuple(shape), dtype=dtype).pin_memory()
-    return buf
+    entry = cache.get(key)
+    if entry is None:
+        while len(cache) >= _PINNED_MAX:
+            cache.popitem(last=False)
+        entry = cache[key] = [torch.empty(tuple(shape), dtype=dtype).pin_memory(), None]
+    cache.move_to_end(key)
+    if entry[1] is not None:
+        entry[1].synchronize()
+        entry[1] = None
+    return entry
 
 
 def _to_host(t: torch.Tensor) -> np.ndarray:
     """Device tensor -> fresh ndarray (the reference returns freshly allocated arrays) via pinned staging,
     in row chunks: a chunk is copied out of the staging buffer (a few threads) while the next crosses PCIe."""
-    stage = _pinned(t.shape, t.dtype, "d2h")
+    entry = _pinned(t.shape, t.dtype, "d2h")
+    stage = entry[0]
     chunks = row_chunks(t.shape[0], t.numel() * t.element_size()) if t.dim() >= 2 else [(0, t.shape[0])]
     events = []
-    for a, b in chunks:
-        stage[a:b].copy_(t[a:b], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        events.append(ev)
+    with torch.cuda.device(t.device):
+        for a, b in chunks:
+            stage[a:b].copy_(t[a:b], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            events.append(ev)
     out = np.empty(tuple(t.shape), stage.numpy().dtype)
     sn = stage.numpy()
     for (a, b), ev in zip(chunks, events):
@@ -83,21 +159,27 @@ def _to_host(t: torch.Tensor) -> np.ndarray:
     return out
 
 
-def _upload(a: np.ndarray) -> torch.Tensor:
-    """uint8 ndarray -> CUDA tensor via pinned staging, in row chunks (copy of chunk k overlaps the PCIe
-    transfer of chunk k - 1)."""
-    stage = _pinned(a.shape, torch.uint8, "h2d")
-    torch.cuda.current_stream().synchronize()  # the staging buffer may still feed an earlier transfer
-    dev = torch.empty(tuple(a.shape), dtype=torch.uint8, device="cuda")
-    sn = stage.numpy()
-    for lo, hi in row_chunks(a.shape[0], a.nbytes):
-        par_copy(sn[lo:hi], a[lo:hi])
-        dev[lo:hi].copy_(stage[lo:hi], non_blocking=True)
-    return dev
+def _upload(a: np.ndarray, device=None) -> torch.Tensor:
+    """ndarray -> CUDA tensor on `device` (default: current) via pinned staging, in row chunks (the host copy of
+    chunk k overlaps the PCIe transfer of chunk k - 1)."""
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    tdtype = torch.from_numpy(np.empty(0, a.dtype)).dtype
+    entry = _pinned(a.shape, tdtype, "h2d")
+    stage = entry[0]
+    with torch.cuda.device(dev):
+        out = torch.empty(tuple(a.shape), dtype=tdtype, device=dev)
+        sn = stage.numpy()
+        for lo, hi in row_chunks(a.shape[0], a.nbytes):
+            par_copy(sn[lo:hi], a[lo:hi])
+            out[lo:hi].copy_(stage[lo:hi], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        entry[1] = ev
+    return out
 
 
 def _device_image(image, height: int, width: int) -> torch.Tensor:
-    """uint8 CUDA tensor (h, w, 3) of the pixels behind ``.image``."""
+    """uint8 CUDA tensor (h, w, 3) of the pixels behind ``.image`` (a tensor stays on ITS device)."""
     nat.require_gpu()
     if isinstance(image, torch.Tensor):
         t = image
@@ -115,6 +197,16 @@ def _device_image(image, height: int, width: int) -> torch.Tensor:
     if tuple(t.shape) != (height, width, 3):
         raise ValueError(f"image must have shape ({height}, {width}, 3), got {tuple(t.shape)}")
     return t.contiguous()
+
+
+def _check_map_tensor(cmap: torch.Tensor, device=None) -> None:
+    """A tensor coordinate map must be what the kernels index: contiguous float64 (H, W, 3) on the image's device."""
+    if not (cmap.is_cuda and cmap.dtype == torch.float64 and cmap.is_contiguous()):
+        raise TypeError("tensor coordinate maps must be contiguous float64 CUDA tensors")
+    if cmap.dim() != 3 or cmap.shape[2] != 3:
+        raise ValueError(f"a coordinate map has shape (H, W, 3), got {tuple(cmap.shape)}")
+    if device is not None and cmap.device != device:
+        raise ValueError(f"coordinate map on {cmap.device} but the image on {device}")
 
 
 class ProjectionImage(Protocol):
@@ -158,20 +250,20 @@ class _GpuProjection:
         on_device = isinstance(self.image, torch.Tensor)
         img = _device_image(self.image, src.height, src.width)
         if isinstance(coordinate_map, CoordinateMap) and coordinate_map.is_lazy:
-            plan = _plan_for(coordinate_map.dst_proj, coordinate_map.rotations, src)
+            # bilinear taps come from the tile models: that mode needs the prepared plan from the first use on
+            plan = _plan_for(coordinate_map.dst_proj, coordinate_map.rotations, src, device=img.device, eager=interpolation != "nearest")
             out = plan.remap(img, interpolation=interpolation)
             if src.kind == nat.KIND_PANO:
                 coordinate_map.note_invalid_zeroed()  # projection.py:534-536
             return out if on_device else _to_host(out)
         if isinstance(coordinate_map, torch.Tensor):
-            if not (coordinate_map.is_cuda and coordinate_map.dtype == torch.float64 and coordinate_map.is_contiguous()):
-                raise TypeError("tensor coordinate maps must be contiguous float64 CUDA tensors")
+            _check_map_tensor(coordinate_map, img.device)
             out = nat.sample_map(src, coordinate_map, img)
             return out if on_device else _to_host(out)
         host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
         if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
             raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
-        dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+        dev = torch.from_numpy(np.ascontiguousarray(host)).to(img.device)
         out = nat.sample_map(src, dev, img)
         if src.kind == nat.KIND_PANO:
             host[...] = dev.cpu().numpy()  # the in-place zeroing of invalid pixels
@@ -254,8 +346,7 @@ def map_projection(coordinate_map):
     red (stretched over the valid pixels), longitude in green, the invalid flag in blue.  Runs on the GPU
     (pb_map_projection_u8); like the reference it zeroes lat/lon of invalid pixels in the map it is given."""
     if isinstance(coordinate_map, torch.Tensor):
-        if not (coordinate_map.is_cuda and coordinate_map.dtype == torch.float64 and coordinate_map.is_contiguous()):
-            raise TypeError("tensor coordinate maps must be contiguous float64 CUDA tensors")
+        _check_map_tensor(coordinate_map)
         return nat.map_projection(coordinate_map)
     host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
     if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):

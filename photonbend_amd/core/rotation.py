@@ -40,6 +40,8 @@ class Rotation:
         if isinstance(coordinate_map, torch.Tensor):
             if not (coordinate_map.is_cuda and coordinate_map.dtype == torch.float64 and coordinate_map.is_contiguous()):
                 raise TypeError("tensor coordinate maps must be contiguous float64 CUDA tensors")
+            if coordinate_map.dim() != 3 or coordinate_map.shape[2] != 3:
+                raise ValueError(f"a coordinate map has shape (H, W, 3), got {tuple(coordinate_map.shape)}")
             return nat.rotate(self.rotation_matrix, coordinate_map)
         host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
         if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):

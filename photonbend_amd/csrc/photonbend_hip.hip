@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <new>
 #include <string>
 
@@ -49,6 +50,11 @@ struct pb_plan {
     PbDoubleFix* dbl_px_fix = nullptr;
     double* lat_tab = nullptr;   // faithful latitudes of the pixels of merge-band tiles (PB_TILE_W_LAT), 8 KiB per tile
     unsigned n_row_weight_tiles = 0, n_lat_tiles = 0;
+    // the tile flags as classified and certified with the largest window budget: pb_apply_budget derives the flags
+    // in use from them, so the budget can be changed at any time without touching a pixel
+    int32_t* saved_l = nullptr;
+    int32_t* saved_r = nullptr;
+    double prepare_ms = 0.0, tune_ms = 0.0;  // host wall time of the device preparation / of the optional budget tuning
 };
 
 static thread_local std::string g_err;
@@ -324,92 +330,135 @@ static void pb_launch_faithful_remap(const PbParams& P, const uint8_t* src, uint
 static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames, size_t src_frame_stride,
                            size_t dst_frame_stride, hipStream_t st);
 
-// Picks the plan's LDS window budget by measurement: smaller windows let more workgroups share a CU (the hot
+// The LDS window budget of a plan (bytes per wave).  Smaller windows let more workgroups share a CU (the hot
 // kernels are latency x concurrency bound) but push tiles with larger windows onto the direct-gather path; which
-// side wins depends on the geometry (c2 is fastest with 12 KiB windows, c1 / c3 / c5 with 7-8 KiB).  The
-// classification only decides the PATH a tile takes, never its pixels, so the choice cannot change a byte.
-// Four candidate budgets x a few launches on scratch frames, once per plan; small outputs are not worth it.
-static void pb_tune_window_budget(pb_plan* pl) {
+// side wins depends on the geometry.  The classification only decides the PATH a tile takes, never its pixels
+// (same model, same anchors, same tables), so a budget change cannot change a byte.
+#define PB_DEFAULT_WIN_BUDGET 8176  // 5 workgroups per CU; c1 / c3 / c5 measured fastest at 7-8 KiB, c2 within 4 % of its best
+static int pb_clamp_budget(int budget) {
+    budget &= ~15;
+    if (budget < PB_DIRECT_LDS_BYTES) budget = PB_DIRECT_LDS_BYTES;
+    if (budget > PB_WINLDS_MAX) budget = PB_WINLDS_MAX;
+    return budget;
+}
+
+// keeps the certified flags (once) and applies `budget` to them; synchronous on the default stream
+static int pb_apply_budget(pb_plan* pl, int budget) {
     PbParams& P = pl->P;
-    if (!(pl->fast_ready || pl->dbl_ready)) return;
-    const char* forced = getenv("PB_WIN_BUDGET");
-    const size_t sb = 3ull * P.src.height * P.src.width, db = 3ull * P.dst.height * P.dst.width;
-    const bool worth = (unsigned long long)P.dst.height * P.dst.width >= (1ull << 21) && sb + db <= (1ull << 30);
-    if (!forced && !worth) return;
+    if (!(pl->fast_ready || pl->dbl_ready)) return PB_OK;
     const unsigned nt = pl->n_tiles;
-    int32_t *saved_l = nullptr, *saved_r = nullptr;
+    const dim3 g((nt + 255) / 256), b(256);
+    if (!pl->saved_l) {
+        PB_HIP(hipMalloc((void**)&pl->saved_l, (size_t)nt * sizeof(int32_t)));
+        hipLaunchKernelGGL(pb_save_flags_kernel, g, b, 0, 0, pl->table, pl->saved_l, nt);
+        if (pl->dbl_ready) {
+            PB_HIP(hipMalloc((void**)&pl->saved_r, (size_t)nt * sizeof(int32_t)));
+            hipLaunchKernelGGL(pb_save_flags_kernel, g, b, 0, 0, pl->table_r, pl->saved_r, nt);
+        }
+    }
     unsigned* counters = nullptr;
+    PB_HIP(hipMalloc((void**)&counters, 2 * sizeof(unsigned)));
+    (void)hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
+    budget = pb_clamp_budget(budget);
+    if (pl->dbl_ready)
+        hipLaunchKernelGGL(pb_budget_double_kernel, g, b, 0, 0, pl->table, pl->table_r, pl->saved_l, pl->saved_r, nt, budget, counters);
+    else
+        hipLaunchKernelGGL(pb_budget_kernel, g, b, 0, 0, pl->table, pl->saved_l, nt, budget, counters);
+    P.win_budget = budget;
+    unsigned res[2] = {0, 0};
+    const hipError_t e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
+    (void)hipFree(counters);
+    PB_HIP(e);
+    pl->n_lean_tiles = res[0];
+    pl->n_direct_tiles = res[1];
+    return PB_OK;
+}
+
+// OPT-IN (PB_PLAN_TUNE): picks the budget by measurement - four candidates x a few launches on scratch frames
+// (allocates and fills frame-sized scratch; tens of frames' worth of GPU time).  Returns the winner.
+static int pb_tune_window_budget(pb_plan* pl) {
+    PbParams& P = pl->P;
+    int best = P.win_budget;
+    if (!(pl->fast_ready || pl->dbl_ready)) return best;
+    const size_t sb = 3ull * P.src.height * P.src.width, db = 3ull * P.dst.height * P.dst.width;
+    if (sb + db > (1ull << 30)) return best;
     uint8_t *src = nullptr, *dst = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    int n_scratch = 1, launch_no = 0;
-    size_t src_step = 0, dst_step = 0;
-    const dim3 g((nt + 255) / 256), b(256);
-    auto apply = [&](int budget) {
-        (void)hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
-        if (pl->dbl_ready)
-            hipLaunchKernelGGL(pb_budget_double_kernel, g, b, 0, 0, pl->table, pl->table_r, saved_l, saved_r, nt, budget, counters);
-        else
-            hipLaunchKernelGGL(pb_budget_kernel, g, b, 0, 0, pl->table, saved_l, nt, budget, counters);
-        P.win_budget = budget;
-    };
     do {
-        if (hipMalloc((void**)&saved_l, (size_t)nt * sizeof(int32_t)) != hipSuccess) break;
-        if (pl->dbl_ready && hipMalloc((void**)&saved_r, (size_t)nt * sizeof(int32_t)) != hipSuccess) break;
-        if (hipMalloc((void**)&counters, 2 * sizeof(unsigned)) != hipSuccess) break;
-        hipLaunchKernelGGL(pb_save_flags_kernel, g, b, 0, 0, pl->table, saved_l, nt);
-        if (pl->dbl_ready) hipLaunchKernelGGL(pb_save_flags_kernel, g, b, 0, 0, pl->table_r, saved_r, nt);
-        int best = PB_WINLDS_MAX;
-        if (forced) {
-            best = atoi(forced) & ~15;
-            if (best < PB_DIRECT_LDS_BYTES || best > PB_WINLDS_MAX) best = PB_WINLDS_MAX;
-        } else {
-            // scratch frames in rotation, more than the 256 MiB Infinity Cache in total: the launches being timed
-            // must stream from HBM like real frames do, not hit a cache-resident copy
-            const size_t sb16 = (sb + 255) & ~(size_t)255, db16 = (db + 255) & ~(size_t)255;
-            n_scratch = (int)(((size_t)320 << 20) / (sb16 + db16)) + 1;
-            if (n_scratch < 2) n_scratch = 2;
-            if (n_scratch > 8) n_scratch = 8;
-            if (hipMalloc((void**)&src, n_scratch * sb16) != hipSuccess || hipMalloc((void**)&dst, n_scratch * db16) != hipSuccess) break;
-            if (hipMemsetAsync(src, 0x55, n_scratch * sb16, 0) != hipSuccess) break;
-            src_step = sb16;
-            dst_step = db16;
-            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
-            const int cand[4] = {PB_WINLDS_MAX, 10224, 8176, 7168};  // 3, 4, 5 and 5 workgroups per CU (LDS-wise)
-            float t_min[4] = {1e30f, 1e30f, 1e30f, 1e30f};
-            bool failed = false;
-            for (int pass = 0; pass < 2 && !failed; ++pass)  // two interleaved passes: clock ramps and noise hit all alike
-                for (int c = 0; c < 4 && !failed; ++c) {
-                    apply(cand[c]);
-                    for (int rep = 0; rep < 4; ++rep) {  // the first launch after a reclassification is not counted
-                        (void)hipEventRecord(e0, 0);
-                        const int slot = launch_no++ % n_scratch;
-                        if (pb_remap_launch(pl, src + slot * src_step, dst + slot * dst_step, 1, 0, 0, 0) != PB_OK) { failed = true; break; }
-                        (void)hipEventRecord(e1, 0);
-                        if (hipEventSynchronize(e1) != hipSuccess) { failed = true; break; }
-                        float ms = 0.f;
-                        (void)hipEventElapsedTime(&ms, e0, e1);
-                        if (rep > 0 && ms < t_min[c]) t_min[c] = ms;
-                    }
+        // scratch frames in rotation, more than the 256 MiB Infinity Cache in total: the launches being timed
+        // must stream from HBM like real frames do, not hit a cache-resident copy
+        const size_t sb16 = (sb + 255) & ~(size_t)255, db16 = (db + 255) & ~(size_t)255;
+        int n_scratch = (int)(((size_t)320 << 20) / (sb16 + db16)) + 1;
+        if (n_scratch < 2) n_scratch = 2;
+        if (n_scratch > 8) n_scratch = 8;
+        if (hipMalloc((void**)&src, n_scratch * sb16) != hipSuccess || hipMalloc((void**)&dst, n_scratch * db16) != hipSuccess) break;
+        if (hipMemsetAsync(src, 0x55, n_scratch * sb16, 0) != hipSuccess) break;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+        const int cand[4] = {PB_WINLDS_MAX, 10224, 8176, 7168};  // 3, 4, 5 and 5 workgroups per CU (LDS-wise)
+        float t_min[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+        bool failed = false;
+        int launch_no = 0;
+        for (int pass = 0; pass < 2 && !failed; ++pass)  // two interleaved passes: clock ramps and noise hit all alike
+            for (int c = 0; c < 4 && !failed; ++c) {
+                if (pb_apply_budget(pl, cand[c]) != PB_OK) { failed = true; break; }
+                for (int rep = 0; rep < 4; ++rep) {  // the first launch after a reclassification is not counted
+                    (void)hipEventRecord(e0, 0);
+                    const int slot = launch_no++ % n_scratch;
+                    if (pb_remap_launch(pl, src + slot * sb16, dst + slot * db16, 1, 0, 0, 0) != PB_OK) { failed = true; break; }
+                    (void)hipEventRecord(e1, 0);
+                    if (hipEventSynchronize(e1) != hipSuccess) { failed = true; break; }
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, e0, e1);
+                    if (rep > 0 && ms < t_min[c]) t_min[c] = ms;
                 }
-            // the fastest candidate; ties within 1 % go to the larger windows
-            int bi = 0;
-            for (int c = 1; c < 4; ++c)
-                if (t_min[c] < t_min[bi] * 0.99f) bi = c;
-            best = cand[bi];
-            if (failed) best = PB_WINLDS_MAX;
-        }
-        apply(best);
-        unsigned res[2] = {0, 0};
-        if (hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost) == hipSuccess) {
-            pl->n_lean_tiles = res[0];
-            pl->n_direct_tiles = res[1];
-        }
+            }
+        // the fastest candidate; ties within 1 % go to the larger windows
+        int bi = 0;
+        for (int c = 1; c < 4; ++c)
+            if (t_min[c] < t_min[bi] * 0.99f) bi = c;
+        if (!failed) best = cand[bi];
     } while (0);
     (void)hipDeviceSynchronize();
     (void)hipGetLastError();
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    (void)hipFree(src); (void)hipFree(dst); (void)hipFree(saved_l); (void)hipFree(saved_r); (void)hipFree(counters);
+    (void)hipFree(src); (void)hipFree(dst);
+    return best;
+}
+
+static double pb_now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+// device preparation of a plan on the current device + its window budget (0 = default; PB_WIN_BUDGET overrides
+// the default for experiments); PB_PLAN_TUNE times candidates instead
+static int pb_plan_prepare_full(pb_plan* pl, unsigned flags, int win_budget) {
+    if (pl->fast_ready || pl->dbl_ready || pl->sep_ready || pl->device >= 0) {
+        // already prepared: only the budget may change
+        if (win_budget > 0) return pb_apply_budget(pl, win_budget);
+        return PB_OK;
+    }
+    const double t0 = pb_now_ms();
+    int rc = pb_plan_prepare_on_device(pl);
+    if (rc != PB_OK) return rc;
+    int budget = win_budget > 0 ? win_budget : PB_DEFAULT_WIN_BUDGET;
+    if (win_budget <= 0) {
+        const char* forced = getenv("PB_WIN_BUDGET");
+        if (forced && atoi(forced) > 0) budget = atoi(forced);
+    }
+    rc = pb_apply_budget(pl, budget);
+    if (rc != PB_OK) return rc;
+    PB_HIP(hipDeviceSynchronize());
+    pl->prepare_ms = pb_now_ms() - t0;
+    if ((flags & PB_PLAN_TUNE) && win_budget <= 0) {
+        const double t1 = pb_now_ms();
+        const int best = pb_tune_window_budget(pl);
+        rc = pb_apply_budget(pl, best);
+        pl->tune_ms = pb_now_ms() - t1;
+    }
+    return rc;
 }
 
 extern "C" {
@@ -436,13 +485,16 @@ int pb_device_name(char* buf, size_t buflen) {
     return PB_OK;
 }
 
-int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, pb_plan** out) {
+int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, unsigned flags, int win_budget,
+                      pb_plan** out) {
     std::string why;
     if (!out) return pb_fail(PB_ERR_INVALID, "null out pointer");
     *out = nullptr;
     if (!pb_end_ok(dst, why) || !pb_end_ok(src, why)) return pb_fail(PB_ERR_INVALID, why);
     if (n_rot < 0 || n_rot > PB_MAX_ROTATIONS) return pb_fail(PB_ERR_INVALID, "n_rot outside [0, PB_MAX_ROTATIONS]");
     if (n_rot > 0 && !rot3x3) return pb_fail(PB_ERR_INVALID, "null rotation matrices");
+    if (flags & ~(unsigned)(PB_PLAN_DEFER | PB_PLAN_TUNE)) return pb_fail(PB_ERR_INVALID, "unknown plan flags");
+    if (win_budget < 0) return pb_fail(PB_ERR_INVALID, "negative window budget");
     pb_plan* pl = new (std::nothrow) pb_plan();
     if (!pl) return pb_fail(PB_ERR_INVALID, "out of host memory");
     memset(&pl->P, 0, sizeof(PbParams));
@@ -457,15 +509,46 @@ int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
     (void)hipGetLastError();
-    if (ndev > 0) {
-        const int rc = pb_plan_prepare_on_device(pl);
+    if (ndev > 0 && !(flags & PB_PLAN_DEFER)) {
+        const int rc = pb_plan_prepare_full(pl, flags, win_budget);
         if (rc != PB_OK) {
-            delete pl;
+            pb_plan_destroy(pl);
             return rc;
         }
-        pb_tune_window_budget(pl);
     }
     *out = pl;
+    return PB_OK;
+}
+
+int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, pb_plan** out) {
+    return pb_plan_create_ex(dst, rot3x3, n_rot, src, 0u, 0, out);
+}
+
+int pb_plan_prepare(pb_plan* plan, unsigned flags, int win_budget) {
+    if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (flags & ~(unsigned)PB_PLAN_TUNE) return pb_fail(PB_ERR_INVALID, "unknown plan flags");
+    if (win_budget < 0) return pb_fail(PB_ERR_INVALID, "negative window budget");
+    if (plan->device >= 0) {
+        int dev = -1;
+        PB_HIP(hipGetDevice(&dev));
+        if (dev != plan->device) return pb_fail(PB_ERR_INVALID, "plan was prepared on another device; create one plan per device");
+    }
+    return pb_plan_prepare_full(plan, flags, win_budget);
+}
+
+int pb_plan_set_window_budget(pb_plan* plan, int win_budget) {
+    if (!plan || win_budget <= 0) return pb_fail(PB_ERR_INVALID, "null plan or non-positive budget");
+    if (!(plan->fast_ready || plan->dbl_ready)) return pb_fail(PB_ERR_UNSUPPORTED, "the plan has no tile tables (not prepared, or a geometry without a fast path)");
+    int dev = -1;
+    PB_HIP(hipGetDevice(&dev));
+    if (dev != plan->device) return pb_fail(PB_ERR_INVALID, "plan was prepared on another device; create one plan per device");
+    return pb_apply_budget(plan, win_budget);
+}
+
+int pb_plan_timing(const pb_plan* plan, double* prepare_ms, double* tune_ms) {
+    if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (prepare_ms) *prepare_ms = plan->prepare_ms;
+    if (tune_ms) *tune_ms = plan->tune_ms;
     return PB_OK;
 }
 
@@ -482,6 +565,8 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->lat_tab);
     (void)hipFree(plan->dbl_tile_fix);
     (void)hipFree(plan->dbl_px_fix);
+    (void)hipFree(plan->saved_l);
+    (void)hipFree(plan->saved_r);
     delete plan;
 }
 
@@ -516,6 +601,8 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
     if (!src_frame_stride) src_frame_stride = 3ull * P.src.height * P.src.width;
     if (!dst_frame_stride) dst_frame_stride = 3ull * npx;
     if (dst_frame_stride < 3ull * npx) return pb_fail(PB_ERR_INVALID, "dst_frame_stride smaller than a frame");
+    if (n_frames > 1 && src_frame_stride < 3ull * P.src.height * P.src.width)
+        return pb_fail(PB_ERR_INVALID, "src_frame_stride smaller than a frame");
     return pb_remap_launch(plan, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride, (hipStream_t)stream);
 }
 }  // extern "C"
@@ -577,6 +664,8 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
     if (!src_frame_stride) src_frame_stride = 3ull * P.src.height * P.src.width;
     if (!dst_frame_stride) dst_frame_stride = 3ull * npx;
     if (dst_frame_stride < 3ull * npx) return pb_fail(PB_ERR_INVALID, "dst_frame_stride smaller than a frame");
+    if (n_frames > 1 && src_frame_stride < 3ull * P.src.height * P.src.width)
+        return pb_fail(PB_ERR_INVALID, "src_frame_stride smaller than a frame");
     hipStream_t st = (hipStream_t)stream;
     if (pb_use_fast(plan)) {
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
@@ -767,6 +856,178 @@ int pb_synth_frame_u8(uint8_t* frame_dev, int height, int width, uint32_t frame,
     const unsigned total = (unsigned)height * (unsigned)width;
     hipLaunchKernelGGL(pb_synth_kernel, dim3(pb_blocks(total)), dim3(PB_BLOCK), 0, (hipStream_t)stream, frame_dev,
                        height, width, fkey, circle_mask);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+// ---- plan persistence ------------------------------------------------------------------
+// A prepared plan as one host blob: header, PbParams, then the device tables in a fixed order.  The blob is a
+// cache of a computation (like a compiled kernel), valid for this library build (ABI version, struct sizes) and
+// integrity-checked (FNV-1a over the payload); it is not a hardened file format.
+}  // extern "C"
+
+namespace {
+struct PbBlobHeader {
+    uint32_t magic, version, params_size, entry_size;
+    int32_t fast_ready, sep_ready, dbl_ready, reserved;
+    uint32_t n_tiles, n_fail_tiles, n_fix_px, n_lean_tiles, n_black_tiles, n_direct_tiles, n_row_weight_tiles, n_lat_tiles;
+    int64_t diff_pixels;
+    uint64_t section_bytes[13];
+    uint64_t checksum;  // of everything after the header
+};
+const uint32_t PB_BLOB_MAGIC = 0x4C504250u;  // "PBPL"
+const uint32_t PB_BLOB_VERSION = 2;
+
+struct PbSection {
+    void** ptr;
+    size_t bytes;
+};
+// the plan's device tables and their sizes (0 = absent), in blob order
+void pb_plan_sections(pb_plan* pl, PbSection sec[13]) {
+    const size_t nt = pl->n_tiles, nf = pl->n_fail_tiles ? pl->n_fail_tiles : 1, np = pl->n_fix_px ? pl->n_fix_px : 1;
+    const bool tiles = pl->fast_ready || pl->dbl_ready;
+    sec[0] = {(void**)&pl->table, tiles ? nt * sizeof(PbTileEntry) : 0};
+    sec[1] = {(void**)&pl->table_r, pl->dbl_ready ? nt * sizeof(PbTileEntry) : 0};
+    sec[2] = {(void**)&pl->fail_tiles, tiles ? nf * sizeof(int32_t) : 0};
+    sec[3] = {(void**)&pl->fix_px, tiles ? np * sizeof(int32_t) : 0};
+    sec[4] = {(void**)&pl->idx_tab, pl->fast_ready ? nf * PB_TILE * PB_TILE * sizeof(int32_t) : 0};
+    sec[5] = {(void**)&pl->fix_idx, pl->fast_ready ? np * sizeof(int32_t) : 0};
+    sec[6] = {(void**)&pl->sep_rows, pl->sep_rows ? (size_t)pl->P.dst.height * sizeof(PbSepRow) : 0};
+    sec[7] = {(void**)&pl->sep_cols, pl->sep_cols ? (size_t)pl->P.dst.width * sizeof(PbSepCol) : 0};
+    sec[8] = {(void**)&pl->dbl_tile_fix, pl->dbl_ready ? nf * PB_TILE * PB_TILE * sizeof(PbDoubleFix) : 0};
+    sec[9] = {(void**)&pl->dbl_px_fix, pl->dbl_ready ? np * sizeof(PbDoubleFix) : 0};
+    sec[10] = {(void**)&pl->lat_tab, (size_t)pl->n_lat_tiles * PB_LAT_TILE_DOUBLES * sizeof(double)};
+    sec[11] = {(void**)&pl->saved_l, tiles ? nt * sizeof(int32_t) : 0};
+    sec[12] = {(void**)&pl->saved_r, pl->dbl_ready ? nt * sizeof(int32_t) : 0};
+}
+uint64_t pb_fnv1a(const uint8_t* p, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= p[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+}  // namespace
+
+extern "C" {
+
+int pb_plan_serialize(const pb_plan* plan_c, void* buf, size_t capacity, size_t* size_out) {
+    if (!plan_c || !size_out) return pb_fail(PB_ERR_INVALID, "null argument");
+    pb_plan* pl = const_cast<pb_plan*>(plan_c);  // sections are described through member addresses; nothing is modified
+    if (!(pl->fast_ready || pl->dbl_ready || pl->sep_ready)) return pb_fail(PB_ERR_UNSUPPORTED, "the plan holds no device tables (not prepared)");
+    PbSection sec[13];
+    pb_plan_sections(pl, sec);
+    size_t total = sizeof(PbBlobHeader) + sizeof(PbParams);
+    for (int i = 0; i < 13; ++i) total += sec[i].bytes;
+    *size_out = total;
+    if (!buf) return PB_OK;  // size query
+    if (capacity < total) return pb_fail(PB_ERR_INVALID, "buffer too small for the serialized plan");
+    int dev = -1;
+    PB_HIP(hipGetDevice(&dev));
+    if (dev != pl->device) return pb_fail(PB_ERR_INVALID, "plan was prepared on another device; create one plan per device");
+    uint8_t* out = static_cast<uint8_t*>(buf);
+    PbBlobHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = PB_BLOB_MAGIC;
+    h.version = PB_BLOB_VERSION;
+    h.params_size = (uint32_t)sizeof(PbParams);
+    h.entry_size = (uint32_t)sizeof(PbTileEntry);
+    h.fast_ready = pl->fast_ready; h.sep_ready = pl->sep_ready; h.dbl_ready = pl->dbl_ready;
+    h.n_tiles = pl->n_tiles; h.n_fail_tiles = pl->n_fail_tiles; h.n_fix_px = pl->n_fix_px; h.n_lean_tiles = pl->n_lean_tiles;
+    h.n_black_tiles = pl->n_black_tiles; h.n_direct_tiles = pl->n_direct_tiles; h.n_row_weight_tiles = pl->n_row_weight_tiles;
+    h.n_lat_tiles = pl->n_lat_tiles; h.diff_pixels = pl->diff_pixels;
+    uint8_t* q = out + sizeof(PbBlobHeader);
+    memcpy(q, &pl->P, sizeof(PbParams));
+    q += sizeof(PbParams);
+    PB_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < 13; ++i) {
+        h.section_bytes[i] = sec[i].bytes;
+        if (!sec[i].bytes) continue;
+        if (!*sec[i].ptr) return pb_fail(PB_ERR_INVALID, "inconsistent plan: a table is missing");
+        PB_HIP(hipMemcpy(q, *sec[i].ptr, sec[i].bytes, hipMemcpyDeviceToHost));
+        q += sec[i].bytes;
+    }
+    h.checksum = pb_fnv1a(out + sizeof(PbBlobHeader), total - sizeof(PbBlobHeader));
+    memcpy(out, &h, sizeof(h));
+    return PB_OK;
+}
+
+int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
+    if (!buf || !out) return pb_fail(PB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (size < sizeof(PbBlobHeader) + sizeof(PbParams)) return pb_fail(PB_ERR_INVALID, "serialized plan truncated");
+    const uint8_t* in = static_cast<const uint8_t*>(buf);
+    PbBlobHeader h;
+    memcpy(&h, in, sizeof(h));
+    if (h.magic != PB_BLOB_MAGIC || h.version != PB_BLOB_VERSION || h.params_size != sizeof(PbParams) || h.entry_size != sizeof(PbTileEntry))
+        return pb_fail(PB_ERR_INVALID, "serialized plan is not from this library build (magic / version / struct sizes)");
+    if (h.checksum != pb_fnv1a(in + sizeof(PbBlobHeader), size - sizeof(PbBlobHeader)))
+        return pb_fail(PB_ERR_INVALID, "serialized plan is corrupt (checksum)");
+    pb_plan* pl = new (std::nothrow) pb_plan();
+    if (!pl) return pb_fail(PB_ERR_INVALID, "out of host memory");
+    memcpy(&pl->P, in + sizeof(PbBlobHeader), sizeof(PbParams));
+    pl->fast_ready = h.fast_ready; pl->sep_ready = h.sep_ready; pl->dbl_ready = h.dbl_ready;
+    pl->n_tiles = h.n_tiles; pl->n_fail_tiles = h.n_fail_tiles; pl->n_fix_px = h.n_fix_px; pl->n_lean_tiles = h.n_lean_tiles;
+    pl->n_black_tiles = h.n_black_tiles; pl->n_direct_tiles = h.n_direct_tiles; pl->n_row_weight_tiles = h.n_row_weight_tiles;
+    pl->n_lat_tiles = h.n_lat_tiles; pl->diff_pixels = h.diff_pixels;
+    pl->mode = PB_MODE_AUTO;
+    const bool tiles = pl->fast_ready || pl->dbl_ready;
+    bool ok = (!tiles || pl->n_tiles == pb_num_tiles(pl->P)) && pl->n_fail_tiles <= 2u * pl->n_tiles + 1u &&
+              pl->P.win_budget >= PB_DIRECT_LDS_BYTES && pl->P.win_budget <= PB_WINLDS_MAX && (pl->P.win_budget & 15) == 0 &&
+              pl->P.n_rot >= 0 && pl->P.n_rot <= PB_MAX_ROTATIONS;
+    // section presence is decided by pointers on the writing side: reproduce it from the recorded sizes
+    PbSection sec[13];
+    static uint8_t present_tag;  // any non-null value
+    if (h.section_bytes[6]) pl->sep_rows = reinterpret_cast<PbSepRow*>(&present_tag);
+    if (h.section_bytes[7]) pl->sep_cols = reinterpret_cast<PbSepCol*>(&present_tag);
+    pb_plan_sections(pl, sec);
+    pl->sep_rows = nullptr;
+    pl->sep_cols = nullptr;
+    size_t total = sizeof(PbBlobHeader) + sizeof(PbParams);
+    for (int i = 0; i < 13; ++i) {
+        ok = ok && h.section_bytes[i] == sec[i].bytes;
+        total += h.section_bytes[i];
+    }
+    if (!ok || total != size) {
+        delete pl;
+        return pb_fail(PB_ERR_INVALID, "serialized plan is inconsistent (sizes do not match its geometry)");
+    }
+    int rc = PB_OK;
+    if (hipGetDevice(&pl->device) != hipSuccess) rc = PB_ERR_HIP;
+    const uint8_t* q = in + sizeof(PbBlobHeader) + sizeof(PbParams);
+    for (int i = 0; i < 13 && rc == PB_OK; ++i) {
+        if (!sec[i].bytes) continue;
+        if (hipMalloc(sec[i].ptr, sec[i].bytes) != hipSuccess || hipMemcpy(*sec[i].ptr, q, sec[i].bytes, hipMemcpyHostToDevice) != hipSuccess)
+            rc = PB_ERR_HIP;
+        q += sec[i].bytes;
+    }
+    if (rc != PB_OK) {
+        g_err = std::string("plan upload failed: ") + hipGetErrorString(hipGetLastError());
+        pb_plan_destroy(pl);
+        return rc;
+    }
+    *out = pl;
+    return PB_OK;
+}
+
+// ---- measurement utility: a plain device copy (16 bytes per lane), the practical HBM ceiling next to which
+// bench.py reports the remap kernel (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s by such a copy) -------------
+}  // extern "C"
+__global__ __launch_bounds__(256) void pb_copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+extern "C" {
+int pb_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream) {
+    if (!dst_dev || !src_dev) return pb_fail(PB_ERR_INVALID, "null argument");
+    if ((((uintptr_t)dst_dev | (uintptr_t)src_dev | bytes) & 15u) != 0) return pb_fail(PB_ERR_INVALID, "pb_stream_copy needs 16-byte aligned pointers and size");
+    const size_t n16 = bytes / 16;
+    if (!n16) return PB_OK;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 256u * 16u) blocks = 256u * 16u;  // 16 workgroups per CU, grid-stride
+    hipLaunchKernelGGL(pb_copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const uint4*>(src_dev),
+                       static_cast<uint4*>(dst_dev), n16);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }

@@ -173,20 +173,18 @@ BUDGET_CASES = [
 
 
 @pytest.mark.parametrize("case", BUDGET_CASES, ids=[c.name for c in BUDGET_CASES])
-def test_window_budget_only_moves_tiles_between_paths(case, monkeypatch):
-    """The per-plan LDS window budget (normally picked by timing at plan creation) decides which PATH a tile takes
-    - LDS window or direct gather - never its pixels: every budget reproduces the faithful bytes, in the nearest
-    and (where supported) the bilinear mode."""
-    from photonbend_amd.core.projection import _PLAN_CACHE
-
+def test_window_budget_only_moves_tiles_between_paths(case):
+    """The per-plan LDS window budget (pb_plan_create_ex / pb_plan_set_window_budget) decides which PATH a tile
+    takes - LDS window or direct gather - never its pixels: every budget reproduces the faithful bytes, in the
+    nearest and (where supported) the bilinear mode; the same plan object is re-budgeted in place."""
     frames = torch.stack([nat.synth_frame(case.src[1], case.src[2], frame=f) for f in range(2)])
     want = None
     b0 = None
     leans = []
+    src, cmap = H.pb_chain(case, image=np.zeros((case.src[1], case.src[2], 3), np.uint8))
+    plan = nat.Plan(cmap.dst_proj, cmap.rotations, src._proj(), budget=12288)
     for budget in (12288, 8176, 6144, 4224):
-        monkeypatch.setenv("PB_WIN_BUDGET", str(budget))
-        _PLAN_CACHE.clear()
-        plan = H.pb_plan(case)
+        plan.set_window_budget(budget)
         info = plan.info()
         assert info["window_budget"] == budget
         leans.append(info["lean_tiles"])
@@ -201,5 +199,4 @@ def test_window_budget_only_moves_tiles_between_paths(case, monkeypatch):
             if b0 is None:
                 b0 = got.clone()
             assert torch.equal(got, b0), budget
-    _PLAN_CACHE.clear()
     assert leans == sorted(leans, reverse=True) and leans[0] > leans[-1]  # smaller windows: fewer LEAN tiles

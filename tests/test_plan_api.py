@@ -1,0 +1,193 @@
+"""The explicit plan API (pb_plan_create_ex / pb_plan_prepare / pb_plan_set_window_budget / pb_plan_serialize) and
+the host-side plan cache: deferred plans cost nothing and run the faithful kernel, preparation never tunes unless
+asked, a serialized plan reproduces the original bytes, the cache is LRU, per device and thread-safe."""
+
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import photonbend_amd as pb
+from photonbend_amd import _native as nat
+from photonbend_amd.core import projection as proj
+from tests import helpers as H
+from tests.cases import Case, cam, dbl, inscribed, pano
+
+CASES = [
+    Case("api_pano", cam(320, 352, "equisolid", 200, inscribed(320)), pano(256, 512), [(10, 20, 30)]),
+    Case("api_cam", pano(256, 512), cam(320, 320, "equidistant", 360, inscribed(320))),
+    Case("api_double", pano(256, 512), dbl(240, 480, "equidistant", 195), [(3, 90, -7)], mask=2),
+    Case("api_double_sep", pano(256, 512), dbl(240, 480, "equidistant", 180), mask=2),
+]
+
+
+def _projs(case):
+    src, cmap = H.pb_chain(case, image=np.zeros((case.src[1], case.src[2], 3), np.uint8))
+    return cmap.dst_proj, cmap.rotations, src._proj()
+
+
+# ---- CPU: argument validation and the cache's bookkeeping (deferred plans need no device) -----------------
+def test_create_ex_argument_validation():
+    lib = nat.load()
+    h = ctypes.c_void_p()
+    good = nat.make_proj(nat.KIND_PANO, 8, 16)
+    assert lib.pb_plan_create_ex(ctypes.byref(good), None, 0, ctypes.byref(good), 64, 0, ctypes.byref(h)) == -1  # unknown flag
+    assert lib.pb_plan_create_ex(ctypes.byref(good), None, 0, ctypes.byref(good), 0, -5, ctypes.byref(h)) == -1
+    assert lib.pb_plan_create_ex(ctypes.byref(good), None, 0, ctypes.byref(good), nat.PLAN_DEFER, 0, ctypes.byref(h)) == 0
+    n = ctypes.c_size_t()
+    assert lib.pb_plan_serialize(h, None, 0, ctypes.byref(n)) == -3  # nothing prepared: unsupported
+    assert lib.pb_plan_set_window_budget(h, 8192) == -3
+    assert lib.pb_plan_window_budget(h) == 0
+    lib.pb_plan_destroy(h)
+    assert lib.pb_plan_deserialize(b"\0" * 16, 16, ctypes.byref(h)) == -1
+    junk = bytes(4096)
+    assert lib.pb_plan_deserialize(junk, len(junk), ctypes.byref(h)) == -1
+    assert lib.pb_stream_copy(None, None, 16, None) == -1
+
+
+def test_plan_cache_is_lru_and_keyed_by_device(monkeypatch):
+    monkeypatch.setattr(proj, "_PLAN_CACHE_MAX", 3)
+    proj._PLAN_CACHE.clear()
+    src = nat.make_proj(nat.KIND_PANO, 8, 16)
+    dsts = [nat.make_proj(nat.KIND_PANO, 8 + k, 16) for k in range(4)]
+    plans = [proj._plan_for(d, [], src, device="cuda:0", eager=False) for d in dsts[:3]]
+    assert proj._plan_for(dsts[0], [], src, device="cuda:0", eager=False) is plans[0]  # a hit refreshes the entry
+    proj._plan_for(dsts[3], [], src, device="cuda:0", eager=False)  # evicts ONE entry: the least recently used (dsts[1])
+    assert len(proj._PLAN_CACHE) == 3
+    assert proj._plan_for(dsts[0], [], src, device="cuda:0", eager=False) is plans[0]
+    assert proj._plan_for(dsts[2], [], src, device="cuda:0", eager=False) is plans[2]
+    assert proj._plan_for(dsts[1], [], src, device="cuda:0", eager=False) is not plans[1]
+    # same geometry on another device: another plan
+    assert proj._plan_for(dsts[0], [], src, device="cuda:1", eager=False) is not proj._plan_for(dsts[0], [], src, device="cuda:0", eager=False)
+    proj._PLAN_CACHE.clear()
+
+
+def test_plan_cache_survives_concurrent_callers():
+    proj._PLAN_CACHE.clear()
+    src = nat.make_proj(nat.KIND_PANO, 8, 16)
+    got, errs = [], []
+
+    def worker(k):
+        try:
+            for i in range(50):
+                got.append(proj._plan_for(nat.make_proj(nat.KIND_PANO, 8 + (i + k) % 5, 16), [], src, device="cuda:0", eager=False))
+        except Exception as exc:  # pragma: no cover
+            errs.append(exc)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs and len(got) == 200 and len(proj._PLAN_CACHE) == 5
+    proj._PLAN_CACHE.clear()
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_deferred_prepare_serialize_roundtrip(case):
+    d, rots, s = _projs(case)
+    frames = torch.stack([nat.synth_frame(case.src[1], case.src[2], frame=f, circle_mask=case.mask) for f in range(2)])
+    plan = nat.Plan(d, rots, s, defer=True)
+    info = plan.info()
+    assert not info["fast_path"] and info["tiles"] == -1 and info["window_budget"] == 0
+    faithful = plan.remap(frames).clone()  # a deferred plan runs the float64 chain
+    plan.prepare(budget=6144)
+    info = plan.info()
+    assert info["fast_path"] and info["window_budget"] == 6144 and plan.timing()["prepare_ms"] > 0 and plan.timing()["tune_ms"] == 0
+    assert torch.equal(plan.remap(frames), faithful)
+    plan.prepare()  # idempotent
+    assert plan.info() == info
+    blob = plan.serialize()
+    twin = nat.Plan.deserialize(blob, d, s, len(rots))
+    assert twin.info() == info
+    assert torch.equal(twin.remap(frames), faithful) and torch.equal(twin.remap(frames[1]), faithful[1])
+    twin.set_window_budget(12288)  # the certified flags travel with the blob
+    assert twin.info()["lean_tiles"] >= info["lean_tiles"] and torch.equal(twin.remap(frames), faithful)
+    # a corrupted blob is rejected, not uploaded
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 0x40
+    with pytest.raises(nat.PbError, match="corrupt"):
+        nat.Plan.deserialize(bytes(bad), d, s, len(rots))
+    with pytest.raises(nat.PbError):
+        nat.Plan.deserialize(blob[:-7], d, s, len(rots))
+
+
+@pytest.mark.gpu
+def test_tune_is_opt_in_and_changes_no_byte():
+    case = Case("tune", cam(1536, 1536, "equidistant", 360, inscribed(1536)), pano(1024, 2048))
+    d, rots, s = _projs(case)
+    frame = nat.synth_frame(1024, 2048, frame=3)
+    plain = nat.Plan(d, rots, s)
+    assert plain.timing()["tune_ms"] == 0 and plain.info()["window_budget"] == 8176
+    tuned = nat.Plan(d, rots, s, tune=True)
+    assert tuned.timing()["tune_ms"] > 0 and tuned.info()["window_budget"] in (12288, 10224, 8176, 7168)
+    assert torch.equal(plain.remap(frame), tuned.remap(frame))
+
+
+@pytest.mark.gpu
+def test_facade_first_use_is_faithful_second_use_prepares(tmp_path, monkeypatch):
+    proj._PLAN_CACHE.clear()
+    monkeypatch.delenv("PB_PLAN_EAGER", raising=False)
+    monkeypatch.setenv("PB_PLAN_CACHE_DIR", str(tmp_path))
+    frame = nat.synth_frame(256, 512, frame=1).cpu().numpy()
+    dst = pb.CameraImage(np.zeros((300, 300, 3), np.uint8), pb.utils.to_radians(190), pb.equisolid())
+    src = pb.PanoramaImage(frame)
+    a = src.process_coordinate_map(dst.get_coordinate_map())
+    (entry,) = proj._PLAN_CACHE.values()
+    assert entry[1] == 1 and not entry[2] and not entry[0].info()["fast_path"]
+    b = src.process_coordinate_map(dst.get_coordinate_map())
+    (entry,) = proj._PLAN_CACHE.values()
+    assert entry[2] and entry[0].info()["fast_path"]
+    assert np.array_equal(a, b)
+    blobs = list(tmp_path.glob("*.pbplan"))
+    assert len(blobs) == 1
+    # a new process (here: an emptied cache) takes the prepared plan from disk, without certification
+    proj._PLAN_CACHE.clear()
+    monkeypatch.setenv("PB_PLAN_EAGER", "1")
+    c = src.process_coordinate_map(dst.get_coordinate_map())
+    (entry,) = proj._PLAN_CACHE.values()
+    assert entry[0].info()["fast_path"] and entry[0].timing()["prepare_ms"] == 0
+    assert np.array_equal(a, c)
+    proj._PLAN_CACHE.clear()
+
+
+@pytest.mark.gpu
+def test_stride_validation_and_stream_copy():
+    lib = nat.load()
+    case = CASES[0]
+    d, rots, s = _projs(case)
+    plan = nat.Plan(d, rots, s)
+    frames = torch.stack([nat.synth_frame(case.src[1], case.src[2], frame=f) for f in range(2)])
+    out = torch.empty((2, d.height, d.width, 3), dtype=torch.uint8, device="cuda")
+    assert lib.pb_remap_u8(plan.handle, frames.data_ptr(), out.data_ptr(), 2, 16, 0, None) == -1
+    assert b"src_frame_stride" in lib.pb_last_error()
+    assert lib.pb_remap_u8(plan.handle, frames.data_ptr(), out.data_ptr(), 2, 0, 16, None) == -1
+    a = torch.randint(0, 255, (1 << 20,), dtype=torch.uint8, device="cuda")
+    b = torch.zeros_like(a)
+    nat.check(lib.pb_stream_copy(b.data_ptr(), a.data_ptr(), a.numel(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert lib.pb_stream_copy(b.data_ptr() + 1, a.data_ptr(), 16, None) == -1
+
+
+@pytest.mark.gpu
+def test_two_threads_remap_same_sized_images_without_sharing_staging():
+    """the staging buffers were process-wide; two threads remapping same-sized ndarray images at once
+    interleaved their writes.  They are per thread now: every result must equal its single-threaded twin."""
+    fov = pb.utils.to_radians(180)
+    dst = pb.CameraImage(np.zeros((256, 256, 3), np.uint8), fov, pb.equidistant())
+    frames = [nat.synth_frame(256, 512, frame=f).cpu().numpy() for f in range(4)]
+    want = [pb.PanoramaImage(f).process_coordinate_map(dst.get_coordinate_map()) for f in frames]
+    res = {}
+
+    def worker(k):
+        for rep in range(6):
+            out = pb.PanoramaImage(frames[k]).process_coordinate_map(dst.get_coordinate_map())
+            res[(k, rep)] = np.array_equal(out, want[k])
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert len(res) == 24 and all(res.values())
