@@ -11,7 +11,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libphotonbend_hip.so"
-LIB_PATH = os.path.join(HERE, LIB_NAME)
+# PB_LIB_PATH: load another build of the same sources (A/B experiments: -DPB_STAMPS, -DPB_ABLATION); the product is the in-tree file
+LIB_PATH = os.environ.get("PB_LIB_PATH") or os.path.join(HERE, LIB_NAME)
 
 # -ffp-contract=off: the reference rounds every multiply and add separately; the
 # kernels fuse only where they say fma() (see csrc/pb_stages.hpp).
@@ -48,10 +49,11 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build_library(force: bool = False, verbose: bool = False, out: str = None, defines=()) -> str:
+    out = out or LIB_PATH
+    if not force and out == LIB_PATH and not _stale():
         return LIB_PATH
-    cmd = [_hipcc(), *HIPCC_FLAGS, *sources(), "-o", LIB_PATH]
+    cmd = [_hipcc(), *HIPCC_FLAGS, *[f"-D{d}" for d in defines], *sources(), "-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -59,7 +61,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
     if verbose and res.stderr:
         print(res.stderr, file=sys.stderr)
-    return LIB_PATH
+    return out
 
 
 if __name__ == "__main__":

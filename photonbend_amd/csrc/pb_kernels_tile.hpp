@@ -1,6 +1,6 @@
 // pb_kernels_tile.hpp - the fast path for pano / camera sources.
 //
-//   per frame (pb_remap_u8):    pb_hot_win_kernel, ONE launch (16-byte aligned frames: LDS-DMA windows)
+//   per call (pb_remap_u8):     pb_hot_win_kernel, ONE launch for all frames (16-byte aligned frames: LDS-DMA windows)
 //                               else pb_hot_kernel -> pb_fix_kernel (direct gathers; also the int32 index-map output)
 //   per plan  (pb_plan_create): pb_threshold_kernel -> pb_model_kernel -> pb_window_kernel -> pb_certify_kernel
 //                               -> pb_fix_tables_kernel (exact lookup tables) -> pb_budget_kernel (LDS budget, tuned)
@@ -185,21 +185,33 @@ __device__ __forceinline__ unsigned* pb_wave_window(const PbParams& P, int wave,
 static inline size_t pb_window_lds_bytes(const PbParams& P, int pad_dwords = 4) {
     return (size_t)PB_TILE_WAVES * ((size_t)P.win_budget + 4u * pad_dwords);
 }
-#ifdef PB_STAMPS
-__device__ unsigned long long pb_stamp_acc[65536 * 8];
-#define PB_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) pb_stamp_acc[(size_t)(ty * pb_tiles_x(P) + tx) * 8 + i] += t_ - t_prev; t_prev = t_; } while (0)
+#ifdef PB_TRACE  // diagnostic build (experiments/diag_trace.py): absolute time of every phase of every tile's wave
+// pb_trace[tile * 16 + i]: 0 wave started, 1 entry in SGPRs, 2 addresses computed, 3 loads issued, 4 loads landed,
+// 5 stores issued, 6 tile done (stores complete), 7 wave done (incl. fix pixels); 15: HW_ID.  s_memrealtime ticks (10 ns).
+__device__ unsigned long long pb_trace[65536 * 16];
+#define PB_TR(i) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + (i)] = t_; } while (0)
 #else
-#define PB_STAMP(i)
+#define PB_TR(i)
 #endif
 
+// one sample of a direct-gather tile as ONE aligned 8-byte load (the 3 wanted bytes lie within 8 bytes of the dword
+// boundary below them) + v_alignbyte, instead of an unaligned 4-byte load: the texture path splits unaligned dwords
+__device__ __forceinline__ unsigned pb_load3_x2(const uint8_t* __restrict__ s, unsigned off) {
+    uint2 v;
+    __builtin_memcpy(&v, (const uint8_t*)__builtin_assume_aligned(s + (off & ~3u), 4), 8);
+    return __builtin_amdgcn_alignbyte(v.y, v.x, off);
+}
+
+// part: this wave issues the row groups part, part + parts, ... (a workgroup loading one window together)
 __device__ __forceinline__ void pb_issue_window_loads(const uint8_t* __restrict__ s, unsigned* win, int lane, unsigned gbase,
-                                                      unsigned rowbytes, int nrows, int n16, unsigned safe_len) {
+                                                      unsigned rowbytes, int nrows, int n16, unsigned safe_len, unsigned part = 0,
+                                                      unsigned parts = 1) {
     const unsigned pitch = 16u * (unsigned)n16;
     const unsigned inv = (65536u + n16 - 1) / n16;  // lane / n16 for lane < 64
     const unsigned lrow = ((unsigned)lane * inv) >> 16, chunk = (unsigned)lane - lrow * n16;
     const unsigned rpp = 64u / n16;
     const bool lane_on = lrow < rpp;
-    for (unsigned rowb = 0; rowb < (unsigned)nrows; rowb += rpp) {
+    for (unsigned rowb = part * rpp; rowb < (unsigned)nrows; rowb += parts * rpp) {
         const unsigned row = rowb + lrow;
         // a row segment starts at the 16-byte boundary at or below its first sample
         const unsigned ga = ((gbase + row * rowbytes) & ~15u) + 16u * chunk;
@@ -222,6 +234,17 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
     const int W = P.dst.width, H = P.dst.height;
     const int x = X0 + 4 * xg;
 
+#ifdef PB_ABLATION  // timing experiments only (experiments/): skipped work = wrong pixels; never compiled into the product
+    if ((P.exp_flags & 4) && (flags & PB_TILE_DIRECT)) return;
+    if ((P.exp_flags & 8) && (flags & PB_TILE_LEAN)) return;
+    if ((P.exp_flags & 64) && !(flags & (PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK))) return;
+    if ((P.exp_flags & 128) && (flags & PB_TILE_BLACK)) return;
+#define PB_ABL_NO_STORE(v) ((P.exp_flags & 16) && (v) != 0x12345678u)
+#define PB_ABL_NO_LOAD (P.exp_flags & 32)
+#else
+#define PB_ABL_NO_STORE(v) false
+#define PB_ABL_NO_LOAD false
+#endif
     if (flags & PB_TILE_BLACK) {
         for (int f = 0; f < n_frames; ++f) {
             uint8_t* d = dst + (unsigned long long)f * dst_stride;
@@ -276,12 +299,26 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
                 go[n] = gbase + (unsigned)(int)fv.x * rowbytes + __umul24((unsigned)(int)fv.y, 3u);
             }
         }
+        PB_TR(2);
         for (int f = 0; f < n_frames; ++f) {
             const uint8_t* s = src + (unsigned long long)f * src_stride;
             uint8_t* d = dst + (unsigned long long)f * dst_stride;
             unsigned t[16];
+            if (PB_ABL_NO_LOAD) {
 #pragma unroll
-            for (int n = 0; n < 16; ++n) __builtin_memcpy(&t[n], s + go[n], 4);
+                for (int n = 0; n < 16; ++n) t[n] = go[n];
+            } else if (P.exp_flags & PB_EXP_DIRECT_X2) {
+#pragma unroll
+                for (int n = 0; n < 16; ++n) t[n] = pb_load3_x2(s, go[n]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < 16; ++n) __builtin_memcpy(&t[n], s + go[n], 4);
+            }
+#ifdef PB_TRACE
+            PB_TR(3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PB_TR(4);
+#endif
             // park as [y][x] with a 33-dword pitch, read back as 4 consecutive pixels x 4 rows per lane
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
@@ -293,6 +330,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             for (int jr = 0; jr < 4; ++jr) {
                 const unsigned* r = win + (yb + 8 * jr) * 33 + 4 * xg;
                 const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
+                if (PB_ABL_NO_STORE(r[0])) continue;
                 if ((((uintptr_t)d + off) & 3u) == 0) {
                     // panorama sources stream through once: plain stores (L2 merges the half lines of neighbouring
                     // tiles) measured 2 % faster on c2; fisheye sources are re-read across tiles and keep the
@@ -310,6 +348,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
                     }
                 }
             }
+            PB_TR(5);
             pb_wave_sync();
         }
         return;
@@ -321,10 +360,6 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
         float u[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) u[k] = pb_tile_coord(4 * xg + k);
-#ifdef PB_STAMPS
-        unsigned long long t_prev;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev) :: "memory");
-#endif
         for (int f = 0; f < n_frames; ++f) {
             const uint8_t* s = src + (unsigned long long)f * src_stride;
             uint8_t* d = dst + (unsigned long long)f * dst_stride;
@@ -343,12 +378,12 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             // the window loads are issued AFTER the model math: measured 2 % faster on c2 than issuing them first
             // and computing while they fly (the other waves of the CU keep the memory pipeline busy anyway)
             asm volatile("" ::: "memory");
-            pb_issue_window_loads(s, win, lane, gbase, rowbytes, nrows, n16, safe_len);
-            PB_STAMP(0);
-            PB_STAMP(1);
+            PB_TR(2);
+            if (!PB_ABL_NO_LOAD) pb_issue_window_loads(s, win, lane, gbase, rowbytes, nrows, n16, safe_len);
+            PB_TR(3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             pb_wave_sync();
-            PB_STAMP(2);
+            PB_TR(4);
 #pragma unroll
             for (int jr = 0; jr < 4; ++jr) {
                 unsigned a[4];
@@ -359,6 +394,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
                 }
                 // LEAN tiles lie fully inside the image; the 12-byte store is 4-byte aligned when the base is
                 const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
+                if (PB_ABL_NO_STORE(a[0])) continue;
                 if ((((uintptr_t)d + off) & 3u) == 0) {
                     __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));  // write-once output: keep it out of the source's cache space
                 } else {
@@ -370,9 +406,9 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
                     }
                 }
             }
-            PB_STAMP(3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PB_STAMP(4);
+            PB_TR(5);
+            // no wait for the stores: their data left the registers at issue; the next frame's window loads only
+            // need this frame's LDS reads done (their results were consumed by the packing above)
             pb_wave_sync();  // the window is overwritten by the next frame's loads
         }
         return;
@@ -479,92 +515,119 @@ __device__ __forceinline__ void pb_load_entry(const PbTileEntry* __restrict__ e,
 //   fix_idx  the source index of every pixel of the fix list (parallel to fix_px).
 // With them the hot launch is the only launch of a frame: a failed tile is gathered by its own wave through its
 // index slot, a tile's fix pixels are re-copied by its wave after its stores; no float64 in the kernel.
-// ONE: single-frame launch - the frame loops (and the registers that keep their invariants alive) disappear.
-template <int SRC_KIND, bool ONE>
+template <bool ONE>
+__device__ __forceinline__ void pb_failed_tile(const PbParams& P, const PbTileEntry* __restrict__ e, const int tx, const int ty,
+                                               const int lane, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                               const int n_frames, const unsigned long long src_stride,
+                                               const unsigned long long dst_stride, const int32_t* __restrict__ idx_tab) {
+    // failed tile: gather through the plan's exact indices (lane = 4 consecutive pixels x 4 rows)
+    const int xg = lane & 7, yb = lane >> 3;
+    const int W = P.dst.width, H = P.dst.height;
+    const int x = tx * PB_TILE + 4 * xg;
+    const int32_t* __restrict__ slot = idx_tab + (size_t)e->aux_off * (PB_TILE * PB_TILE);
+    int id[4][4];
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+        const int4 v = *reinterpret_cast<const int4*>(slot + (yb + 8 * jr) * PB_TILE + 4 * xg);
+        id[jr][0] = v.x; id[jr][1] = v.y; id[jr][2] = v.z; id[jr][3] = v.w;
+    }
+    const unsigned last_px = (unsigned)P.src.height * (unsigned)P.src.width - 1u;
+    for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* s = src + (unsigned long long)f * src_stride;
+        uint8_t* d = dst + (unsigned long long)f * dst_stride;
+        // branch-free, so that the 16 gathers of a lane are in flight together: a black pixel (-1) reads pixel 0
+        // and is masked; the frame's very last pixel is read one byte early (a 4-byte read at its own address
+        // would touch one byte past the buffer) and shifted
+        unsigned a[4][4];
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = id[jr][k];
+                const bool last = (unsigned)v == last_px;
+                const unsigned off = v < 0 ? 0u : 3u * (unsigned)v - (last ? 1u : 0u);
+                unsigned t;
+                __builtin_memcpy(&t, s + off, 4);
+                a[jr][k] = v < 0 ? 0u : (last ? t >> 8 : t);
+            }
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const int y = ty * PB_TILE + yb + 8 * jr;
+            if (y >= H) continue;
+            const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+            if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
+                __builtin_nontemporal_store(pb_pack_px4(a[jr][0], a[jr][1], a[jr][2], a[jr][3]), reinterpret_cast<pb_u32x3*>(d + off));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (x + k < W) {
+                        d[off + 3 * k + 0] = (uint8_t)(a[jr][k] & 0xFF);
+                        d[off + 3 * k + 1] = (uint8_t)((a[jr][k] >> 8) & 0xFF);
+                        d[off + 3 * k + 2] = (uint8_t)((a[jr][k] >> 16) & 0xFF);
+                    }
+            }
+        }
+    }
+}
+
+// The hot kernel: one wave per 32x32 tile, one launch per pb_remap_u8 call whatever the number of frames.
+// Frames of a batch are a GRID dimension (workgroup = (frame, 2x2 tile group); frame-major, so the XCD residue of a
+// tile group is the same in every frame): the launch ramp, the drain of the last waves and the gap between dependent
+// launches - about 5 of a c2 frame's 43 us (experiments/diag_trace.py) - are paid once per batch instead of once per
+// frame, and the index math (0.35 us of a wave's 6.3) is simply repeated.  A wave that loops over the frames of its
+// tile instead has a lifetime, and therefore a drain, n_frames times as long: measured no faster than single launches.
+// (Also measured and rejected, see experiments/README.md: waves that work through 2-8 tiles with the next entry
+// prefetched - the entry's scalar round trip disappears from the timeline but the frame gets slower, the workgroups
+// become too coarse for the hardware's dealing; the four waves of a workgroup sharing one source window; aligned
+// 8-byte loads in the direct-gather tiles.)
+template <int SRC_KIND>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
                                                                          const uint8_t* __restrict__ src,
-                                                                         uint8_t* __restrict__ dst, int n_frames_arg,
+                                                                         uint8_t* __restrict__ dst, const unsigned groups_per_frame,
                                                                          unsigned long long src_stride,
                                                                          unsigned long long dst_stride,
                                                                          const int32_t* __restrict__ idx_tab,
                                                                          const int32_t* __restrict__ fix_px,
                                                                          const int32_t* __restrict__ fix_idx) {
-    const int n_frames = ONE ? 1 : n_frames_arg;
     // every kernel argument the tile prologue needs, in one scalar round trip (the compiler would otherwise fetch
     // the table pointer only after the tile index is known: a second dependent trip per wave)
-    asm volatile("" ::"s"(table), "s"(P.dst.width), "s"(P.dst.height), "s"(P.src.width), "s"(P.src.height), "s"(P.win_budget));
+    asm volatile("" ::"s"(table), "s"(P.dst.width), "s"(P.dst.height), "s"(P.src.width), "s"(P.src.height), "s"(P.win_budget), "s"(groups_per_frame));
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // A workgroup is `wpw` waves (1, 2 or 4; blockDim.x / 64).  LDS is released per WORKGROUP: with four waves the
+    // window of a wave that has finished idles until the slowest of the four is done.  Tile groups (2x2 tiles) keep
+    // their XCD: workgroup id -> (XCD residue, slot); the slot's waves continue the XCD's list of tile groups.
+    const unsigned wpw = blockDim.x >> 6;
+    unsigned wg = blockIdx.x;
+    const unsigned wgs_per_frame = groups_per_frame * (4u / wpw);
+    if (wg >= wgs_per_frame) {  // a batch: which frame
+        const unsigned f = wg / wgs_per_frame;
+        wg -= f * wgs_per_frame;
+        src += (unsigned long long)f * src_stride;
+        dst += (unsigned long long)f * dst_stride;
+    }
+    const unsigned flat = (wg >> 3) * wpw + (unsigned)wave_in_wg;
+    const unsigned group = (flat >> 2) * 8u + (wg & 7u);
+    const int wave = (int)(flat & 3u);
     int tx, ty;
-    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
+    if (!pb_tile_of_wave(P, wave, tx, ty, group)) return;
+    PB_TR(0);
+#ifdef PB_TRACE
+    if (lane == 0) pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+#endif
     PbTileEntry entry;
     pb_load_entry(table + ((size_t)ty * pb_tiles_x(P) + tx), entry);
     const PbTileEntry* __restrict__ e = &entry;
     const int flags = e->flags;
+    PB_TR(1);
     if (flags & PB_TILE_FAILED) {
-        // failed tile: gather through the plan's exact indices (lane = 4 consecutive pixels x 4 rows)
-        const int xg = lane & 7, yb = lane >> 3;
-        const int W = P.dst.width, H = P.dst.height;
-        const int x = tx * PB_TILE + 4 * xg;
-        const int32_t* __restrict__ slot = idx_tab + (size_t)e->aux_off * (PB_TILE * PB_TILE);
-        int id[4][4];
-#pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            const int4 v = *reinterpret_cast<const int4*>(slot + (yb + 8 * jr) * PB_TILE + 4 * xg);
-            id[jr][0] = v.x; id[jr][1] = v.y; id[jr][2] = v.z; id[jr][3] = v.w;
-        }
-        const unsigned last_px = (unsigned)P.src.height * (unsigned)P.src.width - 1u;
-        for (int f = 0; f < n_frames; ++f) {
-            const uint8_t* s = src + (unsigned long long)f * src_stride;
-            uint8_t* d = dst + (unsigned long long)f * dst_stride;
-            // branch-free, so that the 16 gathers of a lane are in flight together: a black pixel (-1) reads pixel 0
-            // and is masked; the frame's very last pixel is read one byte early (a 4-byte read at its own address
-            // would touch one byte past the buffer) and shifted
-            unsigned a[4][4];
-#pragma unroll
-            for (int jr = 0; jr < 4; ++jr)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int v = id[jr][k];
-                    const bool last = (unsigned)v == last_px;
-                    const unsigned off = v < 0 ? 0u : 3u * (unsigned)v - (last ? 1u : 0u);
-                    unsigned t;
-                    __builtin_memcpy(&t, s + off, 4);
-                    a[jr][k] = v < 0 ? 0u : (last ? t >> 8 : t);
-                }
-#pragma unroll
-            for (int jr = 0; jr < 4; ++jr) {
-                const int y = ty * PB_TILE + yb + 8 * jr;
-                if (y >= H) continue;
-                const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
-                if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
-                    __builtin_nontemporal_store(pb_pack_px4(a[jr][0], a[jr][1], a[jr][2], a[jr][3]), reinterpret_cast<pb_u32x3*>(d + off));
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (x + k < W) {
-                            d[off + 3 * k + 0] = (uint8_t)(a[jr][k] & 0xFF);
-                            d[off + 3 * k + 1] = (uint8_t)((a[jr][k] >> 8) & 0xFF);
-                            d[off + 3 * k + 2] = (uint8_t)((a[jr][k] >> 16) & 0xFF);
-                        }
-                }
-            }
-        }
+        pb_failed_tile<true>(P, e, tx, ty, lane, src, dst, 1, src_stride, dst_stride, idx_tab);
         return;
     }
-#ifdef PB_STAMPS
-    unsigned long long tw0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tw0) :: "memory");
-#endif
-    pb_win_tile<SRC_KIND>(P, e, flags, tx, ty, lane, pb_wave_window(P, wave), src, dst, n_frames, src_stride, dst_stride);
-#ifdef PB_STAMPS
-    {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long tw1;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tw1) :: "memory");
-        const int cls = (flags & PB_TILE_LEAN) ? 5 : ((flags & PB_TILE_DIRECT) ? 6 : 7);
-        if (lane == 0) pb_stamp_acc[(size_t)(ty * pb_tiles_x(P) + tx) * 8 + cls] += tw1 - tw0;
-    }
+    pb_win_tile<SRC_KIND>(P, e, flags, tx, ty, lane, pb_wave_window(P, wave_in_wg), src, dst, 1, src_stride, dst_stride);
+#ifdef PB_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PB_TR(6);
 #endif
     // this tile's fix pixels (where the model's truncation differs from the faithful one): re-copied through
     // their exact indices after the wave's own stores have completed
@@ -574,15 +637,17 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
         if (lane < n_fix) {
             const unsigned p = (unsigned)fix_px[e->fix_off + lane];
             const int id = fix_idx[e->fix_off + lane];
-            for (int f = 0; f < n_frames; ++f) {
-                const unsigned v = pb_load_px(src + (unsigned long long)f * src_stride, id);
-                uint8_t* o = dst + (unsigned long long)f * dst_stride + 3ull * p;
-                o[0] = (uint8_t)(v & 0xFF);
-                o[1] = (uint8_t)((v >> 8) & 0xFF);
-                o[2] = (uint8_t)((v >> 16) & 0xFF);
-            }
+            const unsigned v = pb_load_px(src, id);
+            uint8_t* o = dst + 3ull * p;
+            o[0] = (uint8_t)(v & 0xFF);
+            o[1] = (uint8_t)((v >> 8) & 0xFF);
+            o[2] = (uint8_t)((v >> 16) & 0xFF);
         }
     }
+#ifdef PB_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PB_TR(7);
+#endif
 }
 
 // Plan creation: applies an LDS budget to the classification made with PB_WINLDS_MAX.  saved = the flags as
@@ -801,8 +866,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_window_kernel(const PbP
     const int lr0 = rmin - 1, lc0 = cmin - 1, rows = rmax - rmin + 3, cols = cmax - cmin + 3;
     // (an eye's margin texel may lie in the other eye's half: inside the frame, never sampled)
     if (lr0 < 0 || lc0 < 0 || lr0 + rows > h || lc0 + cols > w) return;
-    // the last sample's 4-byte read must stay inside the frame
-    if ((unsigned)(lr0 + rows - 1) * rowbytes + 3u * (unsigned)(lc0 + cols - 1) + 4u > rowbytes * (unsigned)h) return;
+    // the last sample's read (4 bytes; 8 from the dword boundary below it on the aligned-load path) must stay inside the frame
+    if ((unsigned)(lr0 + rows - 1) * rowbytes + 3u * (unsigned)(lc0 + cols - 1) + 8u > rowbytes * (unsigned)h) return;
     const unsigned a0 = (3u * (unsigned)lc0) & 15u;
     const unsigned n16 = (a0 + 3u * (unsigned)cols + 1u + 15u) >> 4;
     const unsigned last_chunk_end = (((unsigned)(lr0 + rows - 1) * rowbytes + 3u * (unsigned)lc0) & ~15u) + 16u * n16;

@@ -11,6 +11,10 @@
 
 #define PB_PI 3.141592653589793  // == numpy.pi == M_PI
 
+// kernel variant switches (PbParams::exp_flags; default from PB_DEFAULT_EXP, overridden by the PB_EXP environment
+// variable at plan creation).  They select how a tile's bytes are fetched, never which bytes.
+#define PB_EXP_DIRECT_X2 1   // direct-gather tiles: one ALIGNED 8-byte load per sample instead of an unaligned 4-byte one
+
 struct PbEnd {
     int32_t kind, lens, height, width;
     double fov, f_distance;
@@ -27,7 +31,7 @@ struct PbParams {
     double dst_right_min;  // pi - fov / 2.0     projection.py:358-360 (double)
     double dst_x0, dst_y0; // first linspace samples, projection.py:177-180, :390-400
     int32_t dst_half_w;    // W // 2 (double)    projection.py:355
-    int32_t pad1;
+    int32_t exp_flags;     // kernel variant switches (PB_EXP_*): paths, never pixels
     // pano destination: np.linspace(start, stop, num) = k*step + start, last = stop
     double pano_lon_start, pano_lon_stop, pano_lon_step;  // projection.py:500-504
     double pano_lat_step;                                 // projection.py:505

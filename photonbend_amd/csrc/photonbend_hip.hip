@@ -27,6 +27,7 @@
 #include "pb_kernels_double.hpp"
 #include "pb_kernels_bilinear.hpp"
 
+#define PB_WAVES_PER_WG 4  // waves per workgroup of the hot kernel (LDS is released per workgroup)
 struct pb_plan {
     PbParams P;
     int mode = PB_MODE_AUTO;     // PB_MODE_AUTO / PB_MODE_FAITHFUL / PB_MODE_FAST
@@ -289,15 +290,24 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
     if (windowed) {
         // one launch per frame: failed tiles and fix pixels are looked up in the plan's exact-index tables by the
         // hot waves themselves (pb_kernels_tile.hpp)
-#define PB_LAUNCH_WIN(KIND, ONE)                                                                                               \
-    hipLaunchKernelGGL((pb_hot_win_kernel<KIND, ONE>), grid, block, pb_window_lds_bytes(P), st, P, pl->table, src, dst, n_frames, ss, ds, pl->idx_tab, \
+        // frames are a grid dimension, frame-major; a frame's share of the grid is a multiple of 8 workgroups so that a
+        // tile group keeps its XCD residue in every frame
+        const unsigned gpf = (grid.x + 7u) & ~7u;
+        static const unsigned wpw = [] { const char* e = getenv("PB_WPW"); const int v = e ? atoi(e) : PB_WAVES_PER_WG; return (v == 1 || v == 2) ? (unsigned)v : 4u; }();
+        const dim3 wblock(64u * wpw);
+        const size_t lds = pb_window_lds_bytes(P) / PB_TILE_WAVES * wpw;
+        const unsigned wpf = gpf * (4u / wpw);
+        const int per_launch = (int)(0x7FFFFFFFu / wpf);  // grid limit: absurdly long batches go in several launches
+        for (int f0 = 0; f0 < n_frames; f0 += per_launch) {
+            const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;
+            const dim3 bgrid(wpf * (unsigned)nf);
+            const uint8_t* sf = src + (unsigned long long)f0 * ss;
+            uint8_t* df = dst + (unsigned long long)f0 * ds;
+#define PB_LAUNCH_WIN(KIND)                                                                                                   \
+    hipLaunchKernelGGL((pb_hot_win_kernel<KIND>), bgrid, wblock, lds, st, P, pl->table, sf, df, gpf, ss, ds, pl->idx_tab, \
                        pl->fix_px, pl->fix_idx)
-        if (P.src.kind == PB_KIND_PANO) {
-            if (n_frames == 1) PB_LAUNCH_WIN(PB_KIND_PANO, true);
-            else PB_LAUNCH_WIN(PB_KIND_PANO, false);
-        } else {
-            if (n_frames == 1) PB_LAUNCH_WIN(PB_KIND_CAMERA, true);
-            else PB_LAUNCH_WIN(PB_KIND_CAMERA, false);
+            if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_WIN(PB_KIND_PANO);
+            else PB_LAUNCH_WIN(PB_KIND_CAMERA);
         }
 #undef PB_LAUNCH_WIN
         return;
@@ -334,6 +344,7 @@ static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t*
 // kernels are latency x concurrency bound) but push tiles with larger windows onto the direct-gather path; which
 // side wins depends on the geometry.  The classification only decides the PATH a tile takes, never its pixels
 // (same model, same anchors, same tables), so a budget change cannot change a byte.
+#define PB_DEFAULT_EXP 0
 #define PB_DEFAULT_WIN_BUDGET 8176  // 5 workgroups per CU; c1 / c3 / c5 measured fastest at 7-8 KiB, c2 within 4 % of its best
 static int pb_clamp_budget(int budget) {
     budget &= ~15;
@@ -357,15 +368,15 @@ static int pb_apply_budget(pb_plan* pl, int budget) {
         }
     }
     unsigned* counters = nullptr;
-    PB_HIP(hipMalloc((void**)&counters, 2 * sizeof(unsigned)));
-    (void)hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
+    PB_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
+    (void)hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
     budget = pb_clamp_budget(budget);
     if (pl->dbl_ready)
         hipLaunchKernelGGL(pb_budget_double_kernel, g, b, 0, 0, pl->table, pl->table_r, pl->saved_l, pl->saved_r, nt, budget, counters);
     else
         hipLaunchKernelGGL(pb_budget_kernel, g, b, 0, 0, pl->table, pl->saved_l, nt, budget, counters);
     P.win_budget = budget;
-    unsigned res[2] = {0, 0};
+    unsigned res[4] = {0, 0, 0, 0};
     const hipError_t e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
     (void)hipFree(counters);
     PB_HIP(e);
@@ -505,6 +516,8 @@ int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const
         for (int e = 0; e < 9; ++e) pl->P.R[k][e] = rot3x3[9 * k + e];
     pb_derive(pl->P);
     pl->P.win_budget = PB_WINLDS_MAX;
+    pl->P.exp_flags = PB_DEFAULT_EXP;
+    if (const char* ex = getenv("PB_EXP")) pl->P.exp_flags = atoi(ex);
     pl->mode = PB_MODE_AUTO;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
@@ -718,19 +731,15 @@ int pb_index_map_i32(const pb_plan* plan, int32_t* idx_dev, double* weights_dev,
     return PB_OK;
 }
 
-#ifdef PB_STAMPS
-__attribute__((visibility("default"))) int pb_debug_stamps(unsigned long long* out8, int reset) {
-    static unsigned long long hostbuf[65536 * 8];
-    if (out8) {
-        (void)hipMemcpyFromSymbol(hostbuf, HIP_SYMBOL(pb_stamp_acc), sizeof(hostbuf));
-        for (int i = 0; i < 8; ++i) { out8[i] = 0; for (int t = 0; t < 65536; ++t) out8[i] += hostbuf[(size_t)t * 8 + i]; }
+#ifdef PB_TRACE
+__attribute__((visibility("default"))) int pb_debug_trace(unsigned long long* out, size_t n_words, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(pb_trace), n_words * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(pb_trace)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 65536 * 16) != hipSuccess) return -2;
     }
-    if (reset) { memset(hostbuf, 0, sizeof(hostbuf)); (void)hipMemcpyToSymbol(HIP_SYMBOL(pb_stamp_acc), hostbuf, sizeof(hostbuf)); }
     return 0;
 }
-#endif
-
-#ifdef PB_STAMPS
 __attribute__((visibility("default"))) int pb_debug_copy_table(const pb_plan* plan, void* host, size_t bytes) {
     if (!plan || !plan->table) return -1;
     const size_t have = (size_t)plan->n_tiles * sizeof(PbTileEntry);
