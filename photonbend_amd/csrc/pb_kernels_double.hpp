@@ -194,13 +194,27 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
                                                                             const PbDoubleFix* __restrict__ tile_fix,
                                                                             const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                             int n_frames, unsigned long long src_stride,
-                                                                            unsigned long long dst_stride) {
-    const int frames = ONE ? 1 : n_frames;
+                                                                            unsigned long long dst_stride, const unsigned groups_per_frame,
+                                                                            const int frames_per_wave) {
+    // A batch is cut into chunks of frames_per_wave frames; chunks are a grid dimension (chunk-major, a tile group keeps
+    // its XCD residue): the launch ramp and drain are paid once per batch, and inside a chunk the wave reuses its two
+    // entries, blend weights and per-pixel addresses across the frames (ONE: chunks of one frame, no frame loop).
+    unsigned group = blockIdx.x;
+    int frames = ONE ? 1 : frames_per_wave;
+    if (group >= groups_per_frame) {
+        const unsigned chunk = group / groups_per_frame;
+        group -= chunk * groups_per_frame;
+        src += (unsigned long long)chunk * (unsigned)frames_per_wave * src_stride;
+        dst += (unsigned long long)chunk * (unsigned)frames_per_wave * dst_stride;
+        if (!ONE) frames = min(frames_per_wave, n_frames - (int)chunk * frames_per_wave);
+    } else if (!ONE) {
+        frames = min(frames_per_wave, n_frames);
+    }
     PbTileCtx C;
     C.lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tx, ty;
-    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
+    if (!pb_tile_of_wave(P, wave, tx, ty, group)) return;
     const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
     const PbTileEntry* __restrict__ el = table_l + tile;
     const PbTileEntry* __restrict__ er = table_r + tile;

@@ -27,6 +27,7 @@
 #include "pb_kernels_double.hpp"
 #include "pb_kernels_bilinear.hpp"
 
+#define PB_DOUBLE_FRAMES_PER_WAVE 1  // frames a double-source wave loops over (the rest of a batch is a grid dimension)
 #define PB_WAVES_PER_WG 4  // waves per workgroup of the hot kernel (LDS is released per workgroup)
 struct pb_plan {
     PbParams P;
@@ -631,11 +632,16 @@ static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t*
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
         // one launch per frame: failed tiles and fix pixels go through the plan's stored faithful taps
         const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
+        static const int fpw_env = [] { const char* e = getenv("PB_DOUBLE_FPW"); return e ? atoi(e) : 0; }();
+        const int fpw = fpw_env > 0 ? fpw_env : PB_DOUBLE_FRAMES_PER_WAVE;
+        const unsigned gpf = (grid.x + 7u) & ~7u;
+        const unsigned chunks = (unsigned)((n_frames + fpw - 1) / fpw);
+        const dim3 bgrid(gpf * chunks);  // (h*w < 2^29 and n_frames an int: far below the grid limit for any batch that fits memory)
 #define PB_LAUNCH_DOUBLE(WMODE, ONE)                                                                                              \
-    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, ONE>), grid, block, pb_window_lds_bytes(P, 8), st, P, plan->table, plan->table_r, rows, plan->lat_tab, \
+    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, ONE>), bgrid, block, pb_window_lds_bytes(P, 8), st, P, plan->table, plan->table_r, rows, plan->lat_tab, \
                        plan->fix_px, plan->dbl_px_fix, plan->dbl_tile_fix, src_dev, dst_dev, n_frames, src_frame_stride,           \
-                       dst_frame_stride)
-        const bool one = n_frames == 1;
+                       dst_frame_stride, gpf, fpw)
+        const bool one = n_frames == 1 || fpw == 1;
         if (rows && one) PB_LAUNCH_DOUBLE(1, true);
         else if (rows) PB_LAUNCH_DOUBLE(1, false);
         else if (plan->n_lat_tiles && one) PB_LAUNCH_DOUBLE(2, true);
