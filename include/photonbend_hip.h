@@ -61,7 +61,9 @@ typedef enum pb_lens {
     PB_LENS_RECTILINEAR = 2,
     PB_LENS_STEREOGRAPHIC = 3,
     PB_LENS_ORTHOGRAPHIC = 4,
-    PB_LENS_THOBY = 5
+    PB_LENS_THOBY = 5,
+    PB_LENS_CUSTOM = 6 /* Lens(forward_function, reverse_function) of arbitrary Python callables (lens.py:48-64): the HOST
+                          evaluates them; accepted only by pb_index_from_map_i32 together with its distance planes */
 } pb_lens;
 
 /* One end of a remap.  f_distance is computed by the HOST with the reference
@@ -182,6 +184,25 @@ int pb_rotate_f64(const double* rot3x3, double* map_in_dev, double* map_out_dev,
  * (projection.py:534-536). */
 int pb_sample_map_u8(const pb_proj* src, double* map_dev, int height, int width, const uint8_t* src_dev,
                      uint8_t* dst_dev, void* stream);
+
+/* The sampling half of process_coordinate_map without the gather (projection.py:197-260 camera, :408-462 double,
+ * :515-547 panorama): coordinate map (height, width, 3) -> int32 source index per pixel (-1 = black; a double source:
+ * [2][height*width], left eye then right eye, and weights_dev float64 [2][height*width] when not NULL).  PB_KIND_PANO
+ * zeroes invalid lat/lon in map_dev like the reference.  dist_l_dev / dist_r_dev (float64 [height*width], optional):
+ * forward_lens(latitude) * f_distance evaluated by the host for a PB_LENS_CUSTOM source (the right eye's plane is
+ * forward_lens(pi - latitude) * f_distance); with them the built-in forward lens is not used.
+ * Together with pb_gather_px / pb_gather_blend_u8 this serves every image the reference accepts but the fused
+ * uint8 RGB path does not: grey (H, W), RGBA (H, W, 4), 16-bit samples - the reference fancy-indexes whatever array
+ * it is given (projection.py:234-243, :545-546). */
+int pb_index_from_map_i32(const pb_proj* src, double* map_dev, int height, int width, const double* dist_l_dev,
+                          const double* dist_r_dev, int32_t* idx_dev, double* weights_dev, void* stream);
+/* dst[p] = idx[p] < 0 ? 0 : src[idx[p]], bytes_per_px bytes each (1..64). */
+int pb_gather_px(const int32_t* idx_dev, const void* src_dev, void* dst_dev, size_t n_px, int bytes_per_px, void* stream);
+/* The double-fisheye blend for `channels` interleaved samples of 1 or 2 bytes (unsigned): per channel
+ * (left * fl + right * fr).astype(uint8) - uint8 output whatever the input width, like the reference
+ * (projection.py:447-460).  idx2_dev / weights2_dev as written by pb_index_map_i32 / pb_index_from_map_i32. */
+int pb_gather_blend_u8(const int32_t* idx2_dev, const double* weights2_dev, const void* src_dev, uint8_t* dst_dev,
+                       size_t n_px, int channels, int sample_bytes, void* stream);
 
 /* map_projection (projection.py:550-599): coordinate map -> colour map (red = latitude stretched to
  * 0..255 over the valid pixels, green = longitude * 255 / 2pi, blue = invalid * 255).  Zeroes invalid

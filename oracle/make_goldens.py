@@ -10,6 +10,7 @@ under tests/golden/:
   small.npz       G2-G6  per case: f_distance bits, rotation matrices, integer
                   source-index map, uint8 output on the synthetic frame, fragile
                   mask, and (for keep_map cases) the float64 coordinate maps
+  mid.json        1-2 k pixel pins for the lenses / degenerate geometries the BASELINE configs do not touch
   full.json       G7  full-size pins for the BASELINE configs: SHA-256 of the
                   index map and of the uint8 output, 65 536 seeded samples,
                   valid-pixel and distinct-texel counts
@@ -35,8 +36,9 @@ sys.path.insert(0, "/root/reference")
 import numpy as np  # noqa: E402
 
 from oracle import reference_path as orc  # noqa: E402
-from oracle.synth import synth_frame  # noqa: E402
-from tests.cases import Case, full_cases, small_cases  # noqa: E402
+from oracle.synth import synth_frame, synth_image  # noqa: E402
+from tests import cases as tc  # noqa: E402
+from tests.cases import Case, full_cases, mid_cases, small_cases  # noqa: E402
 
 import photonbend.core.lens as ref_lens  # noqa: E402
 from photonbend.core.projection import CameraImage, DoubleCameraImage, PanoramaImage  # noqa: E402
@@ -48,13 +50,21 @@ warnings.simplefilter("ignore")
 np.seterr(all="ignore")
 
 
+def ref_lens_obj(lens):
+    if lens == "custom":
+        return ref_lens.Lens(tc.custom_forward, tc.custom_reverse)
+    if lens == "thobylike":
+        return ref_lens.Lens(tc.thoby_like_forward, tc.thoby_like_reverse)
+    return getattr(ref_lens, lens)()
+
+
 def ref_obj(p, image=None):
     kind, h, w, lens, fov, mag = p
     if image is None:
         image = np.zeros((h, w, 3), np.uint8)
     if kind == "pano":
         return PanoramaImage(image)
-    L = getattr(ref_lens, lens)()
+    L = ref_lens_obj(lens)
     if kind == "camera":
         return CameraImage(image, to_radians(fov), L, magnitude=mag)
     return DoubleCameraImage(image, to_radians(fov), L)
@@ -183,6 +193,31 @@ def gen_mapproj():
     print("mapproj.npz written,", len(out), "cases")
 
 
+def gen_generic():
+    """Images beyond uint8 RGB, user lenses, more than eight rotations, odd-width double frames: the REFERENCE's
+    outputs for tests/cases.py generic_cases (it fancy-indexes whatever array it is given, projection.py:234-243)."""
+    out = {}
+    for name, case, layout in tc.generic_cases():
+        _, cmap, _, _ = ref_map(case)
+        kind, h, w, *_ = case.src
+        img = synth_image(h, w, layout, frame=3, circle_mask=case.mask)
+        res = ref_obj(case.src, img).process_coordinate_map(np.copy(cmap))
+        out[name] = res
+        print(f"  {name}: {img.dtype}{img.shape} -> {res.dtype}{res.shape}")
+    # utils.calculate_size_panorama_to_photo (utils/__init__.py:81-118)
+    from photonbend.utils import calculate_size_panorama_to_photo
+
+    sizes = []
+    for lname in ("equidistant", "equisolid", "stereographic", "orthographic", "thoby"):
+        for wh in ((8192, 4096), (6144, 3072), (1000, 500), (2, 1)):
+            for vert in (False, True):
+                sizes.append((lname, wh[0], wh[1], int(vert), *calculate_size_panorama_to_photo(wh, getattr(ref_lens, lname)().forward_function, vert)))
+    with open(os.path.join(GOLD, "size_rule.json"), "w") as f:  # Python ints: the orthographic vertical rule overflows int64
+        json.dump([[r[0], *map(int, r[1:])] for r in sizes], f)
+    np.savez_compressed(os.path.join(GOLD, "generic.npz"), **out)
+    print("generic.npz written,", len(out), "arrays")
+
+
 def gen_cli():
     """f-2: the reference's own CLI (click CliRunner) on small synthetic PNGs -> output pixel arrays."""
     import tempfile
@@ -194,14 +229,20 @@ def gen_cli():
 
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for name, cmd, opts, (h, w, mask) in cli_cases():
+        for name, cmd, opts, spec in cli_cases():
+            h, w, mask, layout = (*spec, "RGB")[:4]
             inp, outp = os.path.join(tmp, name + "_in.png"), os.path.join(tmp, name + "_out.png")
-            Image.fromarray(synth_frame(h, w, frame=5, seed=0, circle_mask=mask)).save(inp)
+            Image.fromarray(synth_image(h, w, layout, frame=5, circle_mask=mask)).save(inp)
             # argument order differs per command only in where OUTPUT sits; click accepts options anywhere
             res = CliRunner().invoke(ref_main, [cmd, inp, *opts, outp])
+            if res.exception is not None and not isinstance(res.exception, SystemExit):
+                # the reference CLI itself rejects the input (grey images: "height, width, _ = shape"): pin the exception type
+                out[name] = np.array("raises:" + type(res.exception).__name__)
+                print(f"  {name}: reference raises {type(res.exception).__name__}: {res.exception}")
+                continue
             assert res.exit_code == 0, (name, res.output, res.exception)
             out[name] = np.asarray(Image.open(outp))
-            print(f"  {name}: {out[name].shape}")
+            print(f"  {name}: {out[name].dtype}{out[name].shape}")
     np.savez_compressed(os.path.join(GOLD, "cli.npz"), **out)
     print("cli.npz written,", len(out), "cases")
 
@@ -232,6 +273,40 @@ def gen_real():
     with open(os.path.join(GOLD, "c1_real.json"), "w") as f:
         json.dump(pin, f)
     print("c1_real.json written", out.shape, h)
+
+
+def gen_mid():
+    """1-2 k pixel pins (tests/cases.py mid_cases): hashes, samples and counts from the REAL reference, the oracle
+    asserted equal on every pixel, and the size of the fragile set (pre-truncation coordinate within 2^-40 of an
+    integer) - the only pixels where a last-bit libm difference may legitimately flip a truncation."""
+    pins = {}
+    for case in mid_cases():
+        dst, cmap, _, mats = ref_map(case)
+        kind, h, w, *_ = case.src
+        frame = synth_frame(h, w, frame=0, seed=0, circle_mask=case.mask)
+        src = ref_obj(case.src, frame)
+        idx = ref_index(case, cmap)
+        u8 = src.process_coordinate_map(np.copy(cmap))
+        od, os_ = orc_proj(case.dst), orc_proj(case.src)
+        rots = [tuple(map(to_radians, r)) for r in case.rotations]
+        assert np.array_equal(orc.remap_index(od, os_, rots), idx), case.name
+        assert np.array_equal(orc.remap(od, os_, frame, rots), u8), case.name
+        fragile = orc.fragile_mask(orc.pretrunc(od, os_, rots))
+        H, W = u8.shape[:2]
+        pos = np.random.default_rng(777).integers(0, H * W, size=4096)
+        pins[case.name] = {
+            "dst": list(case.dst), "src": list(case.src), "rotations": [list(r) for r in case.rotations], "mask": case.mask,
+            "idx_sha256": sha(idx), "u8_sha256": sha(u8), "frame_sha256": sha(frame), "sample_seed": 777,
+            "idx_samples": [int(v) for v in idx.ravel()[pos[:1024]]],
+            "u8_samples": [int(v) for v in u8.reshape(-1, 3)[pos[:1024]].ravel()],
+            "in_bounds_samples": int((idx >= 0).sum()),
+            "fragile_pixels": int(fragile.sum()),
+            "fragile_sha256": sha(np.packbits(fragile)),
+        }
+        print(f"  {case.name}: {H}x{W}, in-bounds {pins[case.name]['in_bounds_samples']}, fragile {pins[case.name]['fragile_pixels']}")
+    with open(os.path.join(GOLD, "mid.json"), "w") as f:
+        json.dump(pins, f, indent=1)
+    print("mid.json written")
 
 
 def gen_full():
@@ -293,13 +368,19 @@ if __name__ == "__main__":
     ap.add_argument("--mapproj", action="store_true")
     ap.add_argument("--cli", action="store_true")
     ap.add_argument("--real", action="store_true")
+    ap.add_argument("--mid", action="store_true")
+    ap.add_argument("--generic", action="store_true")
     a = ap.parse_args()
-    everything = not (a.lens or a.small or a.full or a.mapproj or a.cli or a.real)
+    everything = not (a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic)
     os.makedirs(GOLD, exist_ok=True)
     if a.lens or everything:
         gen_lens()
     if a.small or everything:
         gen_small()
+    if a.mid or everything:
+        gen_mid()
+    if a.generic or everything:
+        gen_generic()
     if a.full or everything:
         gen_full()
     if a.mapproj or everything:

@@ -50,3 +50,21 @@ def circle_mask_u8(height: int, width: int, mode: int) -> np.ndarray:
         xs = 2 * xl + 1 - half
         d = min(height, half)
     return ((ys[:, None] ** 2 + xs[None, :] ** 2) <= d * d).astype(np.uint8)
+
+
+def synth_image(height: int, width: int, layout: str = "RGB", frame: int = 0, circle_mask: int = 0) -> np.ndarray:
+    """Synthetic images in the layouts Pillow hands to the reference unconverted: "RGB" uint8 (H, W, 3), "RGBA" uint8
+    (H, W, 4), "L" uint8 (H, W), "I;16" uint16 (H, W), "RGB16" uint16 (H, W, 3) - built from synth_frame planes."""
+    a = synth_frame(height, width, frame=frame, circle_mask=circle_mask)
+    b = synth_frame(height, width, frame=frame + 1000, circle_mask=circle_mask)
+    if layout == "RGB":
+        return a
+    if layout == "RGBA":
+        return np.ascontiguousarray(np.concatenate([a, b[:, :, :1]], axis=2))
+    if layout == "L":
+        return np.ascontiguousarray(a[:, :, 0])
+    if layout == "I;16":
+        return a[:, :, 0].astype(np.uint16) | (b[:, :, 0].astype(np.uint16) << 8)
+    if layout == "RGB16":
+        return a.astype(np.uint16) | (b.astype(np.uint16) << 8)
+    raise KeyError(layout)

@@ -31,6 +31,7 @@ LENS_IDS = {
     "orthographic": 4,
     "thoby": 5,
 }
+LENS_CUSTOM = 6  # a Lens of user callables: the host evaluates it (pb_index_from_map_i32's distance planes)
 
 
 class PbError(RuntimeError):
@@ -79,6 +80,9 @@ SIGNATURES = {
     "pb_coordmap_f64": (C.c_int, [C.POINTER(pb_proj), _VP, _VP]),
     "pb_rotate_f64": (C.c_int, [C.POINTER(C.c_double), _VP, _VP, C.c_int, C.c_int, _VP]),
     "pb_sample_map_u8": (C.c_int, [C.POINTER(pb_proj), _VP, C.c_int, C.c_int, _VP, _VP, _VP]),
+    "pb_index_from_map_i32": (C.c_int, [C.POINTER(pb_proj), _VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP]),
+    "pb_gather_px": (C.c_int, [_VP, _VP, _VP, C.c_size_t, C.c_int, _VP]),
+    "pb_gather_blend_u8": (C.c_int, [_VP, _VP, _VP, _VP, C.c_size_t, C.c_int, C.c_int, _VP]),
     "pb_map_projection_u8": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP]),
     "pb_synth_frame_u8": (C.c_int, [_VP, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, _VP]),
     "pb_malloc": (C.c_int, [C.POINTER(_VP), C.c_size_t]),
@@ -299,6 +303,43 @@ def sample_map(src: pb_proj, cmap: torch.Tensor, image: torch.Tensor) -> torch.T
     out = torch.empty((cmap.shape[0], cmap.shape[1], 3), dtype=torch.uint8, device=cmap.device)
     with torch.cuda.device(cmap.device):
         check(load().pb_sample_map_u8(C.byref(src), cmap.data_ptr(), cmap.shape[0], cmap.shape[1], image.data_ptr(), out.data_ptr(), current_stream()))
+    return out
+
+
+def index_from_map(src: pb_proj, cmap: torch.Tensor, dist_l: torch.Tensor | None = None, dist_r: torch.Tensor | None = None):
+    """cmap (H, W, 3) float64 cuda -> (int32 indices (H, W) or (2, H, W) for a double source, float64 weights (2, H, W) or None).
+    Zeroes invalid lat/lon in cmap for a panorama source, like the reference."""
+    require_gpu()
+    H, W = cmap.shape[0], cmap.shape[1]
+    double = src.kind == KIND_DOUBLE
+    idx = torch.empty((2, H, W) if double else (H, W), dtype=torch.int32, device=cmap.device)
+    w = torch.empty((2, H, W), dtype=torch.float64, device=cmap.device) if double else None
+    for d in (dist_l, dist_r):
+        if d is not None and not (d.is_cuda and d.dtype == torch.float64 and d.is_contiguous() and d.numel() == H * W and d.device == cmap.device):
+            raise PbError("distance planes must be contiguous float64 CUDA tensors of the map's size on the map's device")
+    with torch.cuda.device(cmap.device):
+        check(load().pb_index_from_map_i32(C.byref(src), cmap.data_ptr(), H, W, dist_l.data_ptr() if dist_l is not None else None,
+                                           dist_r.data_ptr() if dist_r is not None else None, idx.data_ptr(), w.data_ptr() if w is not None else None, current_stream()))
+    return idx, w
+
+
+def gather_px(idx: torch.Tensor, img_bytes: torch.Tensor) -> torch.Tensor:
+    """idx int32 (H, W), img_bytes uint8 (h, w, bpp) -> uint8 (H, W, bpp): src[idx] or zeros where idx < 0."""
+    require_gpu()
+    bpp = img_bytes.shape[2]
+    out = torch.empty((idx.shape[0], idx.shape[1], bpp), dtype=torch.uint8, device=idx.device)
+    with torch.cuda.device(idx.device):
+        check(load().pb_gather_px(idx.data_ptr(), img_bytes.data_ptr(), out.data_ptr(), idx.numel(), bpp, current_stream()))
+    return out
+
+
+def gather_blend(idx2: torch.Tensor, w2: torch.Tensor, img_bytes: torch.Tensor, channels: int, sample_bytes: int) -> torch.Tensor:
+    """The double-fisheye blend of arbitrary-width images: uint8 (H * W * channels)."""
+    require_gpu()
+    n = idx2.shape[1] * idx2.shape[2]
+    out = torch.empty(n * channels, dtype=torch.uint8, device=idx2.device)
+    with torch.cuda.device(idx2.device):
+        check(load().pb_gather_blend_u8(idx2.data_ptr(), w2.data_ptr(), img_bytes.data_ptr(), out.data_ptr(), n, channels, sample_bytes, current_stream()))
     return out
 
 

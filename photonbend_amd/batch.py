@@ -22,7 +22,7 @@ def plan_for(dst_image, rotations, src_image) -> nat.Plan:
     """The plan of ``src_image.process_coordinate_map(rotations(dst_image.get_coordinate_map()))``.
     ``rotations``: sequence of ``Rotation`` objects (or 3x3 matrices), applied in order."""
     mats = [getattr(r, "rotation_matrix", r) for r in rotations]
-    return _plan_for(dst_image._proj(), mats, src_image._proj())
+    return _plan_for(dst_image._proj("dst"), mats, src_image._proj("src"))
 
 
 from .utils.hostcopy import par_copy as _par_copy

@@ -30,6 +30,13 @@ class CoordinateMap:
         self._array = None
         self._zero_invalid = False  # a later stage zeroed invalid lat/lon "in place"
 
+    @classmethod
+    def from_array(cls, dst_proj: nat.pb_proj, array: np.ndarray) -> "CoordinateMap":
+        """A map that is an ndarray from the start (a destination whose lens the host evaluated)."""
+        m = cls(dst_proj)
+        m._array = np.ascontiguousarray(array, dtype=np.float64)
+        return m
+
     # -- recipe ---------------------------------------------------------------------
     @property
     def is_lazy(self) -> bool:

@@ -223,61 +223,148 @@ class ProjectionImage(Protocol):
         ...
 
 
+def _image_info(image):
+    """(height, width, trailing shape, numpy dtype) of an image array or tensor.  The reference fancy-indexes whatever
+    array it is given (projection.py:234-243, :545-546): grey (H, W), RGB, RGBA (H, W, 4), 8- or 16-bit samples."""
+    shp = tuple(int(v) for v in image.shape)
+    if len(shp) < 2:
+        raise ValueError("an image needs at least (height, width)")
+    if isinstance(image, torch.Tensor):
+        dt = torch.empty(0, dtype=image.dtype).numpy().dtype
+    else:
+        dt = np.asarray(image).dtype
+    return shp[0], shp[1], shp[2:], np.dtype(dt)
+
+
+def _device_bytes(image, device=None) -> torch.Tensor:
+    """The image's pixels as a contiguous uint8 CUDA tensor (h, w, bytes per pixel)."""
+    nat.require_gpu()
+    h, w, tail, dt = _image_info(image)
+    bpp = int(np.prod(tail, dtype=np.int64)) * dt.itemsize
+    if isinstance(image, torch.Tensor):
+        t = image if image.is_cuda else image.cuda()
+        return t.contiguous().view(torch.uint8).reshape(h, w, bpp)
+    a = np.ascontiguousarray(image)
+    return _upload(a.view(np.uint8).reshape(h, w, bpp), device)
+
+
 class _GpuProjection:
     """Shared GPU plumbing of the three projection classes."""
 
     image: Union[np.ndarray, torch.Tensor]
 
-    def _proj(self) -> nat.pb_proj:  # pragma: no cover - overridden
+    def _proj(self, role: str = "src") -> nat.pb_proj:  # pragma: no cover - overridden
         raise NotImplementedError
 
     def get_coordinate_map(self) -> CoordinateMap:
-        """This image's coordinate map, as a lazy recipe (see ``CoordinateMap``)."""
-        return CoordinateMap(self._proj())
+        """This image's coordinate map, as a lazy recipe (see ``CoordinateMap``).  A destination whose lens is made
+        of user callables gets a materialised map: ``reverse_function`` runs on the host over the exact radius mesh
+        (lens.py:48-64, projection.py:186-189), everything around it on the GPU."""
+        proj = self._proj("dst")
+        if proj.kind != nat.KIND_PANO and proj.lens == nat.LENS_CUSTOM:
+            return CoordinateMap.from_array(proj, self._custom_coordinate_map(proj))
+        return CoordinateMap(proj)
+
+    # -- the sampling half, for everything the fused uint8 RGB kernel does not take ------------------------------
+    def _source_distances(self, lat: np.ndarray):  # pragma: no cover - overridden by the camera classes
+        raise NotImplementedError
+
+    def _index_from_map(self, src: nat.pb_proj, dev_map: torch.Tensor):
+        """int32 source indices (and float64 weights for a double source) of a materialised map on the device."""
+        dl = dr = None
+        if src.kind != nat.KIND_PANO and src.lens == nat.LENS_CUSTOM:
+            # forward_function is host Python by definition: latitude plane down, distances up (projection.py:251)
+            lat = dev_map[..., 0].contiguous().cpu().numpy()
+            planes = self._source_distances(lat)
+            dl = torch.from_numpy(np.ascontiguousarray(planes[0], dtype=np.float64)).to(dev_map.device)
+            if src.kind == nat.KIND_DOUBLE:
+                dr = torch.from_numpy(np.ascontiguousarray(planes[1], dtype=np.float64)).to(dev_map.device)
+        return nat.index_from_map(src, dev_map, dl, dr)
+
+    def _gather(self, src: nat.pb_proj, idx: torch.Tensor, weights, img_bytes: torch.Tensor, tail, dt: np.dtype):
+        """index map -> output pixels, any channel count / sample width; returns a CUDA tensor of the output dtype."""
+        H, W = (idx.shape[-2], idx.shape[-1])
+        if src.kind == nat.KIND_DOUBLE:
+            if len(tail) != 1:
+                # the reference multiplies (H, W) samples by an (H, W, 1) factor map: NumPy cannot broadcast that
+                raise ValueError(f"operands could not be broadcast together with shapes ({H},{W}) ({H},{W},1)")
+            if dt not in (np.dtype(np.uint8), np.dtype(np.uint16)):
+                raise NotImplementedError(f"the double-fisheye blend takes uint8 or uint16 images, got {dt}")
+            out = nat.gather_blend(idx, weights, img_bytes, tail[0], dt.itemsize)  # uint8, like .astype(np.uint8)
+            return out.reshape(H, W, tail[0])
+        out = nat.gather_px(idx, img_bytes)
+        tdt = torch.from_numpy(np.empty(0, dt)).dtype
+        return out.view(tdt).reshape((H, W) + tuple(tail))
 
     def process_coordinate_map(self, coordinate_map, interpolation: str = "nearest"):
-        """Maps this image's pixels through ``coordinate_map`` and returns the new
-        uint8 image (projection.py:197-245, :408-462, :515-547).
+        """Maps this image's pixels through ``coordinate_map`` and returns the new image
+        (projection.py:197-245, :408-462, :515-547).
+
+        uint8 (H, W, 3) images with built-in lenses take the fused kernel (one launch, no map in memory); any other
+        image the reference accepts - grey (H, W), RGBA, 16-bit samples - and sources whose lens is made of user
+        callables go through the integer index map and a gather (same indices, same bytes as the reference).
 
         ``interpolation="bilinear"`` is an opt-in extension with no reference counterpart (the reference
-        truncates to the nearest pixel): lazy maps and camera / panorama sources only."""
-        src = self._proj()
+        truncates to the nearest pixel): lazy maps and uint8 RGB images only."""
+        src = self._proj("src")
+        h, w, tail, dt = _image_info(self.image)
+        rgb8 = tail == (3,) and dt == np.dtype(np.uint8)
+        custom_src = src.kind != nat.KIND_PANO and src.lens == nat.LENS_CUSTOM
+        lazy = isinstance(coordinate_map, CoordinateMap) and coordinate_map.is_lazy
         if interpolation != "nearest":
             if interpolation != "bilinear":
                 raise ValueError("interpolation must be 'nearest' or 'bilinear'")
-            if not (isinstance(coordinate_map, CoordinateMap) and coordinate_map.is_lazy):
+            if not lazy:
                 raise NotImplementedError("bilinear sampling needs a lazy coordinate map (a recipe), not a materialised array")
+            if not rgb8 or custom_src:
+                raise NotImplementedError("bilinear sampling takes uint8 (H, W, 3) images and built-in lenses")
         on_device = isinstance(self.image, torch.Tensor)
-        img = _device_image(self.image, src.height, src.width)
-        if isinstance(coordinate_map, CoordinateMap) and coordinate_map.is_lazy:
+        fused = rgb8 and not custom_src
+        img = _device_image(self.image, h, w) if fused else _device_bytes(self.image)
+        dev = img.device
+        too_many = lazy and len(coordinate_map.rotations) > nat.PB_MAX_ROTATIONS
+        if lazy and not too_many and not custom_src:
             # bilinear taps come from the tile models: that mode needs the prepared plan from the first use on
-            plan = _plan_for(coordinate_map.dst_proj, coordinate_map.rotations, src, device=img.device, eager=interpolation != "nearest")
-            out = plan.remap(img, interpolation=interpolation)
+            plan = _plan_for(coordinate_map.dst_proj, coordinate_map.rotations, src, device=dev, eager=interpolation != "nearest")
+            if fused:
+                out = plan.remap(img, interpolation=interpolation)
+            else:
+                idx, wts = plan.index_map(weights=True, device=dev) if src.kind == nat.KIND_DOUBLE else (plan.index_map(device=dev), None)
+                out = self._gather(src, idx, wts, img, tail, dt)
             if src.kind == nat.KIND_PANO:
                 coordinate_map.note_invalid_zeroed()  # projection.py:534-536
             return out if on_device else _to_host(out)
+        # a materialised map: the caller's tensor / ndarray, or a recipe that has to become one (more rotations than one
+        # fused plan takes: the reference accepts any number of -r options; a source lens evaluated on the host)
+        host = None
         if isinstance(coordinate_map, torch.Tensor):
-            _check_map_tensor(coordinate_map, img.device)
-            out = nat.sample_map(src, coordinate_map, img)
-            return out if on_device else _to_host(out)
-        host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
-        if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
-            raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
-        dev = torch.from_numpy(np.ascontiguousarray(host)).to(img.device)
-        out = nat.sample_map(src, dev, img)
-        if src.kind == nat.KIND_PANO:
-            host[...] = dev.cpu().numpy()  # the in-place zeroing of invalid pixels
+            _check_map_tensor(coordinate_map, dev)
+            dmap = coordinate_map
+        elif lazy:
+            with torch.cuda.device(dev):
+                dmap = coordinate_map.device_tensor()
+            if src.kind == nat.KIND_PANO:
+                coordinate_map.note_invalid_zeroed()
+        else:
+            host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
+            if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
+                raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
+            dmap = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+        if fused:
+            out = nat.sample_map(src, dmap, img)
+        else:
+            idx, wts = self._index_from_map(src, dmap)
+            out = self._gather(src, idx, wts, img, tail, dt)
+        if host is not None and src.kind == nat.KIND_PANO:
+            host[...] = dmap.cpu().numpy()  # the in-place zeroing of invalid pixels
         return out if on_device else _to_host(out)
 
 
-def _builtin_lens_id(lens: Lens) -> int:
-    lid = lens_id(lens)
-    if lid is None:
-        raise NotImplementedError(
-            "the GPU remap path knows the built-in lenses only (equidistant, equisolid, rectilinear, "
-            "stereographic, orthographic, thoby); a Lens made of arbitrary Python callables cannot run in a HIP kernel"
-        )
-    return lid
+def _role_lens_id(lens: Lens, role: str) -> int:
+    """pb_lens id of the function the role uses: a destination inverts (reverse_function), a source projects
+    (forward_function).  A user callable gets PB_LENS_CUSTOM: the host evaluates it (lens.py:48-64)."""
+    lid = lens_id(lens.reverse_function if role == "dst" else lens.forward_function)
+    return nat.LENS_CUSTOM if lid is None else lid
 
 
 class CameraImage(_GpuProjection):
@@ -300,9 +387,25 @@ class CameraImage(_GpuProjection):
         raises what the lens raises (rectilinear beyond 178 degrees)."""
         return self.magnitude / self.forward_lens(self.fov / 2)
 
-    def _proj(self) -> nat.pb_proj:
+    def _proj(self, role: str = "src") -> nat.pb_proj:
         h, w = _shape_hw(self.image)
-        return nat.make_proj(nat.KIND_CAMERA, h, w, _builtin_lens_id(self._lens), self.fov, self.magnitude, self.f_distance)
+        return nat.make_proj(nat.KIND_CAMERA, h, w, _role_lens_id(self._lens, role), self.fov, self.magnitude, self.f_distance)
+
+    def _custom_coordinate_map(self, proj: nat.pb_proj) -> np.ndarray:
+        """get_coordinate_map for a user reverse_function (projection.py:147-194).  The radius mesh
+        sqrt(x^2 + y^2) / f_distance is IEEE-exact arithmetic: it comes from the device as the latitude plane of
+        the equidistant lens (whose inverse is the identity), the longitudes with it; the callable and the
+        validity rule run here."""
+        eq = nat.make_proj(nat.KIND_CAMERA, proj.height, proj.width, nat.LENS_IDS["equidistant"], proj.fov, proj.magnitude, proj.f_distance)
+        m = nat.coordmap(eq).cpu().numpy()
+        lat = np.asarray(self.reverse_lens(m[:, :, 0].copy()), dtype=np.float64)
+        m[:, :, 0] = lat
+        with np.errstate(invalid="ignore"):
+            m[:, :, 2] = (lat > self.fov / 2).astype(np.float64)  # projection.py:160 (NaN compares False: valid)
+        return m
+
+    def _source_distances(self, lat: np.ndarray):
+        return (self.forward_lens(lat) * self.f_distance,)  # projection.py:251
 
 
 class DoubleCameraImage(_GpuProjection):
@@ -325,9 +428,34 @@ class DoubleCameraImage(_GpuProjection):
     def _compute_f_distance(self) -> float:
         return self.magnitude / self.forward_lens(self.sensor_fov / 2)
 
-    def _proj(self) -> nat.pb_proj:
+    def _proj(self, role: str = "src") -> nat.pb_proj:
         h, w = _shape_hw(self.image)
-        return nat.make_proj(nat.KIND_DOUBLE, h, w, _builtin_lens_id(self.lens), self.sensor_fov, self.magnitude, self.f_distance)
+        if role == "dst":
+            w = 2 * (w // 2)  # the reference's map of an odd-width double frame has 2 * (W // 2) columns (projection.py:389-397)
+        return nat.make_proj(nat.KIND_DOUBLE, h, w, _role_lens_id(self.lens, role), self.sensor_fov, self.magnitude, self.f_distance)
+
+    def _custom_coordinate_map(self, proj: nat.pb_proj) -> np.ndarray:
+        """get_coordinate_map for a user reverse_function (projection.py:341-406): the two eyes share one radius mesh
+        (the right eye's x axis is the left one negated), taken from the device like CameraImage's."""
+        half = proj.width // 2
+        eq = nat.LENS_IDS["equidistant"]
+        dist = nat.coordmap(nat.make_proj(nat.KIND_CAMERA, proj.height, half, eq, proj.fov, proj.magnitude, proj.f_distance))[:, :, 0].cpu().numpy()
+        m = nat.coordmap(nat.make_proj(nat.KIND_DOUBLE, proj.height, proj.width, eq, proj.fov, proj.magnitude, proj.f_distance)).cpu().numpy()
+        lat = np.asarray(self.reverse_lens(np.concatenate([dist, dist], axis=1)), dtype=np.float64)
+        lat[:, half:] *= -1
+        lat[:, half:] += np.pi
+        with np.errstate(invalid="ignore"):
+            invalid = lat > self.sensor_fov / 2.0
+            invalid[:, half:] = lat[:, half:] < np.pi - (self.sensor_fov / 2.0)
+        m[:, :, 0] = lat
+        m[:, :, 2] = invalid.astype(np.float64)
+        return m
+
+    def _source_distances(self, lat: np.ndarray):
+        lat_r = lat.copy()
+        lat_r *= -1
+        lat_r += np.pi  # projection.py:425-427
+        return self.forward_lens(lat.copy()) * self.f_distance, self.forward_lens(lat_r) * self.f_distance
 
 
 class PanoramaImage(_GpuProjection):
@@ -336,7 +464,7 @@ class PanoramaImage(_GpuProjection):
     def __init__(self, image_arr) -> None:
         self.image = image_arr
 
-    def _proj(self) -> nat.pb_proj:
+    def _proj(self, role: str = "src") -> nat.pb_proj:
         h, w = _shape_hw(self.image)
         return nat.make_proj(nat.KIND_PANO, h, w)
 

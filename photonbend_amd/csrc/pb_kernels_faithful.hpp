@@ -212,6 +212,107 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_sample_map_kernel(const PbParams 
     o[2] = (uint8_t)((v >> 16) & 0xFF);
 }
 
+// ---- generic images and user lenses (drop-in completeness; off the hot path) ------------------------------------
+// map -> integer source index (+ blend weights for a double source): the sampling half of process_coordinate_map
+// (projection.py:197-260, :408-462, :515-547) without the gather, so that images of any channel count / sample
+// width can be gathered by index (pb_gather_px_kernel) - the reference fancy-indexes whatever array it is given.
+// dist_l / dist_r (optional): the per-pixel fisheye radius forward_lens(latitude) * f_distance evaluated by the
+// HOST for a Lens made of Python callables (lens.py:48-64); they replace the built-in forward lens.
+__device__ __forceinline__ bool pb_src_camera_pos_d(double dist, double lon, int h, int w, double cy, double cx, int& py, int& px) {
+    double sl, cl;
+    sincos(lon, &sl, &cl);
+    const double re = cl * dist, im = sl * dist;
+    const long long y = pb_cvt_i64((im * -1.0) + cy);
+    const long long x = pb_cvt_i64(re + cx);
+    if (y >= h || y < 0 || x >= w || x < 0) return false;
+    py = (int)y;
+    px = (int)x;
+    return true;
+}
+
+template <int SRC_KIND>
+__global__ __launch_bounds__(PB_BLOCK) void pb_index_from_map_kernel(const PbParams P, double* __restrict__ map, unsigned total,
+                                                                     const double* __restrict__ dist_l, const double* __restrict__ dist_r,
+                                                                     int32_t* __restrict__ out, double* __restrict__ wout) {
+    const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    double* a = map + 3ull * p;
+    PbCoord c;
+    c.inv = a[2] != 0.0;
+    if (SRC_KIND == PB_KIND_PANO && c.inv) {
+        a[0] = 0.0;  // polar_map[invalid_map] = 0 writes through the view, projection.py:534-536
+        a[1] = 0.0;
+    }
+    c.lat = a[0];
+    c.lon = a[1];
+    if (SRC_KIND == PB_KIND_PANO) {
+        out[p] = pb_src_pano_index(P, c);
+    } else if (SRC_KIND == PB_KIND_CAMERA) {
+        if (dist_l) {
+            int py, px;
+            const bool ok = pb_src_camera_pos_d(dist_l[p], c.lon, P.src.height, P.src.width, P.src_cy, P.src_cx, py, px);
+            out[p] = (ok && !c.inv) ? py * P.src.width + px : -1;
+        } else {
+            out[p] = pb_src_camera_index(P, c);
+        }
+    } else {
+        PbDoubleTap t;
+        if (dist_l) {
+            int py, px;
+            bool ok = pb_src_camera_pos_d(dist_l[p], c.lon, P.src.height, P.src_eye_w, P.src_cy, P.src_cx, py, px);
+            t.il = (ok && !c.inv) ? py * P.src.width + px : -1;
+            ok = pb_src_camera_pos_d(dist_r[p], c.lon, P.src.height, P.src_eye_w_right, P.src_cy, P.src_cx_r, py, px);
+            t.ir = (ok && !c.inv) ? py * P.src.width + (P.src_eye_w + (P.src_eye_w_right - 1 - px)) : -1;
+            t.fl = pb_merge_factor(P, c.lat);
+            t.fr = pb_merge_factor(P, (c.lat * -1.0) + PB_PI);
+        } else {
+            t = pb_src_double_taps(P, c);
+        }
+        out[p] = t.il;
+        out[(size_t)total + p] = t.ir;
+        if (wout) {
+            wout[p] = t.fl;
+            wout[(size_t)total + p] = t.fr;
+        }
+    }
+}
+
+// out[p] = idx[p] < 0 ? zeros : src[idx[p]], bpp bytes per pixel (new_image = image[positions]; new_image[bad] = 0,
+// projection.py:234-243, :545-546) - any channel count, any sample width
+__global__ __launch_bounds__(PB_BLOCK) void pb_gather_px_kernel(const int32_t* __restrict__ idx, const uint8_t* __restrict__ src,
+                                                                uint8_t* __restrict__ dst, unsigned long long total, int bpp) {
+    const unsigned long long p = (unsigned long long)blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    const int id = idx[p];
+    uint8_t* o = dst + p * (unsigned)bpp;
+    if (id < 0) {
+        for (int b = 0; b < bpp; ++b) o[b] = 0;
+    } else {
+        const uint8_t* s = src + (unsigned long long)(unsigned)id * (unsigned)bpp;
+        for (int b = 0; b < bpp; ++b) o[b] = s[b];
+    }
+}
+
+// the double-fisheye blend for any channel count and 8 / 16-bit samples: (left * fl + right * fr).astype(np.uint8)
+// per channel (projection.py:447-460) - the output is uint8 whatever the input width, like the reference's
+template <typename SAMPLE>
+__global__ __launch_bounds__(PB_BLOCK) void pb_gather_blend_kernel(const int32_t* __restrict__ idx2, const double* __restrict__ w2,
+                                                                   const SAMPLE* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                   unsigned long long total, int channels) {
+    const unsigned long long p = (unsigned long long)blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    const int il = idx2[p], ir = idx2[total + p];
+    const double fl = w2[p], fr = w2[total + p];
+    uint8_t* o = dst + p * (unsigned)channels;
+    for (int c = 0; c < channels; ++c) {
+        const double l = il < 0 ? 0.0 : (double)src[(unsigned long long)(unsigned)il * (unsigned)channels + c];
+        const double r = ir < 0 ? 0.0 : (double)src[(unsigned long long)(unsigned)ir * (unsigned)channels + c];
+        // final_image[invalid_map] = 0 (projection.py:460): an invalid destination pixel has both taps -1 -> 0 * f = 0
+        // (NaN / inf factors give NaN, which the cast turns into 0 as well)
+        o[c] = (uint8_t)pb_cvt_u8(l * fl + r * fr);
+    }
+}
+
 __device__ __forceinline__ uint32_t pb_mix32(uint32_t h) {
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;

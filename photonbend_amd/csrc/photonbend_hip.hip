@@ -74,7 +74,8 @@ static int pb_fail(int code, const std::string& msg) {
 // ----------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------
-static bool pb_end_ok(const pb_proj* p, std::string& why) {
+enum { PB_ROLE_DST = 1, PB_ROLE_SRC = 2, PB_ROLE_CUSTOM_OK = 4 };
+static bool pb_end_ok(const pb_proj* p, std::string& why, int role = PB_ROLE_DST | PB_ROLE_SRC) {
     if (!p) {
         why = "null pb_proj";
         return false;
@@ -83,16 +84,24 @@ static bool pb_end_ok(const pb_proj* p, std::string& why) {
         why = "pb_proj.kind out of range";
         return false;
     }
-    if (p->kind != PB_KIND_PANO && (p->lens < PB_LENS_EQUIDISTANT || p->lens > PB_LENS_THOBY)) {
-        why = "pb_proj.lens out of range";
+    if (p->kind != PB_KIND_PANO && (p->lens < PB_LENS_EQUIDISTANT || p->lens > PB_LENS_THOBY) &&
+        !((role & PB_ROLE_CUSTOM_OK) && p->lens == PB_LENS_CUSTOM)) {
+        why = p->lens == PB_LENS_CUSTOM ? "PB_LENS_CUSTOM is valid only where the host supplies the lens values (pb_index_from_map_i32 with distance planes)"
+                                        : "pb_proj.lens out of range";
         return false;
     }
     if (p->height < 1 || p->width < 1 || (long long)p->height * p->width > 0x7FFFFFFFll / 4) {
         why = "pb_proj height/width out of range (need 1 <= h*w < 2^29)";
         return false;
     }
-    if (p->kind == PB_KIND_DOUBLE && (p->width & 1)) {
-        why = "a double-fisheye frame needs an even width";
+    if (p->kind == PB_KIND_DOUBLE && (p->width & 1) && (role & PB_ROLE_DST)) {
+        // the reference's map of an odd-width double DESTINATION is 2 * (W // 2) wide (projection.py:389-397): pass that width;
+        // an odd-width double SOURCE is fine (eyes of W // 2 and W - W // 2 columns, projection.py:429-431)
+        why = "a double-fisheye destination needs an even width (the reference's map is 2 * (W // 2) wide)";
+        return false;
+    }
+    if (p->kind == PB_KIND_DOUBLE && p->width < 2) {
+        why = "a double-fisheye frame needs at least two columns";
         return false;
     }
     return true;
@@ -502,7 +511,7 @@ int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const
     std::string why;
     if (!out) return pb_fail(PB_ERR_INVALID, "null out pointer");
     *out = nullptr;
-    if (!pb_end_ok(dst, why) || !pb_end_ok(src, why)) return pb_fail(PB_ERR_INVALID, why);
+    if (!pb_end_ok(dst, why, PB_ROLE_DST) || !pb_end_ok(src, why, PB_ROLE_SRC)) return pb_fail(PB_ERR_INVALID, why);
     if (n_rot < 0 || n_rot > PB_MAX_ROTATIONS) return pb_fail(PB_ERR_INVALID, "n_rot outside [0, PB_MAX_ROTATIONS]");
     if (n_rot > 0 && !rot3x3) return pb_fail(PB_ERR_INVALID, "null rotation matrices");
     if (flags & ~(unsigned)(PB_PLAN_DEFER | PB_PLAN_TUNE)) return pb_fail(PB_ERR_INVALID, "unknown plan flags");
@@ -787,7 +796,7 @@ int pb_plan_info(const pb_plan* plan, int* fast_path_enabled, long long* stats7,
 int pb_coordmap_f64(const pb_proj* dst, double* map_dev, void* stream) {
     std::string why;
     if (!map_dev) return pb_fail(PB_ERR_INVALID, "null argument");
-    if (!pb_end_ok(dst, why)) return pb_fail(PB_ERR_INVALID, why);
+    if (!pb_end_ok(dst, why, PB_ROLE_DST)) return pb_fail(PB_ERR_INVALID, why);
     PbParams P;
     memset(&P, 0, sizeof(P));
     P.dst = pb_to_end(dst);
@@ -817,7 +826,7 @@ int pb_sample_map_u8(const pb_proj* src, double* map_dev, int height, int width,
                      uint8_t* dst_dev, void* stream) {
     std::string why;
     if (!map_dev || !src_dev || !dst_dev) return pb_fail(PB_ERR_INVALID, "null argument");
-    if (!pb_end_ok(src, why)) return pb_fail(PB_ERR_INVALID, why);
+    if (!pb_end_ok(src, why, PB_ROLE_SRC)) return pb_fail(PB_ERR_INVALID, why);
     if (height < 1 || width < 1 || (long long)height * width > 0x7FFFFFFFll / 4)
         return pb_fail(PB_ERR_INVALID, "map size out of range");
     PbParams P;
@@ -842,6 +851,71 @@ int pb_sample_map_u8(const pb_proj* src, double* map_dev, int height, int width,
             hipLaunchKernelGGL(pb_sample_map_kernel<PB_KIND_DOUBLE>, dim3(pb_blocks(total)), dim3(PB_BLOCK), 0, st, P,
                                map_dev, total, src_dev, dst_dev);
     }
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+int pb_index_from_map_i32(const pb_proj* src, double* map_dev, int height, int width, const double* dist_l_dev, const double* dist_r_dev,
+                          int32_t* idx_dev, double* weights_dev, void* stream) {
+    std::string why;
+    if (!map_dev || !idx_dev) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (!pb_end_ok(src, why, PB_ROLE_SRC | PB_ROLE_CUSTOM_OK)) return pb_fail(PB_ERR_INVALID, why);
+    if (height < 1 || width < 1 || (long long)height * width > 0x7FFFFFFFll / 4) return pb_fail(PB_ERR_INVALID, "map size out of range");
+    if (src->kind != PB_KIND_PANO && src->lens == PB_LENS_CUSTOM && !dist_l_dev)
+        return pb_fail(PB_ERR_INVALID, "a PB_LENS_CUSTOM source needs the host-evaluated distance plane(s)");
+    if (src->kind == PB_KIND_DOUBLE && dist_l_dev && !dist_r_dev) return pb_fail(PB_ERR_INVALID, "a double source needs both distance planes");
+    if (src->kind == PB_KIND_PANO && (dist_l_dev || dist_r_dev)) return pb_fail(PB_ERR_INVALID, "a panorama source has no lens");
+    PbParams P;
+    memset(&P, 0, sizeof(P));
+    P.src = pb_to_end(src);
+    P.dst = P.src;
+    P.dst.kind = PB_KIND_PANO;  // only the source half of the parameters is used
+    P.dst.height = height;
+    P.dst.width = width;
+    pb_derive(P);
+    const unsigned total = (unsigned)height * (unsigned)width;
+    hipStream_t st = (hipStream_t)stream;
+    switch (P.src.kind) {
+        case PB_KIND_PANO:
+            hipLaunchKernelGGL(pb_index_from_map_kernel<PB_KIND_PANO>, dim3(pb_blocks(total)), dim3(PB_BLOCK), 0, st, P, map_dev, total, dist_l_dev,
+                               dist_r_dev, idx_dev, weights_dev);
+            break;
+        case PB_KIND_CAMERA:
+            hipLaunchKernelGGL(pb_index_from_map_kernel<PB_KIND_CAMERA>, dim3(pb_blocks(total)), dim3(PB_BLOCK), 0, st, P, map_dev, total, dist_l_dev,
+                               dist_r_dev, idx_dev, weights_dev);
+            break;
+        default:
+            hipLaunchKernelGGL(pb_index_from_map_kernel<PB_KIND_DOUBLE>, dim3(pb_blocks(total)), dim3(PB_BLOCK), 0, st, P, map_dev, total, dist_l_dev,
+                               dist_r_dev, idx_dev, weights_dev);
+    }
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+int pb_gather_px(const int32_t* idx_dev, const void* src_dev, void* dst_dev, size_t n_px, int bytes_per_px, void* stream) {
+    if (!idx_dev || !src_dev || !dst_dev) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (bytes_per_px < 1 || bytes_per_px > 64) return pb_fail(PB_ERR_INVALID, "bytes_per_px outside [1, 64]");
+    if (n_px > 0x7FFFFFFFull) return pb_fail(PB_ERR_INVALID, "too many pixels");
+    if (!n_px) return PB_OK;
+    hipLaunchKernelGGL(pb_gather_px_kernel, dim3(pb_blocks(n_px)), dim3(PB_BLOCK), 0, (hipStream_t)stream, idx_dev,
+                       static_cast<const uint8_t*>(src_dev), static_cast<uint8_t*>(dst_dev), (unsigned long long)n_px, bytes_per_px);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+int pb_gather_blend_u8(const int32_t* idx2_dev, const double* weights2_dev, const void* src_dev, uint8_t* dst_dev, size_t n_px, int channels,
+                       int sample_bytes, void* stream) {
+    if (!idx2_dev || !weights2_dev || !src_dev || !dst_dev) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (channels < 1 || channels > 16) return pb_fail(PB_ERR_INVALID, "channels outside [1, 16]");
+    if (sample_bytes != 1 && sample_bytes != 2) return pb_fail(PB_ERR_UNSUPPORTED, "the double-fisheye blend takes 8- or 16-bit unsigned samples");
+    if (n_px > 0x7FFFFFFFull) return pb_fail(PB_ERR_INVALID, "too many pixels");
+    if (!n_px) return PB_OK;
+    if (sample_bytes == 1)
+        hipLaunchKernelGGL(pb_gather_blend_kernel<uint8_t>, dim3(pb_blocks(n_px)), dim3(PB_BLOCK), 0, (hipStream_t)stream, idx2_dev, weights2_dev,
+                           static_cast<const uint8_t*>(src_dev), dst_dev, (unsigned long long)n_px, channels);
+    else
+        hipLaunchKernelGGL(pb_gather_blend_kernel<uint16_t>, dim3(pb_blocks(n_px)), dim3(PB_BLOCK), 0, (hipStream_t)stream, idx2_dev, weights2_dev,
+                           static_cast<const uint16_t*>(src_dev), dst_dev, (unsigned long long)n_px, channels);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }

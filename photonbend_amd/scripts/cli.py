@@ -65,13 +65,11 @@ def checked_output(path: Path) -> Path:
     return out
 
 
-def open_rgb(path: Path) -> np.ndarray:
-    """Decoded pixels as uint8 (H, W, 3) (commands/__init__.py:135-143).  The GPU core is RGB-only, so
-    other Pillow modes are converted to RGB first."""
+def open_image(path: Path) -> np.ndarray:
+    """The decoded pixels exactly as Pillow hands them over (commands/__init__.py:135-143): RGB, RGBA, grey
+    ("L" -> (H, W)), 16-bit - nothing is converted, the remap gathers whatever the array holds, like the reference."""
     try:
         with Image.open(path) as im:
-            if im.mode != "RGB":
-                im = im.convert("RGB")
             return np.asarray(im)
     except IOError:
         print("Error: Input image could not be opened!")
@@ -83,7 +81,7 @@ def magnitude_for(image_type: str, shape: Sequence[int]) -> float:
     """Pixels from the centre to where the full fov is reached (commands/__init__.py:91-109)."""
     if len(shape) > 3:
         raise ValueError("Can't calculate magnitude of images with more than 3 dimensions")
-    height, width = shape[0], shape[1]
+    height, width, _ = shape  # like the reference (:96): a grey (H, W) array does not unpack - ValueError
     if image_type == "double":
         return height / 2 - 0.5
     if image_type == "full":
@@ -157,7 +155,8 @@ def make_photo(input_image, otype, lens, fov, output_image, rotation, size):
     OUTPUT is the desired path of the destiny photo.
     """
     out = checked_output(output_image)
-    pano = open_rgb(input_image)
+    pano = open_image(input_image)
+    _, _, _ = pano.shape  # make_photo.py:112 unpacks three dimensions: grey inputs are a ValueError in the reference CLI
     shape = camera_shape(otype, pano, size)
     destiny = camera_object(otype, np.zeros(shape, np.uint8), radians_fov(fov, otype), lens, magnitude_for(otype, shape))
     run_chain(PanoramaImage(pano), destiny, rotation, out)
@@ -181,7 +180,7 @@ def alter_photo(input_image, itype, ilens, ifov, otype, olens, ofov, output_imag
     OUTPUT is the desired path of the destiny photo.
     """
     out = checked_output(output_image)
-    photo = open_rgb(input_image)
+    photo = open_image(input_image)
     source = camera_object(itype, photo, radians_fov(ifov, itype), ilens, magnitude_for(itype, photo.shape))
     shape = camera_shape(otype, photo, size)
     # the destination magnitude comes from the SOURCE shape (alter_photo.py:142): only visible when --size differs
@@ -204,7 +203,7 @@ def make_pano(input_image, itype, lens, fov, output_image, rotation, size):
     OUTPUT is the desired path of the destiny panorama.
     """
     out = checked_output(output_image)
-    photo = open_rgb(input_image)
+    photo = open_image(input_image)
     source = camera_object(itype, photo, radians_fov(fov, itype), lens, magnitude_for(itype, photo.shape))
     h = photo.shape[0] if size is None else size
     destiny = PanoramaImage(np.zeros((h, int(h * 2), 3), np.uint8))  # make_pano.py:142-149

@@ -109,11 +109,84 @@ def full_cases() -> List[Case]:
     ]
 
 
+def mid_cases() -> List[Case]:
+    """1-2 k pixel reference pins (tests/golden/mid.json): the lenses BASELINE's configs do not touch, in both
+    directions with a rotation - sizes at which the windowed hot kernel runs hundreds of LEAN / DIRECT tiles - and
+    the degenerate identity / near-identity remaps whose pre-truncation coordinates sit on integers."""
+    cs: List[Case] = []
+    for lens, fov in (("stereographic", 200), ("orthographic", 170), ("thoby", 180)):
+        cs.append(Case(f"M_photo_{lens}", cam(1280, 1280, lens, fov, inscribed(1280)), pano(1024, 2048), [(12, -30, 7)]))
+        cs.append(Case(f"M_pano_{lens}", pano(768, 1536), cam(1280, 1280, lens, fov, inscribed(1280)), [(5, 60, -20)], mask=1))
+    cs.append(Case("M_photo_rectilinear", cam(1024, 1536, "rectilinear", 120, full_frame(1024, 1536)), pano(1024, 2048), [(12, -30, 7)]))
+    cs.append(Case("M_pano_rectilinear", pano(768, 1536), cam(1024, 1536, "rectilinear", 120, full_frame(1024, 1536)), [(5, 60, -20)]))
+    cs.append(Case("M_alter_ste_thoby", cam(1152, 1152, "thoby", 190, inscribed(1152)), cam(1280, 1280, "stereographic", 220, inscribed(1280)), [(-8, 15, 100)], mask=1))
+    # identity and near-identity: every pre-truncation coordinate is (near) an integer, the truncated index follows the
+    # last bit of cos / sin / atan2 - the reference's own output is rounding noise there (SURVEY 7 hard part 3)
+    cs.append(Case("M_ident_eqd", cam(768, 768, "equidistant", 180, inscribed(768)), cam(768, 768, "equidistant", 180, inscribed(768)), mask=1))
+    cs.append(Case("M_ident_pano", pano(512, 1024), pano(512, 1024)))
+    cs.append(Case("M_near_eqs", cam(640, 640, "equisolid", 180, inscribed(640)), cam(768, 768, "equisolid", 180, inscribed(768)), mask=1))
+    cs.append(Case("M_ident_eqd_rot0", cam(768, 768, "equidistant", 180, inscribed(768)), cam(768, 768, "equidistant", 180, inscribed(768)), [(0, 0, 0)], mask=1))
+    return cs
+
+
 def case_by_name(name: str) -> Case:
-    for c in small_cases() + full_cases():
+    for c in small_cases() + full_cases() + mid_cases():
         if c.name == name:
             return c
     raise KeyError(name)
+
+
+# ---- images and lenses beyond uint8 RGB + built-ins (tests/golden/generic.npz) ------------------------------
+def custom_forward(theta):  # a user lens: NOT one of the six built-ins (thoby has 1.47 / 0.713)
+    import numpy as np
+
+    return 1.3 * np.sin(0.8 * theta)
+
+
+def custom_reverse(r):
+    import numpy as np
+
+    return np.arcsin(r / 1.3) / 0.8
+
+
+def thoby_like_forward(theta):  # the built-in thoby formulas as user callables: must reproduce the built-in's bytes
+    import numpy as np
+
+    return 1.47 * np.sin(0.713 * theta)
+
+
+def thoby_like_reverse(r):
+    import numpy as np
+
+    return np.arcsin(r / 1.47) / 0.713
+
+
+def generic_cases():
+    """(name, Case, layout).  Lens name "custom" / "thobylike" = a Lens built from the callables above; layout = the
+    source image's array layout (oracle.synth.synth_image)."""
+    rot = [(10, 20, 30)]
+    nine = [(5.0 * k, -7.0 * k, 3.0 * k + 1) for k in range(1, 10)]
+    out = []
+    for layout in ("RGBA", "L", "RGB16", "I;16"):
+        out.append((f"G_pano_{layout}", Case("g", cam(40, 40, "equisolid", 190, inscribed(40)), pano(32, 64), rot), layout))
+    out.append(("G_cam_RGBA", Case("g", pano(32, 64), cam(48, 48, "equidistant", 360, inscribed(48)), mask=1), "RGBA"))
+    out.append(("G_cam_I;16", Case("g", pano(32, 64), cam(48, 48, "stereographic", 200, inscribed(48)), rot, mask=1), "I;16"))
+    out.append(("G_double_RGBA", Case("g", pano(32, 64), dbl(40, 80, "equidistant", 195), mask=2), "RGBA"))
+    out.append(("G_double_RGB16", Case("g", pano(32, 64), dbl(40, 80, "equidistant", 200), rot, mask=2), "RGB16"))
+    out.append(("G_double_src_odd", Case("g", pano(32, 64), dbl(40, 81, "equidistant", 195), mask=2), "RGB"))
+    out.append(("G_double_src_odd_rot", Case("g", cam(36, 36, "equidistant", 180, inscribed(36)), dbl(40, 79, "equisolid", 200), rot, mask=2), "RGB"))
+    out.append(("G_double_dst_odd", Case("g", dbl(32, 65, "equidistant", 195), pano(48, 96)), "RGB"))
+    out.append(("G_rot9", Case("g", cam(40, 40, "equidistant", 200, inscribed(40)), pano(32, 64), nine), "RGB"))
+    out.append(("G_rot9_double_gray", Case("g", pano(24, 48), cam(40, 40, "equisolid", 190, inscribed(40)), nine, mask=1), "L"))
+    out.append(("G_custom_dst", Case("g", cam(40, 40, "custom", 170, inscribed(40)), pano(32, 64), rot), "RGB"))
+    out.append(("G_custom_src", Case("g", pano(32, 64), cam(48, 48, "custom", 170, inscribed(48)), rot, mask=1), "RGB"))
+    out.append(("G_custom_src_norot_RGBA", Case("g", pano(32, 64), cam(48, 48, "custom", 175, inscribed(48)), mask=1), "RGBA"))
+    out.append(("G_custom_double_src", Case("g", pano(32, 64), dbl(40, 80, "custom", 195), mask=2), "RGB"))
+    out.append(("G_custom_double_dst", Case("g", dbl(32, 64, "custom", 190), pano(48, 96), rot), "RGB"))
+    out.append(("G_custom_both", Case("g", cam(40, 40, "custom", 160, inscribed(40)), cam(48, 48, "custom", 170, inscribed(48)), rot, mask=1), "I;16"))
+    out.append(("G_thobylike_dst", Case("g", cam(40, 40, "thobylike", 180, inscribed(40)), pano(32, 64), rot), "RGB"))
+    out.append(("G_thobylike_src", Case("g", pano(32, 64), cam(48, 48, "thobylike", 180, inscribed(48)), mask=1), "RGB"))
+    return out
 
 
 def cli_cases():
@@ -131,4 +204,9 @@ def cli_cases():
         ("alter_eqd_eqs_rot", "alter-photo", ["--itype", "inscribed", "--ilens", "equidistant", "--ifov", "360", "--otype", "inscribed", "--olens", "equisolid", "--ofov", "360", "-r", "30", "45", "10"], (64, 64, 1)),
         ("alter_size_quirk", "alter-photo", ["--itype", "inscribed", "--ilens", "equidistant", "--ifov", "180", "--otype", "full", "--olens", "rectilinear", "--ofov", "100", "-s", "40"], (64, 64, 1)),
         ("alter_double_in", "alter-photo", ["--itype", "double", "--ilens", "equidistant", "--ifov", "200", "--otype", "inscribed", "--olens", "equidistant", "--ofov", "180"], (48, 96, 2)),
+        # inputs that are not RGB: the reference hands Pillow's array over unconverted (commands/__init__.py:135-143)
+        ("photo_rgba", "make-photo", ["--type", "inscribed", "--lens", "equisolid", "--fov", "200", "-s", "60", "-r", "10", "20", "30"], (64, 128, 0, "RGBA")),
+        ("pano_gray", "make-pano", ["--type", "inscribed", "--lens", "equidistant", "--fov", "360", "-s", "40"], (72, 72, 1, "L")),
+        ("pano_gray16", "make-pano", ["--type", "inscribed", "--lens", "stereographic", "--fov", "200", "-r", "15", "-40", "5"], (60, 60, 1, "I;16")),
+        ("alter_rgba_double_in", "alter-photo", ["--itype", "double", "--ilens", "equidistant", "--ifov", "200", "--otype", "inscribed", "--olens", "equidistant", "--ofov", "180"], (48, 96, 2, "RGBA")),
     ]

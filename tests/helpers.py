@@ -52,7 +52,16 @@ def pb_obj(p, image=None):
         image = np.zeros((h, w, 3), np.uint8)
     if kind == "pano":
         return pb.PanoramaImage(image)
-    L = getattr(pb, lens)()
+    if lens == "custom":
+        from tests import cases as tc
+
+        L = pb.Lens(tc.custom_forward, tc.custom_reverse)
+    elif lens == "thobylike":
+        from tests import cases as tc
+
+        L = pb.Lens(tc.thoby_like_forward, tc.thoby_like_reverse)
+    else:
+        L = getattr(pb, lens)()
     if kind == "camera":
         return pb.CameraImage(image, pb.utils.to_radians(fov), L, magnitude=mag)
     return pb.DoubleCameraImage(image, pb.utils.to_radians(fov), L)

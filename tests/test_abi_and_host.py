@@ -46,7 +46,15 @@ def test_abi_argument_validation_without_gpu():
     assert b"kind" in lib.pb_last_error()
     assert lib.pb_plan_create(ctypes.byref(good), None, 9, ctypes.byref(good), ctypes.byref(h)) == -1
     odd = nat.make_proj(nat.KIND_DOUBLE, 4, 9)
-    assert lib.pb_plan_create(ctypes.byref(good), None, 0, ctypes.byref(odd), ctypes.byref(h)) == -1
+    # an odd-width double DESTINATION is an error (the reference's map has 2 * (W // 2) columns: the host passes that);
+    # an odd-width double SOURCE is fine (eyes of W // 2 and W - W // 2 columns, projection.py:429-431)
+    assert lib.pb_plan_create(ctypes.byref(odd), None, 0, ctypes.byref(good), ctypes.byref(h)) == -1
+    assert b"even width" in lib.pb_last_error()
+    assert lib.pb_plan_create(ctypes.byref(good), None, 0, ctypes.byref(odd), ctypes.byref(h)) == 0
+    lib.pb_plan_destroy(h)
+    custom = nat.make_proj(nat.KIND_CAMERA, 8, 8, nat.LENS_CUSTOM, 3.0, 3.5, 2.0)
+    assert lib.pb_plan_create(ctypes.byref(good), None, 0, ctypes.byref(custom), ctypes.byref(h)) == -1
+    assert b"PB_LENS_CUSTOM" in lib.pb_last_error()
     assert lib.pb_plan_create(ctypes.byref(good), None, 0, ctypes.byref(good), ctypes.byref(h)) == 0
     hh, ww = ctypes.c_int(), ctypes.c_int()
     assert lib.pb_plan_dst_shape(h, ctypes.byref(hh), ctypes.byref(ww)) == 0 and (hh.value, ww.value) == (4, 8)
@@ -86,10 +94,15 @@ def test_error_behaviour_mirrors_reference():
     d = pb.DoubleCameraImage(np.zeros((8, 16, 3), np.uint8), 3.3, pb.equidistant(), magnitude=99.0)
     assert d.magnitude == 4.0
     assert pb.CameraImage(z, 3.0, pb.equidistant()).magnitude == 4.0  # default: height / 2.0
+    # a Lens of user callables is accepted like in the reference (lens.py:48-64); its map needs the GPU for the mesh
     custom = pb.Lens(lambda t: t * 1.01, lambda r: r / 1.01)
     cam = pb.CameraImage(z, 3.0, custom)
-    with pytest.raises(NotImplementedError):
-        cam.get_coordinate_map()
+    assert cam.f_distance == 4.0 / (1.5 * 1.01)
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(nat.PbError):  # no CPU path behind the user's back
+            cam.get_coordinate_map()
 
 
 def test_lazy_coordinate_map_recipe():

@@ -10,7 +10,7 @@ import pytest
 from click.testing import CliRunner
 from PIL import Image
 
-from oracle.synth import synth_frame
+from oracle.synth import synth_frame, synth_image
 from photonbend_amd.scripts import cli
 from tests import helpers as H
 from tests.cases import cli_cases
@@ -54,14 +54,18 @@ def test_output_suffix_and_overwrite_prompt(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", cli_cases(), ids=lambda c: c[0])
 def test_cli_matches_reference_cli(case, tmp_path):
-    name, cmd, opts, (h, w, mask) = case
+    name, cmd, opts, spec = case
+    h, w, mask, layout = (*spec, "RGB")[:4]
     gold = np.load(os.path.join(H.GOLD, "cli.npz"))[name]
     inp, outp = tmp_path / "in.png", tmp_path / "out.png"
-    Image.fromarray(synth_frame(h, w, frame=5, seed=0, circle_mask=mask)).save(inp)
+    Image.fromarray(synth_image(h, w, layout, frame=5, circle_mask=mask)).save(inp)
     res = CliRunner().invoke(cli.main, [cmd, str(inp), *opts, str(outp)])
+    if gold.dtype.kind == "U":  # the reference CLI rejects this input: so must ours, with the same exception type
+        assert str(gold).startswith("raises:") and type(res.exception).__name__ == str(gold)[7:], (res.output, res.exception)
+        return
     assert res.exit_code == 0, (res.output, res.exception)
     got = np.asarray(Image.open(outp))
-    assert got.shape == gold.shape and got.dtype == np.uint8
+    assert got.shape == gold.shape and got.dtype == gold.dtype  # RGBA stays RGBA: nothing is converted
     d = np.abs(got.astype(np.int16) - gold.astype(np.int16))
     d = np.minimum(d, 256 - d)
     if "double" in " ".join(opts) and cmd != "make-photo":

@@ -51,6 +51,15 @@ def test_full_size_pins(case):
         assert bad == 0, f"{bad} of 2048 sampled indices differ"
         assert int((flat >= 0).sum()) == pin["in_bounds_samples"]
         assert sha(idx) == pin["idx_sha256"], "index map differs somewhere (samples and counts agree)"
+    if case.src[0] != "double":
+        # the same index map, taken from the WINDOWED hot kernel (the kernel bench.py times): source pixels that
+        # encode their own linear index come out as the indices the kernel sampled
+        from tests.test_hip_mid import index_through_windowed_kernel
+
+        widx = index_through_windowed_kernel(plan, case.src[1], case.src[2])
+        assert torch.equal(widx, idx), f"{int((widx != idx).sum())} pixels: windowed kernel and index-map launch disagree"
+        assert sha(widx) == pin["idx_sha256"]
+        del widx
     del idx
     # the uint8 output on the synthetic frame generated ON THE DEVICE
     _, h, w, *_ = case.src

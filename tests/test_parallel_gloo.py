@@ -76,3 +76,67 @@ def test_shard_range_partition(n, world):
     assert sum(parts, []) == list(range(n))
     sizes = [len(p) for p in parts]
     assert max(sizes) - min(sizes) <= 1
+
+
+# ---- two ranks that really remap (one GPU shared by both processes, collectives over gloo) ------------------
+N_FRAMES = 11
+
+
+def _two_rank_projs():
+    fov = pb.utils.to_radians(200)
+    dst = pb.CameraImage(np.zeros((352, 320, 3), np.uint8), fov, pb.equisolid(), magnitude=159.5)
+    rots = [pb.Rotation(0.3, -0.7, 0.2).rotation_matrix]
+    return dst._proj(), rots, nat.make_proj(nat.KIND_PANO, 256, 512)
+
+
+def _remap_worker(rank, world, port, q):
+    import hashlib
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d, rots, s = _two_rank_projs()
+        if rank != 0:  # rank 0's parameters must win: everyone else starts from a different rotation
+            rots = [pb.Rotation(1.0, 1.0, 1.0).rotation_matrix]
+        load = lambda i: nat.synth_frame(256, 512, frame=i, seed=0)
+        ids, outs = parallel.remap_batch_sharded(d, rots, s, load, N_FRAMES, device="cpu", chunk=4)
+        sha = lambda t: hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest()
+        # every rank also remaps frames 0 and N-1 itself: the same frame on another rank must give the same bytes
+        block = parallel.pack_params(d, rots, s) if rank == 0 else None
+        dd, rr, ss = parallel.unpack_params(parallel.broadcast_params(block, device="cpu"))
+        plan = nat.Plan(dd, rr, ss)
+        extra = {i: sha(plan.remap(load(i))) for i in (0, N_FRAMES - 1)}
+        q.put((rank, ids, [sha(o) for o in outs], extra, plan.info()["fast_path"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_remap_a_sharded_batch_byte_identically():
+    """two processes (sharing this box's one GPU, gloo collectives) broadcast the parameter
+    block, each builds and certifies its own plan and remaps its contiguous share of 11 frames.  The union equals the
+    single-process result byte for byte, and a frame remapped by rank 1 equals the same frame remapped by rank 0."""
+    import hashlib
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_remap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, ids0, sh0, ex0, fast0), (r1, ids1, sh1, ex1, fast1) = res
+    assert (r0, r1) == (0, 1) and fast0 and fast1
+    assert ids0 + ids1 == list(range(N_FRAMES)) and len(ids0) == 6
+    # single-process truth, through the facade objects
+    d, rots, s = _two_rank_projs()
+    plan = nat.Plan(d, rots, s)
+    want = [hashlib.sha256(plan.remap(nat.synth_frame(256, 512, frame=i, seed=0)).cpu().numpy().tobytes()).hexdigest() for i in range(N_FRAMES)]
+    assert sh0 + sh1 == want, "the sharded union differs from the single-process result"
+    assert ex0 == ex1 == {0: want[0], N_FRAMES - 1: want[-1]}, "a frame must not depend on the rank that remaps it"
