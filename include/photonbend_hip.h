@@ -162,7 +162,9 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
 /* OPT-IN extension with no reference counterpart (the reference samples nearest-by-truncation only):
  * bilinear interpolation at the reference's pre-truncation coordinate (pixel k covers [k, k+1), centre
  * k + 0.5; taps clamped to the image, panorama columns wrap; round half to even).  Pixels the nearest mode
- * paints black stay black.  Camera and panorama sources only (PB_ERR_UNSUPPORTED for double-fisheye sources). */
+ * paints black stay black.  A double-fisheye source is the reference's blend (projection.py:439-460) of the two eyes'
+ * bilinear samples (each eye sampled like a camera source on its half, rounded to uint8, then blended and cast as the
+ * nearest mode does); that combination runs the float64 chain per pixel. */
 int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames,
                          size_t src_frame_stride, size_t dst_frame_stride, void* stream);
 

@@ -432,27 +432,11 @@ def map_projection(cmap: np.ndarray) -> np.ndarray:
     return np.stack([red, green, blue], axis=2)
 
 
-def remap_bilinear(dst: Proj, src: Proj, image: np.ndarray, rotations=()) -> np.ndarray:
-    """OUR definition of the opt-in bilinear mode (SURVEY 8 f-4) - the reference has no such behaviour, so this
-    function is "parity unpinned": it pins the HIP kernels to a written-down definition, not to the reference.
-
-    The continuous source coordinate is the reference's pre-truncation coordinate f (pixel k covers [k, k+1),
-    centre k + 0.5); s = f - 0.5, i0 = floor(s), t = s - i0; taps clamped to the image (panorama columns wrap),
-    float64 weights, round half to even.  Black where the nearest mode is black."""
-    if src.kind == "double":
-        raise NotImplementedError("bilinear sampling does not support double-fisheye sources")
-    cmap = coordinate_map(dst)
-    for rot in rotations:
-        cmap = rotate_map(rotation_matrix(*rot), cmap)
-    invalid = cmap[:, :, 2] != 0.0
-    h, w = src.height, src.width
+def _bilinear_camera(p: Proj, h: int, w: int, image: np.ndarray, lat, lon, invalid):
+    """One fisheye (or one eye of a double frame) sampled bilinearly -> (uint8 values, live mask)."""
     with np.errstate(all="ignore"):
-        if src.kind == "pano":
-            _, _, _, fy, fx = pano_positions(h, w, cmap)
-            live = ~invalid & np.isfinite(fy) & np.isfinite(fx)
-        else:
-            _, _, fy, fx = camera_positions(src, h, w, cmap[:, :, 0], cmap[:, :, 1])
-            live = ~invalid & np.isfinite(fy) & np.isfinite(fx) & (fy >= 0) & (fy < h) & (fx >= 0) & (fx < w)
+        _, _, fy, fx = camera_positions(p, h, w, lat, lon)
+        live = ~invalid & np.isfinite(fy) & np.isfinite(fx) & (fy >= 0) & (fy < h) & (fx >= 0) & (fx < w)
         fy = np.where(live, fy, 0.5)
         fx = np.where(live, fx, 0.5)
         sy, sx = fy - 0.5, fx - 0.5
@@ -461,10 +445,56 @@ def remap_bilinear(dst: Proj, src: Proj, image: np.ndarray, rotations=()) -> np.
         ty, tx = (sy - r0)[..., None], (sx - c0)[..., None]
         r1, c1 = r0 + 1, c0 + 1
         r0, r1 = np.clip(r0, 0, h - 1), np.clip(r1, 0, h - 1)
-        if src.kind == "pano":
-            c0, c1 = np.clip(c0 % w, 0, w - 1), np.clip(c1 % w, 0, w - 1)
-        else:
-            c0, c1 = np.clip(c0, 0, w - 1), np.clip(c1, 0, w - 1)
+        c0, c1 = np.clip(c0, 0, w - 1), np.clip(c1, 0, w - 1)
+        img = image.astype(np.float64)
+        top = img[r0, c0] + tx * (img[r0, c1] - img[r0, c0])
+        bot = img[r1, c0] + tx * (img[r1, c1] - img[r1, c0])
+        val = np.clip(np.rint(top + ty * (bot - top)), 0, 255).astype(np.uint8)
+    val[~live] = 0
+    return val, live
+
+
+def remap_bilinear(dst: Proj, src: Proj, image: np.ndarray, rotations=()) -> np.ndarray:
+    """OUR definition of the opt-in bilinear mode (SURVEY 8 f-4) - the reference has no such behaviour, so this
+    function is "parity unpinned": it pins the HIP kernels to a written-down definition, not to the reference.
+
+    The continuous source coordinate is the reference's pre-truncation coordinate f (pixel k covers [k, k+1),
+    centre k + 0.5); s = f - 0.5, i0 = floor(s), t = s - i0; taps clamped to the image (panorama columns wrap),
+    float64 weights, round half to even.  Black where the nearest mode is black.  A double-fisheye source is the
+    reference's blend (projection.py:439-460) of the two eyes' bilinear uint8 samples, each eye sampled like a camera
+    source on its half of the frame (the right eye on the mirrored half)."""
+    cmap = coordinate_map(dst)
+    for rot in rotations:
+        cmap = rotate_map(rotation_matrix(*rot), cmap)
+    invalid = cmap[:, :, 2] != 0.0
+    h, w = src.height, src.width
+    if src.kind == "double":
+        left, right, w2 = _double_sides(src)
+        lat = cmap[:, :, 0]
+        fl, fr, lat_r = double_weights(src, lat)
+        l, _ = _bilinear_camera(left, h, w2, image[:, :w2], lat, cmap[:, :, 1], invalid)
+        r, _ = _bilinear_camera(right, h, w - w2, np.copy(image[:, w2:])[:, ::-1], lat_r, cmap[:, :, 1], invalid)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with np.errstate(all="ignore"):
+                out = (l.astype(np.float64) * fl[..., None] + r.astype(np.float64) * fr[..., None]).astype(np.uint8)
+        out[invalid] = 0
+        return out
+    if src.kind == "camera":
+        val, _ = _bilinear_camera(src, h, w, image, cmap[:, :, 0], cmap[:, :, 1], invalid)
+        return val
+    with np.errstate(all="ignore"):
+        _, _, _, fy, fx = pano_positions(h, w, cmap)
+        live = ~invalid & np.isfinite(fy) & np.isfinite(fx)
+        fy = np.where(live, fy, 0.5)
+        fx = np.where(live, fx, 0.5)
+        sy, sx = fy - 0.5, fx - 0.5
+        r0 = np.floor(sy).astype(np.int64)
+        c0 = np.floor(sx).astype(np.int64)
+        ty, tx = (sy - r0)[..., None], (sx - c0)[..., None]
+        r1, c1 = r0 + 1, c0 + 1
+        r0, r1 = np.clip(r0, 0, h - 1), np.clip(r1, 0, h - 1)
+        c0, c1 = np.clip(c0 % w, 0, w - 1), np.clip(c1 % w, 0, w - 1)
         img = image.astype(np.float64)
         top = img[r0, c0] + tx * (img[r0, c1] - img[r0, c0])
         bot = img[r1, c0] + tx * (img[r1, c1] - img[r1, c0])

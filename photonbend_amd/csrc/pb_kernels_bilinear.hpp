@@ -6,7 +6,10 @@
 // coordinate f (pixel k covers [k, k+1), centre k + 0.5).  s = f - 0.5, i0 = floor(s), t = s - i0; the four taps
 // (i0, i0 + 1) x (j0, j0 + 1) are clamped to the image (pano columns wrap), weights (1-t, t); the channel value is
 // rounded half-to-even.  Pixels the nearest mode paints black (invalid destination pixel, camera source position
-// outside [0, h) x [0, w)) stay black.  Double-fisheye sources are not supported in this mode.
+// outside [0, h) x [0, w)) stay black.  A double-fisheye source is the reference's own blend (projection.py:439-460) of
+// the two eyes' BILINEAR samples: each eye is sampled like a camera source on its half of the frame (the right eye on
+// the mirrored half, taps clamped to the eye), rounded to uint8, then (l * fl + r * fr).astype(uint8) with the
+// reference's factors - pb_bilinear_double_kernel, float64 coordinates per pixel.
 //
 //   pb_bilinear_hot_kernel   modelled tiles: float32 tile models give f (error ~1e-5 px, no fix list needed: there
 //                            is no truncation to protect), exact integer validity thresholds; LEAN tiles read their
@@ -238,15 +241,27 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(con
 }
 
 // float64 faithful coordinates; mode 0: the plan's failed tiles (4 blocks each), mode 1: every pixel (no plan state)
+// mode 0 also takes the plan's fix list (blocks beyond the failed tiles): a pixel is on it because the model's index
+// differs from the faithful one - mostly a coordinate a hair from an integer, harmless here, but also the genuine
+// discontinuities a polynomial cannot follow inside an otherwise modelled tile (the edge of a lens inverse's domain,
+// a validity or image boundary): those pixels take the float64 coordinates like the failed tiles.
 template <int SRC_KIND>
 __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_fix_kernel(const PbParams P, const int32_t* __restrict__ fail_tiles,
                                                                    int all_pixels, const uint8_t* __restrict__ src,
                                                                    uint8_t* __restrict__ dst, int n_frames,
-                                                                   unsigned long long src_stride, unsigned long long dst_stride) {
+                                                                   unsigned long long src_stride, unsigned long long dst_stride,
+                                                                   int n_fail_tiles = 0, const int32_t* __restrict__ fix_px = nullptr,
+                                                                   int n_fix_px = 0) {
     int i, j;
     if (all_pixels) {
         const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
         if (p >= (unsigned)P.dst.height * (unsigned)P.dst.width) return;
+        i = p / (unsigned)P.dst.width;
+        j = p - (unsigned)i * (unsigned)P.dst.width;
+    } else if ((int)blockIdx.x >= 4 * n_fail_tiles && fix_px) {
+        const unsigned item = (blockIdx.x - 4u * (unsigned)n_fail_tiles) * PB_BLOCK + threadIdx.x;
+        if (item >= (unsigned)n_fix_px) return;
+        const unsigned p = (unsigned)fix_px[item];
         i = p / (unsigned)P.dst.width;
         j = p - (unsigned)i * (unsigned)P.dst.width;
     } else {
@@ -271,6 +286,64 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_fix_kernel(const PbParam
         unsigned v = 0;
         if (live) v = pb_bilinear_taps<SRC_KIND>(P, src + (unsigned long long)f * src_stride, (float)(sy - by), (float)(sx - bx), by, bx);
         uint8_t* o = dst + (unsigned long long)f * dst_stride + 3 * p;
+        o[0] = (uint8_t)(v & 0xFF);
+        o[1] = (uint8_t)((v >> 8) & 0xFF);
+        o[2] = (uint8_t)((v >> 16) & 0xFF);
+    }
+}
+
+// ---- double-fisheye source (faithful float64 coordinates per pixel; an opt-in mode off the hot path) ----------------
+// one eye's bilinear sample (0 where the nearest mode is black for that eye): eye image = columns [col0, col0 + we) of the
+// frame, mirrored when `mirror` (the right eye, projection.py:430-431)
+__device__ __forceinline__ unsigned pb_bilinear_eye(const PbParams& P, const uint8_t* __restrict__ s, double lat, double lon, int we, double cx,
+                                                    int col0, bool mirror) {
+    const int h = P.src.height, w = P.src.width;
+    const double dist = pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
+    double sl, cl;
+    sincos(lon, &sl, &cl);
+    const double f0 = ((sl * dist) * -1.0) + P.src_cy, f1 = (cl * dist) + cx;
+    const bool live = f0 == f0 && f1 == f1 && fabs(f0) < 1.0e9 && fabs(f1) < 1.0e9 && f0 >= 0.0 && f0 < (double)h && f1 >= 0.0 && f1 < (double)we;
+    if (!live) return 0u;
+    const double sy = f0 - 0.5, sx = f1 - 0.5;
+    const int by = (int)floor(sy), bx = (int)floor(sx);
+    const float ty = (float)(sy - by), tx = (float)(sx - bx);
+    const int r0 = min(max(by, 0), h - 1), r1 = min(max(by + 1, 0), h - 1);
+    int c0 = min(max(bx, 0), we - 1), c1 = min(max(bx + 1, 0), we - 1);
+    c0 = col0 + (mirror ? we - 1 - c0 : c0);
+    c1 = col0 + (mirror ? we - 1 - c1 : c1);
+    const unsigned p00 = pb_load_px(s, r0 * w + c0), p01 = pb_load_px(s, r0 * w + c1);
+    const unsigned p10 = pb_load_px(s, r1 * w + c0), p11 = pb_load_px(s, r1 * w + c1);
+    unsigned out = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float a = (float)((p00 >> (8 * ch)) & 0xFF), b = (float)((p01 >> (8 * ch)) & 0xFF);
+        const float c = (float)((p10 >> (8 * ch)) & 0xFF), d = (float)((p11 >> (8 * ch)) & 0xFF);
+        const float top = fmaf(tx, b - a, a), bot = fmaf(tx, d - c, c);
+        const float v = fmaf(ty, bot - top, top);
+        out |= ((unsigned)(int)rintf(fminf(fmaxf(v, 0.0f), 255.0f))) << (8 * ch);
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_kernel(const PbParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                      int n_frames, unsigned long long src_stride, unsigned long long dst_stride) {
+    const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= (unsigned)P.dst.height * (unsigned)P.dst.width) return;
+    const int i = p / (unsigned)P.dst.width, j = p - (unsigned)i * (unsigned)P.dst.width;
+    PbCoord c = pb_dst_coord(P, i, j);
+    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    const double lat_r = (c.lat * -1.0) + PB_PI;  // projection.py:426-427
+    const double fl = pb_merge_factor(P, c.lat), fr = pb_merge_factor(P, lat_r);
+    for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* s = src + (unsigned long long)f * src_stride;
+        unsigned v = 0;
+        if (!c.inv) {
+            const unsigned l = pb_bilinear_eye(P, s, c.lat, c.lon, P.src_eye_w, P.src_cx, 0, false);
+            const unsigned r = pb_bilinear_eye(P, s, lat_r, c.lon, P.src_eye_w_right, P.src_cx_r, P.src_eye_w, true);
+            v = pb_blend_u8(l & 0xFF, r & 0xFF, fl, fr) | (pb_blend_u8((l >> 8) & 0xFF, (r >> 8) & 0xFF, fl, fr) << 8) |
+                (pb_blend_u8((l >> 16) & 0xFF, (r >> 16) & 0xFF, fl, fr) << 16);
+        }
+        uint8_t* o = dst + (unsigned long long)f * dst_stride + 3ull * p;
         o[0] = (uint8_t)(v & 0xFF);
         o[1] = (uint8_t)((v >> 8) & 0xFF);
         o[2] = (uint8_t)((v >> 16) & 0xFF);

@@ -682,7 +682,6 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
     if (n_frames < 0) return pb_fail(PB_ERR_INVALID, "negative frame count");
     if (n_frames == 0) return PB_OK;
     const PbParams& P = plan->P;
-    if (P.src.kind == PB_KIND_DOUBLE) return pb_fail(PB_ERR_UNSUPPORTED, "bilinear sampling does not support double-fisheye sources");
     if (plan->device >= 0) {
         int dev = -1;
         PB_HIP(hipGetDevice(&dev));
@@ -695,6 +694,12 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
     if (n_frames > 1 && src_frame_stride < 3ull * P.src.height * P.src.width)
         return pb_fail(PB_ERR_INVALID, "src_frame_stride smaller than a frame");
     hipStream_t st = (hipStream_t)stream;
+    if (P.src.kind == PB_KIND_DOUBLE) {
+        hipLaunchKernelGGL(pb_bilinear_double_kernel, dim3(pb_blocks(npx)), dim3(PB_BLOCK), 0, st, P, src_dev, dst_dev, n_frames, src_frame_stride,
+                           dst_frame_stride);
+        PB_HIP(hipGetLastError());
+        return PB_OK;
+    }
     if (pb_use_fast(plan)) {
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
         // LEAN tiles take their taps from LDS windows, except for frames LDS-DMA cannot address (not 16-byte aligned)
@@ -709,9 +714,10 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         else                                                                                                                         \
             hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, false>), grid, block, pb_window_lds_bytes(P), st, P, plan->table, src_dev, dst_dev, n_frames, \
                                src_frame_stride, dst_frame_stride, windows);                                                         \
-        if (plan->n_fail_tiles)                                                                                                      \
-            hipLaunchKernelGGL(pb_bilinear_fix_kernel<KIND>, dim3(4u * plan->n_fail_tiles), dim3(PB_BLOCK), 0, st, P,                \
-                               plan->fail_tiles, 0, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);                 \
+        if (plan->n_fail_tiles || plan->n_fix_px)                                                                                    \
+            hipLaunchKernelGGL(pb_bilinear_fix_kernel<KIND>, dim3(4u * plan->n_fail_tiles + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK),  \
+                               dim3(PB_BLOCK), 0, st, P, plan->fail_tiles, 0, src_dev, dst_dev, n_frames, src_frame_stride,          \
+                               dst_frame_stride, (int)plan->n_fail_tiles, plan->fix_px, (int)plan->n_fix_px);                        \
     } while (0)
         if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_BILINEAR(PB_KIND_PANO);
         else PB_LAUNCH_BILINEAR(PB_KIND_CAMERA);

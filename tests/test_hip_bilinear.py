@@ -23,14 +23,20 @@ CASES = [
     Case("bl_alter", cam(128, 128, "stereographic", 200, inscribed(128)), cam(150, 150, "equidistant", 220, inscribed(150)), [(-20, 10, 100)]),
     Case("bl_pano_pano", pano(80, 160), pano(64, 128), [(12, 34, 56)]),
     Case("bl_double_dst", ("double", 64, 128, "equidistant", 195.0, None), pano(96, 192)),
+    Case("bl_double_src", pano(96, 192), ("double", 120, 240, "equidistant", 195.0, None)),
+    Case("bl_double_src_rot", cam(128, 128, "equidistant", 200, inscribed(128)), ("double", 120, 241, "equisolid", 200.0, None), [(3, 90, -7)]),
 ]
 
 
 def smooth_frame(h, w):
-    """A smooth test pattern: with noise every pixel would sit on an interpolation edge."""
+    """A smooth test pattern, periodic in x (a panorama's columns wrap): on noise, a sawtooth or a seam every pixel
+    would sit on an interpolation edge, and the comparison would measure the pattern, not the sampler."""
     yy, xx = np.mgrid[0:h, 0:w]
-    img = np.stack([(xx * 255 // max(1, w - 1)), (yy * 255 // max(1, h - 1)), ((xx + yy) * 3) % 256], axis=2)
-    return img.astype(np.uint8)
+    ph = 2.0 * np.pi * (xx + 0.5) / w
+    r = 127.5 + 120.0 * np.cos(ph)
+    g = 10.0 + 235.0 * yy / max(1, h - 1)
+    b = 127.5 + 120.0 * np.sin(ph) * np.cos(np.pi * (yy + 0.5) / h)
+    return np.rint(np.stack([r, g, b], axis=2)).astype(np.uint8)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c.name)
@@ -44,9 +50,21 @@ def test_bilinear_matches_definition(case, mode):
     plan.set_mode(mode)
     got = plan.remap(torch.from_numpy(frame).cuda(), interpolation="bilinear").cpu().numpy()
     d = np.abs(got.astype(np.int16) - want.astype(np.int16)).max(axis=2)
+    if case.src[0] == "double":
+        d = np.minimum(d, 256 - d)  # the blend's cast wraps mod 256 like the reference's
     n = d.size
-    assert int((d > 1).sum()) <= max(8, n // 200), f"{int((d > 1).sum())} of {n} pixels differ by more than 1 LSB"
-    assert int((d > 0).sum()) <= n // 8, f"{int((d > 0).sum())} of {n} pixels differ"
+    # <= 1 LSB EVERYWHERE except on the rim of the black regions (one pixel either side of a black / sampled edge of
+    # the definition's output), where a coordinate within float32 reach of a validity or image boundary may flip a
+    # pixel between black and sampled; a double source additionally has the seam of its blend band, where a factor of
+    # up to 1.0 multiplies a 1-LSB tap difference of EACH eye (2 LSB)
+    black = (want == 0).all(axis=2)
+    rim = np.zeros_like(black)
+    for dy, dx in ((0, 1), (1, 0), (0, -1), (-1, 0), (1, 1), (1, -1), (-1, 1), (-1, -1)):
+        rim |= black != np.roll(np.roll(black, dy, axis=0), dx, axis=1)
+    limit = 2 if case.src[0] == "double" else 1
+    inside = d[~rim]
+    assert int((inside > limit).sum()) == 0, f"{int((inside > limit).sum())} pixels off the black rims differ by more than {limit} LSB (max {int(inside.max())})"
+    assert int(rim.sum()) <= n // 8 and int((d > 0).sum()) <= n // 8, f"{int((d > 0).sum())} of {n} pixels differ"
 
 
 def test_bilinear_api_and_noise_frame():
@@ -65,6 +83,6 @@ def test_bilinear_api_and_noise_frame():
         src.process_coordinate_map(cmap, interpolation="bicubic")
     with pytest.raises(NotImplementedError):
         src.process_coordinate_map(np.asarray(cmap), interpolation="bilinear")
-    dsrc = pb.DoubleCameraImage(np.zeros((40, 80, 3), np.uint8), 3.4, pb.equidistant())
-    with pytest.raises(nat.PbError):
-        dsrc.process_coordinate_map(pb.PanoramaImage(np.zeros((16, 32, 3), np.uint8)).get_coordinate_map(), interpolation="bilinear")
+    grey = pb.PanoramaImage(np.zeros((16, 32), np.uint8))
+    with pytest.raises(NotImplementedError):  # the opt-in mode takes uint8 RGB only
+        grey.process_coordinate_map(cmap, interpolation="bilinear")
