@@ -57,6 +57,9 @@ starts, ends = T[:, 0], T[:, 7]
 grid = np.arange(t0, ends.max(), 50)  # every 0.5 us
 alive = [(int(((starts <= g) & (ends > g)).sum())) for g in grid]
 print('waves alive chip-wide every 0.5 us:', alive)
+for cname, m in classes.items():
+    if cname == 'FAILED' or not m.any(): continue
+    print('  alive %-8s every 2 us:' % cname, [int(((starts[m] <= g) & (ends[m] > g)).sum()) for g in grid[::4]])
 print('distinct CU keys:', len(np.unique(cu_key)))
 order = np.argsort(starts)
 print('wave starts (us after first) deciles:', [round(us(np.percentile(starts - t0, q)), 1) for q in range(0, 101, 10)])

@@ -1,0 +1,61 @@
+"""gpurun_out/prof_r2/ (experiments/profile_r2.sh, calib_run.sh) -> profiles/: kernel-stats CSVs (our kernels' rows),
+PMC summaries, the counter calibration, and one traffic_<config>_<budget>.json per config for bench.py's roofline.traffic."""
+import csv, json, os, re, sys
+SRC, DST = 'gpurun_out/prof_r2', 'profiles'
+def pmc(path, kernel_prefix):
+    cur, out = None, {}
+    for line in open(path):
+        if not line.startswith(' '):
+            cur = line.strip()
+        else:
+            m = re.match(r"\s+(\S+)\s+n=\s*(\d+)\s+mean=([0-9.e+]+)", line)
+            if m and cur and kernel_prefix in cur: out[m.group(1)] = (float(m.group(3)), int(m.group(2)), cur)
+    return out
+cal = {}
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for k in ('calib_stream_x4', 'calib_dma_rows96', 'calib_gather_dword', 'calib_store_12'):
+        v = pmc(f'{SRC}/calib_pmc_{c}.txt', k).get(c)
+        if v: cal[f'{k}.{c}_kb'] = v[0]
+known_r, known_w = 100663296, 50331648
+calib = {
+    'source': 'experiments/exp_calib.hip under rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), MI355X, round 2',
+    'known_read_bytes_per_launch': known_r, 'known_write_bytes_per_launch': known_w, 'raw_kb': cal,
+    'read_factor_stream_16B_per_lane': known_r / (cal['calib_stream_x4.FETCH_SIZE_kb'] * 1024),
+    'read_factor_unaligned_dword_gather': known_r / (cal['calib_gather_dword.FETCH_SIZE_kb'] * 1024),
+    'lds_dma_rows96_fetch_x2_over_unique_bytes': 2 * cal['calib_dma_rows96.FETCH_SIZE_kb'] * 1024 / known_r,
+    'write_12B_per_lane_nt_over_bytes': cal['calib_store_12.WRITE_SIZE_kb'] * 1024 / known_w,
+    'conclusion': 'FETCH_SIZE reports exactly 1/2 of the bytes for 16-B-per-lane streams AND for unaligned 4-byte gathers (factor 2.000 both): the x2 '
+                  'correction of MI355X_MICROARCH.md holds for every read shape the remap kernels use.  Misaligned 96-B LDS-DMA row segments fetch 1.33x '
+                  'their unique bytes (sectors shared by neighbouring windows are requested by both).  WRITE_SIZE is 1.10x the bytes for 12-B-per-lane '
+                  'non-temporal stores of 96-B row pieces (partial 64-B lines).',
+}
+json.dump(calib, open(f'{DST}/r02_counter_calibration.json', 'w'), indent=1)
+print(json.dumps(calib, indent=1))
+budgets = {'c1': 7168, 'c2': 12288, 'c3': 7168, 'c5': 7168, 'c4shard': 12288, 'c5shard': 7168, 'c2_alldirect': 4224}
+for cfg, bud in budgets.items():
+    b = json.loads(open(f'{SRC}/{cfg}_bench.json').read().strip().splitlines()[-1])
+    kern = 'pb_hot_double_kernel' if cfg.startswith('c5') else 'pb_hot_win_kernel'
+    f = pmc(f'{SRC}/{cfg}_pmc_FETCH_SIZE.txt', kern)['FETCH_SIZE']
+    w = pmc(f'{SRC}/{cfg}_pmc_WRITE_SIZE.txt', kern)['WRITE_SIZE']
+    r = b['roofline']
+    assert r['window_budget'] == bud, (cfg, r['window_budget'])
+    hbm = int(2 * f[0] * 1024 + w[0] * 1024)
+    rows = [row for row in csv.reader(open(f'{SRC}/{cfg}_kernel_stats.csv'))]
+    keep = [rows[0]] + [row for row in rows[1:] if row[0].startswith(('void pb_', 'pb_'))]
+    csv.writer(open(f'{DST}/r02_{cfg}_kernel_stats.csv', 'w')).writerows(keep)
+    kst = [row for row in keep[1:] if kern in row[0]][0]
+    t = {
+        'kernel': f[2], 'config': cfg, 'window_budget': bud, 'frames_per_launch': b['config']['frames_per_launch'],
+        'fetch_size_kb_raw': f[0], 'write_size_kb_raw': w[0], 'pmc_dispatches': f[1],
+        'correction': 'FETCH_SIZE x 2 (calibrated this round for 16-B streams and unaligned dword gathers: profiles/r02_counter_calibration.json); WRITE_SIZE as reported',
+        'hbm_bytes_per_launch': hbm,
+        'algorithmic_bytes_per_launch': r['algorithmic_bytes_per_launch'], 'must_move_bytes_per_launch': r['must_move_bytes_per_launch'],
+        'traffic_over_algorithmic': round(hbm / r['algorithmic_bytes_per_launch'], 3), 'traffic_over_must_move': round(hbm / r['must_move_bytes_per_launch'], 3),
+        'rocprof_kernel_avg_ns': float(kst[3]), 'rocprof_calls': int(kst[1]),
+        'bench_kernel_ms_mean_same_run': r['kernel_ms_mean'], 'plan': r['plan'],
+        'source_files': [f'profiles/r02_{cfg}_kernel_stats.csv', 'experiments/profile_r2.sh'],
+    }
+    name = f'{DST}/traffic_{cfg}_{bud}.json' if cfg != 'c2_alldirect' else f'{DST}/traffic_c2_{bud}.json'
+    json.dump(t, open(name, 'w'), indent=1)
+    print(cfg, bud, 'fetch x2 %.1f MB write %.1f MB total %.1f MB = %.2fx algorithmic, %.2fx must-move; rocprof avg %.2f us vs hipEvent %.2f us' % (
+        2 * f[0] * 1024 / 1e6, w[0] * 1024 / 1e6, hbm / 1e6, t['traffic_over_algorithmic'], t['traffic_over_must_move'], t['rocprof_kernel_avg_ns'] / 1e3, r['kernel_ms_mean'] * 1e3))

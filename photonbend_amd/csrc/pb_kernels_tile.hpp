@@ -606,17 +606,20 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
         src += (unsigned long long)f * src_stride;
         dst += (unsigned long long)f * dst_stride;
     }
+    // wave slot in launch order: `table` is the plan's LAUNCH-ORDER copy of the tile entries (pb_launch_table_kernel) -
+    // workgroup ids keep their XCD residue, and within an XCD the plan has put the 256x256-px super-tiles in an order
+    // that mixes texture-path-bound (direct gather) and bandwidth-bound (window) tiles in time and leaves the cheap,
+    // all-black ones for the drain of the launch.  The entry itself says which tile it is: no index arithmetic.
     const unsigned flat = (wg >> 3) * wpw + (unsigned)wave_in_wg;
-    const unsigned group = (flat >> 2) * 8u + (wg & 7u);
-    const int wave = (int)(flat & 3u);
-    int tx, ty;
-    if (!pb_tile_of_wave(P, wave, tx, ty, group)) return;
+    const unsigned vslot = ((flat >> 2) * 8u + (wg & 7u)) * 4u + (flat & 3u);
+    PbTileEntry entry;
+    pb_load_entry(table + vslot, entry);
+    const int tx = entry.tile_xy & 0xFFFF, ty = (int)((unsigned)entry.tile_xy >> 16);
+    if (entry.flags & PB_TILE_SKIP) return;
     PB_TR(0);
 #ifdef PB_TRACE
     if (lane == 0) pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
 #endif
-    PbTileEntry entry;
-    pb_load_entry(table + ((size_t)ty * pb_tiles_x(P) + tx), entry);
     const PbTileEntry* __restrict__ e = &entry;
     const int flags = e->flags;
     PB_TR(1);
@@ -662,6 +665,41 @@ __global__ void pb_budget_kernel(PbTileEntry* __restrict__ table, const int32_t*
     table[t].flags = flags;
     if (flags & PB_TILE_LEAN) atomicAdd(&counters[0], 1u);
     if (flags & PB_TILE_DIRECT) atomicAdd(&counters[1], 1u);
+}
+// Plan creation / budget change: the launch-order copy of the tile table.  One wave per wave slot of the hot launch:
+// slot v = virtual workgroup (v >> 2) x wave (v & 3).  Virtual workgroup B runs on XCD B & 7 (round-robin dispatch,
+// speed only) as that XCD's (B >> 3)-th workgroup; unit_of[xcd * units_per_xcd + k] names the k-th unit (a 4x4 group of
+// workgroups = a 256x256-px super-tile, or -1 = none) the host's ordering gave that XCD; without units (unit_of ==
+// nullptr: grids that do not divide into super-tiles) virtual workgroup B is tile group B.
+__global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
+                                                              PbTileEntry* __restrict__ ltable, const int* __restrict__ unit_of,
+                                                              int units_per_xcd, unsigned n_slots) {
+    const unsigned v = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (v >= n_slots) return;
+    const unsigned B = v >> 2, wave = v & 3u;
+    const int gx = (pb_tiles_x(P) + 1) / 2, gy = (pb_tiles_y(P) + 1) / 2;
+    long long group = B;
+    if (unit_of) {
+        const unsigned xcd = B & 7u, slot = B >> 3, k = slot >> 4, inner = slot & 15u;
+        const int S = (int)k < units_per_xcd ? unit_of[xcd * units_per_xcd + k] : -1;
+        const int sgx = gx >> 2;
+        group = S < 0 ? -1 : (long long)((S / sgx) * 4 + (int)(inner >> 2)) * gx + (S % sgx) * 4 + (int)(inner & 3u);
+    }
+    int tx = -1, ty = -1;
+    if (group >= 0 && group < (long long)gx * gy) {
+        const int by = (int)(group / gx), bx = (int)(group - (long long)by * gx);
+        tx = 2 * bx + (int)(wave & 1u);
+        ty = 2 * by + (int)(wave >> 1);
+    }
+    int* out = reinterpret_cast<int*>(ltable + v);
+    if (tx < 0 || tx >= pb_tiles_x(P) || ty >= pb_tiles_y(P)) {
+        out[lane] = lane == 2 ? PB_TILE_SKIP : 0;  // flags is the third dword
+        return;
+    }
+    const int* in = reinterpret_cast<const int*>(table + ((size_t)ty * pb_tiles_x(P) + tx));
+    int w = in[lane];
+    if (lane == offsetof(PbTileEntry, tile_xy) / 4) w = (ty << 16) | tx;
+    out[lane] = w;
 }
 __global__ void pb_save_flags_kernel(const PbTileEntry* __restrict__ table, int32_t* __restrict__ saved, unsigned n_tiles) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;

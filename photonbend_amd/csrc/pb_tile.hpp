@@ -34,6 +34,7 @@
 #define PB_TILE_DIRECT 16  // like LEAN (plain pixels, model anchored at the box origin) but the box is too sparse /
                            // large to stage: samples are fetched with unaligned global loads, no LDS
 #define PB_TILE_BLACK 8  // every pixel of the tile (inside the image) is black: the hot kernel only stores zeros
+#define PB_TILE_SKIP 32  // launch-order table only: an empty wave slot (beyond the image)
 #define PB_LEAN_MAX_PASSES 24  // window rows / rows-per-load-instruction of a LEAN tile (register staging depth)
 
 typedef float pb_f2 __attribute__((ext_vector_type(2)));
@@ -49,7 +50,8 @@ struct __attribute__((aligned(256))) PbTileEntry {
     int32_t win_n16, win_a0;     // LEAN: 16-byte chunks per row, byte offset of column win_c0 in its first chunk
     int32_t fix_off, fix_cnt;    // this tile's slice of the plan's fix-pixel list (<= PB_TILE_FAIL_LIMIT entries)
     int32_t aux_off;             // double sources, left-eye entry: the tile's slot in the plan's latitude table (PB_TILE_W_LAT)
-    int32_t pad1[2];
+    int32_t tile_xy;             // launch-order copy (pb_launch_table_kernel): the tile this entry belongs to, ty << 16 | tx
+    int32_t pad1;
 };
 static_assert(sizeof(PbTileEntry) == 256, "PbTileEntry must be 256 bytes");
 

@@ -15,8 +15,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
+#include <algorithm>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "pb_params.hpp"
 #include "pb_stages.hpp"
@@ -56,6 +59,9 @@ struct pb_plan {
     // in use from them, so the budget can be changed at any time without touching a pixel
     int32_t* saved_l = nullptr;
     int32_t* saved_r = nullptr;
+    // the hot kernel's launch-order copy of `table` (rebuilt with every budget change; derived, never serialized)
+    PbTileEntry* ltable = nullptr;
+    unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
     double prepare_ms = 0.0, tune_ms = 0.0;  // host wall time of the device preparation / of the optional budget tuning
 };
 
@@ -295,14 +301,14 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
     const unsigned fix_blocks = 4u * pl->n_fail_tiles + (pl->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
     // the windowed kernel needs 16-byte aligned frames (LDS-DMA row segments); PB_MODE_FAST_DIRECT and
     // unaligned frames take the direct-gather hot kernel + the fix kernel
-    const bool windowed = OUT == 0 && pl->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
+    const bool windowed = OUT == 0 && pl->ltable && pl->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
                           ((((uintptr_t)src) | ss) & 15u) == 0;
     if (windowed) {
         // one launch per frame: failed tiles and fix pixels are looked up in the plan's exact-index tables by the
         // hot waves themselves (pb_kernels_tile.hpp)
         // frames are a grid dimension, frame-major; a frame's share of the grid is a multiple of 8 workgroups so that a
         // tile group keeps its XCD residue in every frame
-        const unsigned gpf = (grid.x + 7u) & ~7u;
+        const unsigned gpf = pl->launch_groups;
         static const unsigned wpw = [] { const char* e = getenv("PB_WPW"); const int v = e ? atoi(e) : PB_WAVES_PER_WG; return (v == 1 || v == 2) ? (unsigned)v : 4u; }();
         const dim3 wblock(64u * wpw);
         const size_t lds = pb_window_lds_bytes(P) / PB_TILE_WAVES * wpw;
@@ -314,7 +320,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
             const uint8_t* sf = src + (unsigned long long)f0 * ss;
             uint8_t* df = dst + (unsigned long long)f0 * ds;
 #define PB_LAUNCH_WIN(KIND)                                                                                                   \
-    hipLaunchKernelGGL((pb_hot_win_kernel<KIND>), bgrid, wblock, lds, st, P, pl->table, sf, df, gpf, ss, ds, pl->idx_tab, \
+    hipLaunchKernelGGL((pb_hot_win_kernel<KIND>), bgrid, wblock, lds, st, P, pl->ltable, sf, df, gpf, ss, ds, pl->idx_tab, \
                        pl->fix_px, pl->fix_idx)
             if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_WIN(PB_KIND_PANO);
             else PB_LAUNCH_WIN(PB_KIND_CAMERA);
@@ -363,6 +369,77 @@ static int pb_clamp_budget(int budget) {
     return budget;
 }
 
+// The hot kernel's launch order.  Workgroup ids keep their XCD residue (round-robin dispatch: neighbours in the list of
+// one XCD share its L2).  Where the grid divides into 256x256-px super-tiles (16 workgroups), the super-tiles are
+// ordered by cost: dealt to the XCDs from a descending sort (balanced XCDs) and, within an XCD, heavy and light ones
+// alternating - a frame otherwise runs through its tile classes in phases (c2: windows, then a long stretch of
+// texture-path-bound direct gathers, then windows again; experiments/diag_trace.py) - with the lightest (all-black) ones
+// last, where the launch drains.  PB_ORDER=0 keeps the plain spatial order.  Synchronous on the default stream.
+static int pb_build_launch_table(pb_plan* pl) {
+    PbParams& P = pl->P;
+    if (!pl->fast_ready) return PB_OK;
+    const unsigned tiles_x = (P.dst.width + PB_TILE - 1) / PB_TILE, tiles_y = (P.dst.height + PB_TILE - 1) / PB_TILE;
+    const unsigned gx = (tiles_x + 1) / 2, gy = (tiles_y + 1) / 2;
+    const bool units = (gx & 3u) == 0 && (gy & 3u) == 0 && ((gx * gy) & 127u) == 0;
+    static const int order_mode = [] { const char* e = getenv("PB_ORDER"); return e ? atoi(e) : 1; }();
+    std::vector<int> unit_of;
+    int units_per_xcd = 0;
+    unsigned n_groups = (gx * gy + 7u) & ~7u;
+    if (units) {
+        const unsigned sgx = gx / 4, sgy = gy / 4, ns = sgx * sgy;
+        units_per_xcd = (int)((ns + 7u) / 8u);
+        n_groups = 8u * (unsigned)units_per_xcd * 16u;
+        std::vector<int32_t> flags(pl->n_tiles);
+        PB_HIP(hipMemcpy2D(flags.data(), sizeof(int32_t), reinterpret_cast<const uint8_t*>(pl->table) + offsetof(PbTileEntry, flags), sizeof(PbTileEntry),
+                           sizeof(int32_t), pl->n_tiles, hipMemcpyDeviceToHost));
+        std::vector<std::pair<float, int>> cost(ns);
+        for (unsigned S = 0; S < ns; ++S) {
+            float c = 0.f;
+            const unsigned sy = S / sgx, sx = S % sgx;
+            for (unsigned ty = sy * 8; ty < sy * 8 + 8 && ty < tiles_y; ++ty)
+                for (unsigned tx = sx * 8; tx < sx * 8 + 8 && tx < tiles_x; ++tx) {
+                    const int f = flags[(size_t)ty * tiles_x + tx];
+                    c += (f & PB_TILE_BLACK) ? 0.35f : (f & PB_TILE_LEAN) ? 1.0f : (f & PB_TILE_DIRECT) ? 1.2f : (f & PB_TILE_FAILED) ? 1.3f : 1.5f;
+                }
+            cost[S] = {c, (int)S};
+        }
+        unit_of.assign((size_t)8 * units_per_xcd, -1);
+        if (order_mode == 0) {
+            for (unsigned S = 0; S < ns; ++S) unit_of[(size_t)(S & 7u) * units_per_xcd + (S >> 3)] = (int)S;  // spatial: S = xcd + 8 k
+        } else {
+            std::stable_sort(cost.begin(), cost.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; });
+            for (unsigned x = 0; x < 8; ++x) {
+                std::vector<int> mine;
+                for (unsigned i = x; i < ns; i += 8) mine.push_back(cost[i].second);  // descending within the XCD
+                const size_t m = mine.size(), half = (m + 1) / 2;
+                for (size_t k = 0; k < m; ++k) {
+                    int S = mine[k];
+                    if (order_mode == 1) S = (k & 1) ? mine[half + k / 2] : mine[k / 2];  // heavy, light, heavy, light, ...
+                    unit_of[(size_t)x * units_per_xcd + k] = S;
+                }
+            }
+        }
+    }
+    const unsigned n_slots = 4u * n_groups;
+    (void)hipFree(pl->ltable);
+    pl->ltable = nullptr;
+    PB_HIP(hipMalloc((void**)&pl->ltable, (size_t)n_slots * sizeof(PbTileEntry)));
+    int* unit_dev = nullptr;
+    if (units) {
+        PB_HIP(hipMalloc((void**)&unit_dev, unit_of.size() * sizeof(int)));
+        if (hipMemcpy(unit_dev, unit_of.data(), unit_of.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(unit_dev);
+            return pb_fail(PB_ERR_HIP, "launch table: upload failed");
+        }
+    }
+    hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, pl->ltable, unit_dev, units_per_xcd, n_slots);
+    const hipError_t e = hipDeviceSynchronize();
+    (void)hipFree(unit_dev);
+    PB_HIP(e);
+    pl->launch_groups = n_groups;
+    return PB_OK;
+}
+
 // keeps the certified flags (once) and applies `budget` to them; synchronous on the default stream
 static int pb_apply_budget(pb_plan* pl, int budget) {
     PbParams& P = pl->P;
@@ -392,7 +469,7 @@ static int pb_apply_budget(pb_plan* pl, int budget) {
     PB_HIP(e);
     pl->n_lean_tiles = res[0];
     pl->n_direct_tiles = res[1];
-    return PB_OK;
+    return pb_build_launch_table(pl);
 }
 
 // OPT-IN (PB_PLAN_TUNE): picks the budget by measurement - four candidates x a few launches on scratch frames
@@ -590,6 +667,7 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->dbl_px_fix);
     (void)hipFree(plan->saved_l);
     (void)hipFree(plan->saved_r);
+    (void)hipFree(plan->ltable);
     delete plan;
 }
 
@@ -1102,6 +1180,11 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
         pb_plan_destroy(pl);
         return rc;
     }
+    rc = pb_build_launch_table(pl);  // derived state: rebuilt, not stored
+    if (rc != PB_OK) {
+        pb_plan_destroy(pl);
+        return rc;
+    }
     *out = pl;
     return PB_OK;
 }
@@ -1109,9 +1192,21 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
 // ---- measurement utility: a plain device copy (16 bytes per lane), the practical HBM ceiling next to which
 // bench.py reports the remap kernel (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s by such a copy) -------------
 }  // extern "C"
-__global__ __launch_bounds__(256) void pb_copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+typedef unsigned pb_u32x4 __attribute__((ext_vector_type(4)));
+// every workgroup owns one contiguous 32 KiB chunk: 8 non-temporal 16-byte loads per lane in flight, then 8 non-temporal
+// stores - the fastest of the copy shapes measured on MI355X (experiments/exp_copy.hip: 6.35 TB/s read + write on 512 MiB;
+// a grid-stride loop of single loads 4.9-5.8, hipMemcpyDtoD 5.35)
+__global__ __launch_bounds__(256) void pb_copy16_kernel(const pb_u32x4* __restrict__ src, pb_u32x4* __restrict__ dst, size_t n16) {
+    const size_t base = (size_t)blockIdx.x * 2048 + threadIdx.x;
+    if (base + 7 * 256 < n16) {
+        pb_u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + base + u * 256);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) __builtin_nontemporal_store(v[u], dst + base + u * 256);
+    } else {
+        for (size_t i = base; i < n16; i += 256) dst[i] = src[i];
+    }
 }
 extern "C" {
 int pb_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream) {
@@ -1119,10 +1214,10 @@ int pb_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* strea
     if ((((uintptr_t)dst_dev | (uintptr_t)src_dev | bytes) & 15u) != 0) return pb_fail(PB_ERR_INVALID, "pb_stream_copy needs 16-byte aligned pointers and size");
     const size_t n16 = bytes / 16;
     if (!n16) return PB_OK;
-    size_t blocks = (n16 + 255) / 256;
-    if (blocks > 256u * 16u) blocks = 256u * 16u;  // 16 workgroups per CU, grid-stride
-    hipLaunchKernelGGL(pb_copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const uint4*>(src_dev),
-                       static_cast<uint4*>(dst_dev), n16);
+    const size_t blocks = (n16 + 2047) / 2048;
+    if (blocks > 0x7FFFFFFFull) return pb_fail(PB_ERR_INVALID, "pb_stream_copy: too large");
+    hipLaunchKernelGGL(pb_copy16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const pb_u32x4*>(src_dev),
+                       static_cast<pb_u32x4*>(dst_dev), n16);
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
