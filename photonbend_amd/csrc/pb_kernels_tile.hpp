@@ -194,14 +194,6 @@ __device__ unsigned long long pb_trace[65536 * 16];
 #define PB_TR(i)
 #endif
 
-// one sample of a direct-gather tile as ONE aligned 8-byte load (the 3 wanted bytes lie within 8 bytes of the dword
-// boundary below them) + v_alignbyte, instead of an unaligned 4-byte load: the texture path splits unaligned dwords
-__device__ __forceinline__ unsigned pb_load3_x2(const uint8_t* __restrict__ s, unsigned off) {
-    uint2 v;
-    __builtin_memcpy(&v, (const uint8_t*)__builtin_assume_aligned(s + (off & ~3u), 4), 8);
-    return __builtin_amdgcn_alignbyte(v.y, v.x, off);
-}
-
 // part: this wave issues the row groups part, part + parts, ... (a workgroup loading one window together)
 __device__ __forceinline__ void pb_issue_window_loads(const uint8_t* __restrict__ s, unsigned* win, int lane, unsigned gbase,
                                                       unsigned rowbytes, int nrows, int n16, unsigned safe_len, unsigned part = 0,
@@ -307,9 +299,6 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             if (PB_ABL_NO_LOAD) {
 #pragma unroll
                 for (int n = 0; n < 16; ++n) t[n] = go[n];
-            } else if (P.exp_flags & PB_EXP_DIRECT_X2) {
-#pragma unroll
-                for (int n = 0; n < 16; ++n) t[n] = pb_load3_x2(s, go[n]);
             } else {
 #pragma unroll
                 for (int n = 0; n < 16; ++n) __builtin_memcpy(&t[n], s + go[n], 4);
@@ -904,8 +893,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_window_kernel(const PbP
     const int lr0 = rmin - 1, lc0 = cmin - 1, rows = rmax - rmin + 3, cols = cmax - cmin + 3;
     // (an eye's margin texel may lie in the other eye's half: inside the frame, never sampled)
     if (lr0 < 0 || lc0 < 0 || lr0 + rows > h || lc0 + cols > w) return;
-    // the last sample's read (4 bytes; 8 from the dword boundary below it on the aligned-load path) must stay inside the frame
-    if ((unsigned)(lr0 + rows - 1) * rowbytes + 3u * (unsigned)(lc0 + cols - 1) + 8u > rowbytes * (unsigned)h) return;
+    // the last sample's 4-byte read must stay inside the frame
+    if ((unsigned)(lr0 + rows - 1) * rowbytes + 3u * (unsigned)(lc0 + cols - 1) + 4u > rowbytes * (unsigned)h) return;
     const unsigned a0 = (3u * (unsigned)lc0) & 15u;
     const unsigned n16 = (a0 + 3u * (unsigned)cols + 1u + 15u) >> 4;
     const unsigned last_chunk_end = (((unsigned)(lr0 + rows - 1) * rowbytes + 3u * (unsigned)lc0) & ~15u) + 16u * n16;

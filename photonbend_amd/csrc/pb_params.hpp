@@ -11,9 +11,8 @@
 
 #define PB_PI 3.141592653589793  // == numpy.pi == M_PI
 
-// kernel variant switches (PbParams::exp_flags; default from PB_DEFAULT_EXP, overridden by the PB_EXP environment
-// variable at plan creation).  They select how a tile's bytes are fetched, never which bytes.
-#define PB_EXP_DIRECT_X2 1   // direct-gather tiles: one ALIGNED 8-byte load per sample instead of an unaligned 4-byte one
+// kernel variant switches (PbParams::exp_flags; PB_EXP environment variable at plan creation): used only by the
+// -DPB_ABLATION diagnostic build (experiments/), which skips tile classes / loads / stores to attribute time.
 
 struct PbEnd {
     int32_t kind, lens, height, width;

@@ -369,19 +369,20 @@ static int pb_clamp_budget(int budget) {
     return budget;
 }
 
-// The hot kernel's launch order.  Workgroup ids keep their XCD residue (round-robin dispatch: neighbours in the list of
-// one XCD share its L2).  Where the grid divides into 256x256-px super-tiles (16 workgroups), the super-tiles are
-// ordered by cost: dealt to the XCDs from a descending sort (balanced XCDs) and, within an XCD, heavy and light ones
-// alternating - a frame otherwise runs through its tile classes in phases (c2: windows, then a long stretch of
-// texture-path-bound direct gathers, then windows again; experiments/diag_trace.py) - with the lightest (all-black) ones
-// last, where the launch drains.  PB_ORDER=0 keeps the plain spatial order.  Synchronous on the default stream.
+// The hot kernel's launch order: the tile entries copied into the order the waves of a launch take them, so that a
+// wave's entry is found by its slot (no tile arithmetic) and the order is the plan's to choose.  Workgroup ids keep
+// their XCD residue (round-robin dispatch: neighbours in one XCD's list share its L2); where the grid divides into
+// 256x256-px super-tiles (16 workgroups), XCD x takes super-tiles x, x + 8, ... in row-major order (PB_ORDER=0, the
+// default).  Cost-aware orders were measured and lost (PB_ORDER=1: heavy and light super-tiles alternating, which does
+// mix the direct-gather and window phases of a c2 frame in time; 2: heaviest first; black tiles last): c2 44.5 -> 45-46 us,
+// the batch 33.5 -> 35.7 - spatial neighbours close in time matter more than what drains last.  Synchronous.
 static int pb_build_launch_table(pb_plan* pl) {
     PbParams& P = pl->P;
     if (!pl->fast_ready) return PB_OK;
     const unsigned tiles_x = (P.dst.width + PB_TILE - 1) / PB_TILE, tiles_y = (P.dst.height + PB_TILE - 1) / PB_TILE;
     const unsigned gx = (tiles_x + 1) / 2, gy = (tiles_y + 1) / 2;
     const bool units = (gx & 3u) == 0 && (gy & 3u) == 0 && ((gx * gy) & 127u) == 0;
-    static const int order_mode = [] { const char* e = getenv("PB_ORDER"); return e ? atoi(e) : 1; }();
+    static const int order_mode = [] { const char* e = getenv("PB_ORDER"); return e ? atoi(e) : 0; }();
     std::vector<int> unit_of;
     int units_per_xcd = 0;
     unsigned n_groups = (gx * gy + 7u) & ~7u;
@@ -414,7 +415,7 @@ static int pb_build_launch_table(pb_plan* pl) {
                 const size_t m = mine.size(), half = (m + 1) / 2;
                 for (size_t k = 0; k < m; ++k) {
                     int S = mine[k];
-                    if (order_mode == 1) S = (k & 1) ? mine[half + k / 2] : mine[k / 2];  // heavy, light, heavy, light, ...
+                    if (order_mode == 1) S = (k & 1) ? mine[half + k / 2] : mine[k / 2];  // heavy, light, heavy, light, ... (2: descending)
                     unit_of[(size_t)x * units_per_xcd + k] = S;
                 }
             }
