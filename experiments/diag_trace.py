@@ -12,6 +12,7 @@ from tests.cases import full_cases
 
 case = [c for c in full_cases() if c.name == sys.argv[1]][0]
 budget = int(sys.argv[2]) if len(sys.argv) > 2 else 12288
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # > 1: one launch of `batch` frames, the middle frame's waves are recorded
 src, cmap = H.pb_chain(case, image=np.zeros((case.src[1], case.src[2], 3), np.uint8))
 plan = nat.Plan(cmap.dst_proj, cmap.rotations, src._proj(), budget=budget)
 lib = nat.load()
@@ -25,7 +26,15 @@ nt = info['tiles']
 buf = (ctypes.c_ulonglong * (nt * 16))()
 lib.pb_debug_trace(None, 0, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); plan.remap(frames[0], outs[0]); e1.record(); torch.cuda.synchronize()
+if batch > 1:
+    fb = torch.stack([frames[i % 6] for i in range(batch)]); ob = torch.empty((batch,) + tuple(outs[0].shape), dtype=torch.uint8, device='cuda')
+    plan.remap(fb, ob); torch.cuda.synchronize()
+    assert lib.pb_debug_trace_frame(plan.handle, batch // 2) == 0
+    lib.pb_debug_trace(None, 0, 1)
+    e0.record(); plan.remap(fb, ob); e1.record(); torch.cuda.synchronize()
+    print('batch of %d frames: %.1f us per frame' % (batch, e0.elapsed_time(e1) * 1e3 / batch))
+else:
+    e0.record(); plan.remap(frames[0], outs[0]); e1.record(); torch.cuda.synchronize()
 assert lib.pb_debug_trace(buf, nt * 16, 0) == 0
 T = np.frombuffer(buf, dtype=np.uint64).reshape(nt, 16).astype(np.int64)
 tab = (ctypes.c_int32 * (nt * 64))()

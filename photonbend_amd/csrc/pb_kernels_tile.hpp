@@ -189,7 +189,8 @@ static inline size_t pb_window_lds_bytes(const PbParams& P, int pad_dwords = 4) 
 // pb_trace[tile * 16 + i]: 0 wave started, 1 entry in SGPRs, 2 addresses computed, 3 loads issued, 4 loads landed,
 // 5 stores issued, 6 tile done (stores complete), 7 wave done (incl. fix pixels); 15: HW_ID.  s_memrealtime ticks (10 ns).
 __device__ unsigned long long pb_trace[65536 * 16];
-#define PB_TR(i) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + (i)] = t_; } while (0)
+__device__ unsigned pb_trace_wpf = 0xFFFFFFFFu, pb_trace_frame = 0;  // workgroups per frame / which frame of a batch to record (pb_debug_trace_frame)
+#define PB_TR(i) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0 && blockIdx.x / pb_trace_wpf == pb_trace_frame) pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + (i)] = t_; } while (0)
 #else
 #define PB_TR(i)
 #endif
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
     if (entry.flags & PB_TILE_SKIP) return;
     PB_TR(0);
 #ifdef PB_TRACE
-    if (lane == 0) pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+    if (lane == 0 && blockIdx.x / pb_trace_wpf == pb_trace_frame) pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
 #endif
     const PbTileEntry* __restrict__ e = &entry;
     const int flags = e->flags;

@@ -840,6 +840,12 @@ __attribute__((visibility("default"))) int pb_debug_trace(unsigned long long* ou
     }
     return 0;
 }
+__attribute__((visibility("default"))) int pb_debug_trace_frame(const pb_plan* plan, int frame) {
+    // record the waves of frame `frame` of a batch launch (4-wave workgroups); frame < 0: whole launches (single frames)
+    const unsigned wpf = (plan && frame >= 0) ? plan->launch_groups : 0xFFFFFFFFu, f = frame >= 0 ? (unsigned)frame : 0u;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pb_trace_wpf), &wpf, sizeof(wpf)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(pb_trace_frame), &f, sizeof(f)) == hipSuccess ? 0 : -1;
+}
 __attribute__((visibility("default"))) int pb_debug_copy_table(const pb_plan* plan, void* host, size_t bytes) {
     if (!plan || !plan->table) return -1;
     const size_t have = (size_t)plan->n_tiles * sizeof(PbTileEntry);

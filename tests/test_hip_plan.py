@@ -158,7 +158,7 @@ def test_remap_batch_sharded_single_process():
     dst = pb.CameraImage(np.zeros((96, 96, 3), np.uint8), fov, pb.equidistant(), magnitude=47.5)
     rot = pb.Rotation(0.2, 0.1, -0.4)
     srcp = nat.make_proj(nat.KIND_PANO, 64, 128)
-    ids, outs = parallel.remap_batch_sharded(dst._proj(), [rot.rotation_matrix], srcp, lambda i: nat.synth_frame(64, 128, frame=i), 11, chunk=4)
+    ids, outs = parallel.remap_batch_sharded(dst._proj("dst"), [rot.rotation_matrix], srcp, lambda i: nat.synth_frame(64, 128, frame=i), 11, chunk=4)
     assert ids == list(range(11)) and len(outs) == 11
     for i in (0, 5, 10):
         frame = nat.synth_frame(64, 128, frame=i).cpu().numpy()
