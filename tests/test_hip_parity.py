@@ -79,7 +79,10 @@ def ulp_diff(a, b):
 
 
 @pytest.mark.parametrize("case", [c for c in small_cases() if c.keep_map], ids=lambda c: c.name)
-def test_materialised_maps_within_ulps(case):
+def test_materialised_maps_within_ulps(case, capsys):
+    """north_star asks for 1 ULP per channel on floating-point results; the materialised float64 maps differ from the
+    reference's by the last bits of different libms (device OCML vs NumPy's SVML / glibc mix): bound 4 ulp, plus the
+    pole conditioning of acos / atan2 after rotations.  The measured maximum per stage is printed."""
     import photonbend_amd as pb
 
     n = case.name
@@ -102,6 +105,12 @@ def test_materialised_maps_within_ulps(case):
             with np.errstate(all="ignore"):
                 cond = k * 8 * 2.0**-52 / np.maximum(np.abs(np.sin(want[..., 0])), 1e-9)
                 ok = (d <= MAP_ULPS) | (np.abs(g - w) <= np.maximum(1e-15, cond))
+            lens = case.dst[3] if case.dst[0] != "pano" else "pano"
+            well = d[np.abs(np.sin(want[..., 0])) > 1e-3] if k else d
+            with capsys.disabled():
+                print(f"\n[maps {n}: dst lens {lens}, stage {k} ({'after %d rotation(s)' % k if k else 'get_coordinate_map'}), {name}] "
+                      f"max {int(d.max())} ulp, {int((d > 1).sum())} of {d.size} values beyond 1 ulp, "
+                      f"max away from the poles {int(well.max()) if well.size else 0} ulp", end="")
             assert ok.all(), f"stage {k} {name}: max {d.max()} ulp"
 
 
