@@ -201,3 +201,42 @@ def test_window_budget_only_moves_tiles_between_paths(case):
                 b0 = got.clone()
             assert torch.equal(got, b0), budget
     assert leans == sorted(leans, reverse=True) and leans[0] > leans[-1]  # smaller windows: fewer LEAN tiles
+
+
+BATCH_CASES = [
+    Case("bt_pano", cam(200, 232, "equisolid", 200, 99.5), pano(160, 320), [(10, 20, 30)]),  # ragged grid: 7 x 8 tiles, not a multiple of anything
+    Case("bt_cam", pano(192, 384), cam(256, 256, "equidistant", 360, inscribed(256)), mask=1),
+    Case("bt_super", cam(512, 512, "equidistant", 360, inscribed(512)), pano(384, 768)),  # 8 x 8 tile groups: the super-tile launch order
+    Case("bt_double", pano(160, 320), dbl(192, 384, "equidistant", 195), [(3, 90, -7)], mask=2),
+]
+
+
+@pytest.mark.parametrize("case", BATCH_CASES, ids=[c.name for c in BATCH_CASES])
+def test_batches_are_a_grid_dimension_and_change_no_byte(case):
+    """pb_remap_u8 with n_frames > 1 is ONE launch whose grid spans the frames (frame-major; double sources: chunks of
+    frames): 37 distinct frames in one call, through explicit strides, equal 37 single-frame calls and the faithful
+    kernel byte for byte - ragged grids, the super-tile launch order and the padded tail of a frame's workgroups included."""
+    import ctypes
+
+    n = 37
+    _, h, w, *_ = case.src
+    Hd, Wd = case.dst[1], case.dst[2]
+    sb, db = h * w * 3, Hd * Wd * 3
+    s_stride, d_stride = (sb + 48 + 15) // 16 * 16, db + 32  # frames apart from each other: strides larger than a frame
+    src = torch.zeros(n * s_stride, dtype=torch.uint8, device="cuda")
+    for f in range(n):
+        src[f * s_stride : f * s_stride + sb] = nat.synth_frame(h, w, frame=f, circle_mask=case.mask).reshape(-1)
+    plan = H.pb_plan(case)
+    assert plan.info()["fast_path"]
+    dst = torch.full((n * d_stride,), 0xAB, dtype=torch.uint8, device="cuda")
+    nat.check(nat.load().pb_remap_u8(plan.handle, src.data_ptr(), dst.data_ptr(), n, s_stride, d_stride, nat.current_stream()))
+    plan.set_mode(nat.MODE_FAITHFUL)
+    for f in (0, 1, 17, 35, 36):
+        frame = src[f * s_stride : f * s_stride + sb].reshape(h, w, 3)
+        want = plan.remap(frame)
+        assert torch.equal(dst[f * d_stride : f * d_stride + db].reshape(Hd, Wd, 3), want), f
+        assert bool((dst[f * d_stride + db : (f + 1) * d_stride] == 0xAB).all()), "the gap between frames was written"
+    plan.set_mode(nat.MODE_AUTO)
+    for f in (5, 36):
+        frame = src[f * s_stride : f * s_stride + sb].reshape(h, w, 3)
+        assert torch.equal(plan.remap(frame), dst[f * d_stride : f * d_stride + db].reshape(Hd, Wd, 3))
