@@ -31,7 +31,7 @@ calib = {
 }
 json.dump(calib, open(f'{DST}/r02_counter_calibration.json', 'w'), indent=1)
 print(json.dumps(calib, indent=1))
-budgets = {'c1': 7168, 'c2': 12288, 'c3': 7168, 'c5': 7168, 'c4shard': 12288, 'c5shard': 7168, 'c2_alldirect': 4224}
+budgets = {'c1': 7168, 'c2': 7168, 'c3': 7168, 'c5': 7168, 'c4shard': 7168, 'c5shard': 7168, 'c2_alldirect': 4224, 'c2_b12288': 12288}
 for cfg, bud in budgets.items():
     b = json.loads(open(f'{SRC}/{cfg}_bench.json').read().strip().splitlines()[-1])
     kern = 'pb_hot_double_kernel' if cfg.startswith('c5') else 'pb_hot_win_kernel'
@@ -55,7 +55,7 @@ for cfg, bud in budgets.items():
         'bench_kernel_ms_mean_same_run': r['kernel_ms_mean'], 'plan': r['plan'],
         'source_files': [f'profiles/r02_{cfg}_kernel_stats.csv', 'experiments/profile_r2.sh'],
     }
-    name = f'{DST}/traffic_{cfg}_{bud}.json' if cfg != 'c2_alldirect' else f'{DST}/traffic_c2_{bud}.json'
+    name = f'{DST}/traffic_{cfg}_{bud}.json' if not cfg.startswith('c2_') else f'{DST}/traffic_c2_{bud}.json'
     json.dump(t, open(name, 'w'), indent=1)
     print(cfg, bud, 'fetch x2 %.1f MB write %.1f MB total %.1f MB = %.2fx algorithmic, %.2fx must-move; rocprof avg %.2f us vs hipEvent %.2f us' % (
         2 * f[0] * 1024 / 1e6, w[0] * 1024 / 1e6, hbm / 1e6, t['traffic_over_algorithmic'], t['traffic_over_must_move'], t['rocprof_kernel_avg_ns'] / 1e3, r['kernel_ms_mean'] * 1e3))

@@ -20,6 +20,7 @@ run c5 --config c5
 run c4shard --config c4shard
 run c5shard --config c5shard
 run c2_alldirect --config c2 --budget 4224
+run c2_b12288 --config c2 --budget 12288
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/raw_calib_$c -- $R/experiments/exp_calib > $O/calib_$c.log 2>&1
   python3 $R/experiments/pmc_summary.py $O/raw_calib_$c > $O/calib_pmc_$c.txt; cat $O/calib_pmc_$c.txt

@@ -108,7 +108,7 @@ void pb_plan_destroy(pb_plan* plan);
  *               PB_PLAN_TUNE   after preparation, pick the LDS window budget by timing four candidates on scratch
  *                              frames (allocates frame-sized scratch, tens of frames' worth of GPU time; opt-in).
  *   win_budget  bytes of LDS window per wave for the hot kernels (multiple of 16 in [4224, 12288]; clamped);
- *               0 = the library default (8176).  It decides which PATH a tile takes, never its pixels.
+ *               0 = the library default (7168).  It decides which PATH a tile takes, never its pixels.
  * Creation never times anything or allocates frame-sized memory unless PB_PLAN_TUNE is given. */
 #define PB_PLAN_DEFER 1u
 #define PB_PLAN_TUNE 2u

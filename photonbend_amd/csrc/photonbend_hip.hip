@@ -361,7 +361,8 @@ static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t*
 // side wins depends on the geometry.  The classification only decides the PATH a tile takes, never its pixels
 // (same model, same anchors, same tables), so a budget change cannot change a byte.
 #define PB_DEFAULT_EXP 0
-#define PB_DEFAULT_WIN_BUDGET 8176  // 5 workgroups per CU; c1 / c3 / c5 measured fastest at 7-8 KiB, c2 within 4 % of its best
+#define PB_DEFAULT_WIN_BUDGET 7168  // 5 workgroups per CU: fastest or within noise of the fastest on every BASELINE geometry (round-2 sweep r2o / r2p:
+                                    // c1 14.3 us vs 15.1-16 elsewhere, c3 38.4, c5 86.4, c2 flat 44.1-44.6 from 7 to 12 KiB, batches 33.0-33.5 vs 34.9 at 12 KiB)
 static int pb_clamp_budget(int budget) {
     budget &= ~15;
     if (budget < PB_DIRECT_LDS_BYTES) budget = PB_DIRECT_LDS_BYTES;
