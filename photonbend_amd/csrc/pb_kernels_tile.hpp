@@ -597,9 +597,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
         dst += (unsigned long long)f * dst_stride;
     }
     // wave slot in launch order: `table` is the plan's LAUNCH-ORDER copy of the tile entries (pb_launch_table_kernel) -
-    // workgroup ids keep their XCD residue, and within an XCD the plan has put the 256x256-px super-tiles in an order
-    // that mixes texture-path-bound (direct gather) and bandwidth-bound (window) tiles in time and leaves the cheap,
-    // all-black ones for the drain of the launch.  The entry itself says which tile it is: no index arithmetic.
+    // workgroup ids keep their XCD residue, XCD x takes the super-tiles x, x + 8, ... of the output (neighbours in space
+    // are neighbours in time and share an L2).  The entry itself says which tile it is: no index arithmetic.
     const unsigned flat = (wg >> 3) * wpw + (unsigned)wave_in_wg;
     const unsigned vslot = ((flat >> 2) * 8u + (wg & 7u)) * 4u + (flat & 3u);
     PbTileEntry entry;
@@ -663,17 +662,17 @@ __global__ void pb_budget_kernel(PbTileEntry* __restrict__ table, const int32_t*
 // nullptr: grids that do not divide into super-tiles) virtual workgroup B is tile group B.
 __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
                                                               PbTileEntry* __restrict__ ltable, const int* __restrict__ unit_of,
-                                                              int units_per_xcd, unsigned n_slots) {
+                                                              int units_per_xcd, unsigned n_slots, int unit_side) {
     const unsigned v = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (v >= n_slots) return;
     const unsigned B = v >> 2, wave = v & 3u;
     const int gx = (pb_tiles_x(P) + 1) / 2, gy = (pb_tiles_y(P) + 1) / 2;
     long long group = B;
     if (unit_of) {
-        const unsigned xcd = B & 7u, slot = B >> 3, k = slot >> 4, inner = slot & 15u;
+        const unsigned U = (unsigned)unit_side, xcd = B & 7u, slot = B >> 3, k = slot / (U * U), inner = slot - k * U * U;
         const int S = (int)k < units_per_xcd ? unit_of[xcd * units_per_xcd + k] : -1;
-        const int sgx = gx >> 2;
-        group = S < 0 ? -1 : (long long)((S / sgx) * 4 + (int)(inner >> 2)) * gx + (S % sgx) * 4 + (int)(inner & 3u);
+        const int sgx = gx / (int)U;
+        group = S < 0 ? -1 : (long long)((S / sgx) * (int)U + (int)(inner / U)) * gx + (S % sgx) * (int)U + (int)(inner % U);
     }
     int tx = -1, ty = -1;
     if (group >= 0 && group < (long long)gx * gy) {

@@ -382,15 +382,16 @@ static int pb_build_launch_table(pb_plan* pl) {
     if (!pl->fast_ready) return PB_OK;
     const unsigned tiles_x = (P.dst.width + PB_TILE - 1) / PB_TILE, tiles_y = (P.dst.height + PB_TILE - 1) / PB_TILE;
     const unsigned gx = (tiles_x + 1) / 2, gy = (tiles_y + 1) / 2;
-    const bool units = (gx & 3u) == 0 && (gy & 3u) == 0 && ((gx * gy) & 127u) == 0;
+    static const unsigned U = [] { const char* e = getenv("PB_UNIT"); const int v = e ? atoi(e) : 4; return (v == 2 || v == 8 || v == 16) ? (unsigned)v : 4u; }();  // workgroups per unit side
+    const bool units = gx % U == 0 && gy % U == 0 && (gx / U) * (gy / U) >= 16u;
     static const int order_mode = [] { const char* e = getenv("PB_ORDER"); return e ? atoi(e) : 0; }();
     std::vector<int> unit_of;
     int units_per_xcd = 0;
     unsigned n_groups = (gx * gy + 7u) & ~7u;
     if (units) {
-        const unsigned sgx = gx / 4, sgy = gy / 4, ns = sgx * sgy;
+        const unsigned sgx = gx / U, sgy = gy / U, ns = sgx * sgy;
         units_per_xcd = (int)((ns + 7u) / 8u);
-        n_groups = 8u * (unsigned)units_per_xcd * 16u;
+        n_groups = 8u * (unsigned)units_per_xcd * U * U;
         std::vector<int32_t> flags(pl->n_tiles);
         PB_HIP(hipMemcpy2D(flags.data(), sizeof(int32_t), reinterpret_cast<const uint8_t*>(pl->table) + offsetof(PbTileEntry, flags), sizeof(PbTileEntry),
                            sizeof(int32_t), pl->n_tiles, hipMemcpyDeviceToHost));
@@ -398,8 +399,8 @@ static int pb_build_launch_table(pb_plan* pl) {
         for (unsigned S = 0; S < ns; ++S) {
             float c = 0.f;
             const unsigned sy = S / sgx, sx = S % sgx;
-            for (unsigned ty = sy * 8; ty < sy * 8 + 8 && ty < tiles_y; ++ty)
-                for (unsigned tx = sx * 8; tx < sx * 8 + 8 && tx < tiles_x; ++tx) {
+            for (unsigned ty = sy * 2 * U; ty < (sy + 1) * 2 * U && ty < tiles_y; ++ty)
+                for (unsigned tx = sx * 2 * U; tx < (sx + 1) * 2 * U && tx < tiles_x; ++tx) {
                     const int f = flags[(size_t)ty * tiles_x + tx];
                     c += (f & PB_TILE_BLACK) ? 0.35f : (f & PB_TILE_LEAN) ? 1.0f : (f & PB_TILE_DIRECT) ? 1.2f : (f & PB_TILE_FAILED) ? 1.3f : 1.5f;
                 }
@@ -434,7 +435,7 @@ static int pb_build_launch_table(pb_plan* pl) {
             return pb_fail(PB_ERR_HIP, "launch table: upload failed");
         }
     }
-    hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, pl->ltable, unit_dev, units_per_xcd, n_slots);
+    hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, pl->ltable, unit_dev, units_per_xcd, n_slots, (int)U);
     const hipError_t e = hipDeviceSynchronize();
     (void)hipFree(unit_dev);
     PB_HIP(e);
