@@ -40,10 +40,13 @@ T = np.frombuffer(buf, dtype=np.uint64).reshape(nt, 16).astype(np.int64)
 tab = (ctypes.c_int32 * (nt * 64))()
 assert lib.pb_debug_copy_table(plan.handle, tab, nt * 256) == 0
 flags = np.frombuffer(tab, dtype=np.int32).reshape(nt, 64)[:, 2]
+if case.src[0] == 'double':
+    names = ['start->descs', 'descs->issued', 'issued->addr (math)', 'addr->landed', 'landed->stores issued', 'stores issued->done', 'done->wave end']
 t0 = T[:, 0][T[:, 0] > 0].min()
 us = lambda x: x * 0.01  # 100 MHz
 print('event time %.1f us; trace span %.1f us (first wave start -> last wave done); budget %d' % (e0.elapsed_time(e1) * 1e3, us(T[:, 7].max() - t0), info['window_budget']), info)
-names = ['start->entry', 'entry->addr', 'addr->issued', 'issued->landed', 'landed->stores issued', 'stores issued->done', 'done->wave end']
+names0 = ['start->entry', 'entry->addr', 'addr->issued', 'issued->landed', 'landed->stores issued', 'stores issued->done', 'done->wave end']
+names = names if case.src[0] == 'double' else names0
 classes = {'LEAN': (flags & 4) != 0, 'DIRECT': (flags & 16) != 0, 'BLACK': (flags & 8) != 0, 'GENERIC': (flags & (4 | 16 | 8 | 2)) == 0, 'FAILED': (flags & 2) != 0}
 for cname, m in classes.items():
     n = int(m.sum())
@@ -51,7 +54,7 @@ for cname, m in classes.items():
     Tm = T[m]
     life = us(Tm[:, 7] - Tm[:, 0])
     print('%-8s %6d tiles  wave life mean %.2f us p50 %.2f p90 %.2f' % (cname, n, life.mean(), np.percentile(life, 50), np.percentile(life, 90)))
-    if cname in ('LEAN', 'DIRECT'):
+    if cname in ('LEAN', 'DIRECT') or case.src[0] == 'double':
         for i, nm in enumerate(names):
             a, b = (i, i + 1)
             d = us(Tm[:, b] - Tm[:, a])

@@ -48,6 +48,38 @@ __device__ __forceinline__ PbDesc pb_load_desc(const PbTileEntry* __restrict__ e
     return d;
 }
 
+// A tile entry held as ONE vector register (lane i = dword i of the 256-byte entry, one coalesced load): fields and
+// coefficients come out with v_readlane (constant lane -> scalar register).  The double kernel needs two entries per tile:
+// 128 scalar registers do not exist, and scalar loads on demand put a memory round trip into the middle of the model math
+// (measured on c5, experiments/diag_trace.py: 2.85 us of a wave's 8.3 us went there).
+#define PB_E_DWORD(field) (offsetof(PbTileEntry, field) / 4)
+__device__ __forceinline__ int pb_lane_i(unsigned v, int dword) { return __builtin_amdgcn_readlane((int)v, dword); }
+__device__ __forceinline__ float pb_lane_f(unsigned v, int dword) { return __int_as_float(__builtin_amdgcn_readlane((int)v, dword)); }
+
+__device__ __forceinline__ PbDesc pb_desc_of_lanes(unsigned v) {
+    PbDesc d;
+    d.flags = pb_lane_i(v, PB_E_DWORD(flags)); d.anchor_r = pb_lane_i(v, PB_E_DWORD(anchor_r)); d.anchor_c = pb_lane_i(v, PB_E_DWORD(anchor_c));
+    d.win_rows = pb_lane_i(v, PB_E_DWORD(win_rows)); d.win_r0 = pb_lane_i(v, PB_E_DWORD(win_r0)); d.win_c0 = pb_lane_i(v, PB_E_DWORD(win_c0));
+    d.win_cols = pb_lane_i(v, PB_E_DWORD(win_cols)); d.win_n16 = pb_lane_i(v, PB_E_DWORD(win_n16)); d.win_a0 = pb_lane_i(v, PB_E_DWORD(win_a0));
+    return d;
+}
+
+// pb_collapse_row on a lane-held entry: the same packed FMAs on the same values, hence the same bits
+__device__ __forceinline__ void pb_collapse_row_lanes(unsigned v, int y, pb_f2 a[5]) {
+    const float t = pb_tile_coord(y);
+    const int c0 = PB_E_DWORD(c);
+#pragma unroll
+    for (int n = 0; n < 5; ++n) {
+        pb_f2 s = {pb_lane_f(v, c0 + 2 * (20 + n)), pb_lane_f(v, c0 + 2 * (20 + n) + 1)};
+#pragma unroll
+        for (int m = 3; m >= 0; --m) {
+            const pb_f2 cm = {pb_lane_f(v, c0 + 2 * (m * 5 + n)), pb_lane_f(v, c0 + 2 * (m * 5 + n) + 1)};
+            s = pb_fma2(s, t, cm);
+        }
+        a[n] = s;
+    }
+}
+
 #define PB_D_PLAIN(flags) ((flags) & (PB_TILE_LEAN | PB_TILE_DIRECT))
 #define PB_D_GENERIC(flags) (!((flags) & (PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK | PB_TILE_FAILED)))
 
@@ -94,7 +126,7 @@ __device__ __forceinline__ void pb_d_issue(const PbDesc& D, const PbTileCtx& C, 
 //   LEAN: byte address in the eye's LDS window; DIRECT: byte offset in the frame; generic: (row << 16 | col) or -1
 template <int SRC_KIND>
 __device__ __forceinline__ void pb_d_math(const PbParams& P, const PbDesc& D, const PbTileCtx& C, const PbTileEntry* __restrict__ e,
-                                          unsigned q[16]) {
+                                          const unsigned ve, unsigned q[16]) {
     if (PB_D_PLAIN(D.flags)) {
         const bool lean = (D.flags & PB_TILE_LEAN) != 0;
         const unsigned pitch = lean ? 16u * (unsigned)D.win_n16 : C.rowbytes;
@@ -102,7 +134,7 @@ __device__ __forceinline__ void pb_d_math(const PbParams& P, const PbDesc& D, co
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
             pb_f2 a[5];
-            pb_collapse_row(e, C.yb + 8 * jr, a);
+            pb_collapse_row_lanes(ve, C.yb + 8 * jr, a);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const pb_f2 fv = pb_eval_row(a, C.u[k]);
@@ -215,13 +247,18 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int tx, ty;
     if (!pb_tile_of_wave(P, wave, tx, ty, group)) return;
+    const int lane = C.lane;  // (PB_TR)
+    PB_TR(0);
     const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
     const PbTileEntry* __restrict__ el = table_l + tile;
     const PbTileEntry* __restrict__ er = table_r + tile;
-    const PbDesc DL = pb_load_desc(el), DR = pb_load_desc(er);
+    // both entries: one coalesced 256-byte vector load each, in flight together
+    const unsigned vl = reinterpret_cast<const unsigned*>(el)[C.lane], vr = reinterpret_cast<const unsigned*>(er)[C.lane];
+    const PbDesc DL = pb_desc_of_lanes(vl), DR = pb_desc_of_lanes(vr);
+    PB_TR(1);
     if ((DL.flags | DR.flags) & PB_TILE_FAILED) {
         // failed tile: every pixel through its stored faithful taps and factors (lane = 4 consecutive pixels x 4 rows)
-        const PbDoubleFix* __restrict__ slot = tile_fix + (size_t)er->aux_off * (PB_TILE * PB_TILE);
+        const PbDoubleFix* __restrict__ slot = tile_fix + (size_t)pb_lane_i(vr, PB_E_DWORD(aux_off)) * (PB_TILE * PB_TILE);
         const int xg = C.lane & 7, yb = C.lane >> 3, W = P.dst.width, H = P.dst.height;
         for (int f = 0; f < frames; ++f) {
             const uint8_t* s = src + (unsigned long long)f * src_stride;
@@ -248,6 +285,32 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
         }
         return;
     }
+    // A tile that sees ONE eye - the other eye's samples fall outside its image circle (its tile is BLACK), unit blend
+    // weights, nothing on the fix lists - is a plain camera-source tile: its bytes are the live eye's samples (l + 0).
+    // Most tiles of a stitch are of this kind (28 260 of c5's 32 768), and the single-source tile code does them with
+    // half the vector instructions of the two-eye path (PMC: 968 per wave against 405-445).
+    {
+        const int nl = pb_lane_i(vl, PB_E_DWORD(fix_cnt)), nr = pb_lane_i(vr, PB_E_DWORD(fix_cnt));
+        const int plain = PB_TILE_LEAN | PB_TILE_DIRECT;
+        const bool solo_ok = (DL.flags & PB_TILE_W_UNIT) && nl == 0 && nr == 0;
+        const bool solo_l = solo_ok && (DR.flags & PB_TILE_BLACK) && (DL.flags & (plain | PB_TILE_BLACK));
+        const bool solo_r = solo_ok && !solo_l && (DL.flags & PB_TILE_BLACK) && (DR.flags & plain);
+        if (solo_l || solo_r) {
+            const unsigned ve = solo_l ? vl : vr;
+            PbTileEntry entry;
+            int* w = reinterpret_cast<int*>(&entry);
+#pragma unroll
+            for (int i = 0; i < 64; ++i) w[i] = __builtin_amdgcn_readlane((int)ve, i);
+            const int sflags = entry.flags & (plain | PB_TILE_BLACK);
+            pb_win_tile<PB_KIND_CAMERA>(P, &entry, sflags, tx, ty, lane, pb_wave_window(P, wave, 8), src, dst, frames, src_stride, dst_stride);
+#ifdef PB_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PB_TR(6);
+            PB_TR(7);
+#endif
+            return;
+        }
+    }
     const bool by_row = WMODE == 1 && (DL.flags & PB_TILE_W_ROW) != 0;
     const bool by_lat = WMODE == 2 && (DL.flags & PB_TILE_W_LAT) != 0;
     C.rowbytes = 3u * (unsigned)P.src.width;
@@ -270,10 +333,12 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     for (int n = 0; n < 16; ++n) ql[n] = qr[n] = al[n] = ar[n] = 0u;
     pb_d_issue(DL, C, budget_l, src, win_l);
     pb_d_issue(DR, C, budget_r, src, win_r);
-    pb_d_math<PB_KIND_EYE_L>(P, DL, C, el, ql);
+    PB_TR(2);
+    pb_d_math<PB_KIND_EYE_L>(P, DL, C, el, vl, ql);
     if (DL.flags & PB_TILE_DIRECT) pb_d_direct_loads(ql, src, al);
-    pb_d_math<PB_KIND_EYE_R>(P, DR, C, er, qr);
+    pb_d_math<PB_KIND_EYE_R>(P, DR, C, er, vr, qr);
     if (DR.flags & PB_TILE_DIRECT) pb_d_direct_loads(qr, src, ar);
+    PB_TR(3);
     // blend factors: per row group (UNIT / ROW), or per pixel from the stored latitudes (LAT; the loads fly with
     // the window loads, the factors are evaluated at the blend)
     double fl[4], fr[4];
@@ -289,7 +354,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     }
     double lat[WMODE == 2 ? 16 : 1];
     if (by_lat) {
-        const double* __restrict__ lt = lat_tab + (size_t)el->aux_off * PB_LAT_TILE_DOUBLES;
+        const double* __restrict__ lt = lat_tab + (size_t)pb_lane_i(vl, PB_E_DWORD(aux_off)) * PB_LAT_TILE_DOUBLES;
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr)
 #pragma unroll
@@ -316,6 +381,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both windows / the direct gathers have landed
         pb_wave_sync();
+        PB_TR(4);
         pb_d_gather(DL, C, budget_l, ql, win_l, s, al);
         pb_d_gather(DR, C, budget_r, qr, win_r, s, ar);
 #pragma unroll
@@ -351,20 +417,25 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
                     }
             }
         }
+        PB_TR(5);
         if (f + 1 < frames) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // every lane has read its samples: the windows may be refilled
             pb_wave_sync();
         }
     }
+#ifdef PB_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PB_TR(6);
+#endif
     // the tile's fix pixels (either eye's list; a pixel listed by both is written twice): through their stored taps,
     // after the wave's own stores have completed
-    const int nl = el->fix_cnt, nr = er->fix_cnt;  // <= PB_TILE_FAIL_LIMIT each
+    const int nl = pb_lane_i(vl, PB_E_DWORD(fix_cnt)), nr = pb_lane_i(vr, PB_E_DWORD(fix_cnt));  // <= PB_TILE_FAIL_LIMIT each
     if (nl + nr > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (int base = 0; base < nl + nr; base += 64) {
             const int n = base + C.lane;
             if (n < nl + nr) {
-                const int item = n < nl ? el->fix_off + n : er->fix_off + (n - nl);
+                const int item = n < nl ? pb_lane_i(vl, PB_E_DWORD(fix_off)) + n : pb_lane_i(vr, PB_E_DWORD(fix_off)) + (n - nl);
                 const unsigned p = (unsigned)fix_px[item];
                 const PbDoubleFix t = px_fix[item];
                 for (int f = 0; f < frames; ++f) {
@@ -377,6 +448,10 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
             }
         }
     }
+#ifdef PB_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PB_TR(7);
+#endif
 }
 
 // Plan creation: the faithful taps and factors of the failed tiles' pixels (blocks [0, 4 * n_fail_tiles), 256 px
