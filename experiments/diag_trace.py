@@ -75,3 +75,14 @@ for cname, m in classes.items():
 print('distinct CU keys:', len(np.unique(cu_key)))
 order = np.argsort(starts)
 print('wave starts (us after first) deciles:', [round(us(np.percentile(starts - t0, q)), 1) for q in range(0, 101, 10)])
+# per-XCD view (HW_REG_XCC_ID of the wave): does one XCD finish late?
+if case.src[0] != 'double':
+    xcd = T[:, 14] & 15; wgid = T[:, 14] >> 8
+    print('XCC_ID == workgroup & 7 for %.1f %% of waves' % (100.0 * ((wgid & 7) == xcd)[starts > 0].mean()))
+    for x in range(8):
+        m = (xcd == x) & (starts > 0) & (ends > 0)
+        if not m.any(): continue
+        print('XCD %d: %5d tiles (%5d black) first start %.1f last start %.1f last end %.1f us; busy wave-us %.0f' % (
+            x, int(m.sum()), int((m & classes['BLACK']).sum()), us(starts[m].min() - t0), us(starts[m].max() - t0), us(ends[m].max() - t0), us((ends[m] - starts[m]).sum())))
+if os.environ.get('PB_TRACE_SAVE'):
+    np.savez_compressed(os.environ['PB_TRACE_SAVE'], T=T, table=np.frombuffer(tab, dtype=np.int32).reshape(nt, 64))

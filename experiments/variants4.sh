@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1; shift; mkdir -p $O
 for spec in "$@"; do
   set -- $spec; envs=$1; bud=$2; cfg=$3; shift 3
-  tag=${cfg}_${envs//[,=]/_}_b${bud}$(echo "$*" | tr -d ' -')
+  e2=${envs//\/root\/repo\/experiments\//}; tag=${cfg}_${e2//[,=.]/_}_b${bud}$(echo "$*" | tr -d ' -')
   env $(echo $envs | tr ',' ' ') timeout -k 10 200 python bench.py --config $cfg --budget $bud --steps 120 --warmup 10 --no-cpu-baseline "$@" > $O/$tag.json 2> $O/$tag.err || echo "FAILED $tag"
   python3 - <<PY
 import json

@@ -607,13 +607,21 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
     if (entry.flags & PB_TILE_SKIP) return;
     PB_TR(0);
 #ifdef PB_TRACE
-    if (lane == 0 && blockIdx.x / pb_trace_wpf == pb_trace_frame) pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+    if (lane == 0 && blockIdx.x / pb_trace_wpf == pb_trace_frame) {
+        pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + 15] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID
+        pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + 14] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u) | ((unsigned long long)blockIdx.x << 8);  // HW_REG_XCC_ID, workgroup
+    }
 #endif
     const PbTileEntry* __restrict__ e = &entry;
     const int flags = e->flags;
     PB_TR(1);
     if (flags & PB_TILE_FAILED) {
         pb_failed_tile<true>(P, e, tx, ty, lane, src, dst, 1, src_stride, dst_stride, idx_tab);
+#ifdef PB_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PB_TR(6);
+        PB_TR(7);
+#endif
         return;
     }
     pb_win_tile<SRC_KIND>(P, e, flags, tx, ty, lane, pb_wave_window(P, wave_in_wg), src, dst, 1, src_stride, dst_stride);

@@ -372,11 +372,16 @@ static int pb_clamp_budget(int budget) {
 
 // The hot kernel's launch order: the tile entries copied into the order the waves of a launch take them, so that a
 // wave's entry is found by its slot (no tile arithmetic) and the order is the plan's to choose.  Workgroup ids keep
-// their XCD residue (round-robin dispatch: neighbours in one XCD's list share its L2); where the grid divides into
-// 256x256-px super-tiles (16 workgroups), XCD x takes super-tiles x, x + 8, ... in row-major order (PB_ORDER=0, the
-// default).  Cost-aware orders were measured and lost (PB_ORDER=1: heavy and light super-tiles alternating, which does
-// mix the direct-gather and window phases of a c2 frame in time; 2: heaviest first; black tiles last): c2 44.5 -> 45-46 us,
-// the batch 33.5 -> 35.7 - spatial neighbours close in time matter more than what drains last.  Synchronous.
+// their XCD residue (round-robin dispatch); where the grid divides into 256x256-px super-tiles (16 workgroups), XCD x
+// takes the super-tiles x, x + 8, ... of a ROW of super-tiles, and the chip walks through the rows together (every
+// order that gave each XCD its own compact region - row bands, column strips, a Hilbert curve cut into eight - measured
+// 5-15 % slower, in batches too, and so did every order that broke a column's vertical neighbours apart).  Which row comes
+// next is the plan's choice: a launch that ENDS on its cheapest rows drains faster.  Where the rows differ (a fisheye
+// output: black corners above and below, the dense centre between), the walk starts at the heaviest row and moves
+// outwards on two fronts, heavier neighbour first: c2 44.1 -> 41.8 us (ending on the centre rows instead: 46.7).  Rows
+// of even cost keep the plain top-to-bottom order (two fronts cost c3 10 %, c1 2 %).  PB_ORDER=1 forces top-to-bottom.
+// Cost-aware orders of SUPER-TILES (heavy / light alternating, heaviest first, black last, balanced XCDs) all lost:
+// c2 +1...+10 %.  Synchronous.
 static int pb_build_launch_table(pb_plan* pl) {
     PbParams& P = pl->P;
     if (!pl->fast_ready) return PB_OK;
@@ -392,36 +397,43 @@ static int pb_build_launch_table(pb_plan* pl) {
         const unsigned sgx = gx / U, sgy = gy / U, ns = sgx * sgy;
         units_per_xcd = (int)((ns + 7u) / 8u);
         n_groups = 8u * (unsigned)units_per_xcd * U * U;
-        std::vector<int32_t> flags(pl->n_tiles);
-        PB_HIP(hipMemcpy2D(flags.data(), sizeof(int32_t), reinterpret_cast<const uint8_t*>(pl->table) + offsetof(PbTileEntry, flags), sizeof(PbTileEntry),
-                           sizeof(int32_t), pl->n_tiles, hipMemcpyDeviceToHost));
-        std::vector<std::pair<float, int>> cost(ns);
-        for (unsigned S = 0; S < ns; ++S) {
-            float c = 0.f;
-            const unsigned sy = S / sgx, sx = S % sgx;
-            for (unsigned ty = sy * 2 * U; ty < (sy + 1) * 2 * U && ty < tiles_y; ++ty)
-                for (unsigned tx = sx * 2 * U; tx < (sx + 1) * 2 * U && tx < tiles_x; ++tx) {
+        std::vector<unsigned> row_seq(sgy);
+        for (unsigned r = 0; r < sgy; ++r) row_seq[r] = r;
+        if (order_mode == 0 && sgy >= 4) {
+            // a row's cost from its tiles' classes and window widths: a wave's measured life (experiments/diag_trace.py, c2) is
+            // 3 us on a black tile, 10 on a window tile, 9.5 + 0.03 per source column on a direct-gather tile
+            std::vector<int32_t> flags(pl->n_tiles), wcols(pl->n_tiles);
+            PB_HIP(hipMemcpy2D(flags.data(), sizeof(int32_t), reinterpret_cast<const uint8_t*>(pl->table) + offsetof(PbTileEntry, flags), sizeof(PbTileEntry),
+                               sizeof(int32_t), pl->n_tiles, hipMemcpyDeviceToHost));
+            PB_HIP(hipMemcpy2D(wcols.data(), sizeof(int32_t), reinterpret_cast<const uint8_t*>(pl->table) + offsetof(PbTileEntry, win_cols), sizeof(PbTileEntry),
+                               sizeof(int32_t), pl->n_tiles, hipMemcpyDeviceToHost));
+            std::vector<float> row_cost(sgy, 0.f);
+            for (unsigned ty = 0; ty < tiles_y; ++ty) {
+                float c = 0.f;
+                for (unsigned tx = 0; tx < tiles_x; ++tx) {
                     const int f = flags[(size_t)ty * tiles_x + tx];
-                    c += (f & PB_TILE_BLACK) ? 0.35f : (f & PB_TILE_LEAN) ? 1.0f : (f & PB_TILE_DIRECT) ? 1.2f : (f & PB_TILE_FAILED) ? 1.3f : 1.5f;
+                    c += (f & PB_TILE_BLACK) ? 0.3f : (f & PB_TILE_LEAN) ? 0.9f : (f & PB_TILE_DIRECT) ? std::min(2.0f, 0.85f + 0.0027f * (float)wcols[(size_t)ty * tiles_x + tx]) : (f & PB_TILE_FAILED) ? 1.3f : 1.0f;
                 }
-            cost[S] = {c, (int)S};
-        }
-        unit_of.assign((size_t)8 * units_per_xcd, -1);
-        if (order_mode == 0) {
-            for (unsigned S = 0; S < ns; ++S) unit_of[(size_t)(S & 7u) * units_per_xcd + (S >> 3)] = (int)S;  // spatial: S = xcd + 8 k
-        } else {
-            std::stable_sort(cost.begin(), cost.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; });
-            for (unsigned x = 0; x < 8; ++x) {
-                std::vector<int> mine;
-                for (unsigned i = x; i < ns; i += 8) mine.push_back(cost[i].second);  // descending within the XCD
-                const size_t m = mine.size(), half = (m + 1) / 2;
-                for (size_t k = 0; k < m; ++k) {
-                    int S = mine[k];
-                    if (order_mode == 1) S = (k & 1) ? mine[half + k / 2] : mine[k / 2];  // heavy, light, heavy, light, ... (2: descending)
-                    unit_of[(size_t)x * units_per_xcd + k] = S;
+                row_cost[ty / (2 * U)] += c;
+            }
+            const unsigned top = (unsigned)(std::max_element(row_cost.begin(), row_cost.end()) - row_cost.begin());
+            if (row_cost[top] > 1.5f * std::max(row_cost[0], row_cost[sgy - 1])) {
+                int up = (int)top - 1;
+                unsigned down = top + 1, k = 0;
+                row_seq[k++] = top;
+                while (k < sgy) {
+                    const bool take_down = down < sgy && (up < 0 || row_cost[down] >= row_cost[(unsigned)up]);
+                    row_seq[k++] = take_down ? down++ : (unsigned)up--;
                 }
             }
         }
+        unit_of.assign((size_t)8 * units_per_xcd, -1);
+        std::vector<int> filled(8, 0);
+        for (unsigned k = 0; k < sgy; ++k)
+            for (unsigned i = 0; i < sgx; ++i) {
+                const unsigned S = row_seq[k] * sgx + i, x = (k * sgx + i) & 7u;  // XCD = position in the walk, mod 8
+                unit_of[(size_t)x * units_per_xcd + filled[x]++] = (int)S;
+            }
     }
     const unsigned n_slots = 4u * n_groups;
     (void)hipFree(pl->ltable);
