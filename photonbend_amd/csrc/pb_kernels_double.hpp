@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
                 for (int k = 0; k < 4; ++k) a[k] = pb_double_fix_px(slot[(yb + 8 * jr) * PB_TILE + 4 * xg + k], s);
                 const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
                 if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
-                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));
+                    pb_store3<false>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);  // double sources: plain stores (pb_store3)
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
 #pragma unroll
             for (int i = 0; i < 64; ++i) w[i] = __builtin_amdgcn_readlane((int)ve, i);
             const int sflags = entry.flags & (plain | PB_TILE_BLACK);
-            pb_win_tile<PB_KIND_CAMERA>(P, &entry, sflags, tx, ty, lane, pb_wave_window(P, wave, 8), src, dst, frames, src_stride, dst_stride);
+            pb_win_tile<PB_KIND_CAMERA, false>(P, &entry, sflags, tx, ty, lane, pb_wave_window(P, wave, 8), src, dst, frames, src_stride, dst_stride);
 #ifdef PB_TRACE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PB_TR(6);
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
             if (!inside && y >= C.H) continue;
             const unsigned long long off = 3ull * ((unsigned long long)y * C.W + x);
             if ((inside || x + 3 < C.W) && (((uintptr_t)d + off) & 3u) == 0) {
-                __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));  // write-once output
+                pb_store3<false>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)

@@ -195,6 +195,19 @@ __device__ unsigned pb_trace_wpf = 0xFFFFFFFFu, pb_trace_frame = 0;  // workgrou
 #define PB_TR(i)
 #endif
 
+// The 12-byte store of four output pixels.  NT: non-temporal.  A single fisheye source is re-read by neighbouring tiles
+// and keeps its place in L2 when the write-once output goes around it (c1 13.8 us against 17.4 with plain stores, c3
+// batches 29.4 against 33.0); a panorama or a double-fisheye source streams through once, and there plain stores - L2
+// merges the 96-byte row pieces of neighbouring tiles into whole lines - are the faster ones (c2 41.6 -> 40.2 us,
+// c5shard 73.6 -> 71.1; WRITE_SIZE 1.06x the output against 1.23x).
+template <bool NT>
+__device__ __forceinline__ void pb_store3(const pb_u32x3 v, uint8_t* p) {
+    if (NT)
+        __builtin_nontemporal_store(v, reinterpret_cast<pb_u32x3*>(p));
+    else
+        *reinterpret_cast<pb_u32x3*>(p) = v;
+}
+
 // part: this wave issues the row groups part, part + parts, ... (a workgroup loading one window together)
 __device__ __forceinline__ void pb_issue_window_loads(const uint8_t* __restrict__ s, unsigned* win, int lane, unsigned gbase,
                                                       unsigned rowbytes, int nrows, int n16, unsigned safe_len, unsigned part = 0,
@@ -214,7 +227,7 @@ __device__ __forceinline__ void pb_issue_window_loads(const uint8_t* __restrict_
 }
 
 // One tile of the windowed hot kernel (the four tile classes); returns when the tile's pixels are stored.
-template <int SRC_KIND>
+template <int SRC_KIND, bool NT = (SRC_KIND == PB_KIND_CAMERA)>
 __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry* __restrict__ e, const int flags, const int tx,
                                             const int ty, const int lane, unsigned* win, const uint8_t* __restrict__ src,
                                             uint8_t* __restrict__ dst, const int n_frames, const unsigned long long src_stride,
@@ -322,13 +335,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
                 const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
                 if (PB_ABL_NO_STORE(r[0])) continue;
                 if ((((uintptr_t)d + off) & 3u) == 0) {
-                    // panorama sources stream through once: plain stores (L2 merges the half lines of neighbouring
-                    // tiles) measured 2 % faster on c2; fisheye sources are re-read across tiles and keep the
-                    // non-temporal stores that protect them in L2 (c3)
-                    if (SRC_KIND == PB_KIND_PANO)
-                        *reinterpret_cast<pb_u32x3*>(d + off) = pb_pack_px4(r[0], r[1], r[2], r[3]);
-                    else
-                        __builtin_nontemporal_store(pb_pack_px4(r[0], r[1], r[2], r[3]), reinterpret_cast<pb_u32x3*>(d + off));
+                    pb_store3<NT>(pb_pack_px4(r[0], r[1], r[2], r[3]), d + off);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -386,7 +393,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
                 const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
                 if (PB_ABL_NO_STORE(a[0])) continue;
                 if ((((uintptr_t)d + off) & 3u) == 0) {
-                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));  // write-once output: keep it out of the source's cache space
+                    pb_store3<NT>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -461,7 +468,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             if (y < H) {
                 const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
                 if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
-                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));  // write-once output: keep it out of the source's cache space
+                    pb_store3<NT>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
@@ -546,7 +553,7 @@ __device__ __forceinline__ void pb_failed_tile(const PbParams& P, const PbTileEn
             if (y >= H) continue;
             const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
             if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
-                __builtin_nontemporal_store(pb_pack_px4(a[jr][0], a[jr][1], a[jr][2], a[jr][3]), reinterpret_cast<pb_u32x3*>(d + off));
+                pb_store3<true>(pb_pack_px4(a[jr][0], a[jr][1], a[jr][2], a[jr][3]), d + off);  // failed tiles are few: policy irrelevant
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
