@@ -27,7 +27,7 @@ JSON line.
 sample; recomputed here from the plan's own index map and checked against tests/golden/full.json, which holds
 the reference's figure) against the 8 TB/s HBM3E peak, using per-launch HIP-event durations taken on the launch
 stream inside the timed region.  Next to it: ``copy_ceiling_gbs`` (a plain device copy measured in this run),
-``attainable_frac`` (algorithmic bytes / the bytes that MUST cross HBM: every 64-byte source sector that holds a
+``attainable_frac`` (algorithmic bytes / the bytes that MUST cross HBM: every 128-byte source line that holds a
 sample + the output), p10 / p90 of the per-launch durations, ``plan_create_ms`` (cold: the process's first plan, code
 object load included), ``plan_create_warm_ms`` and ``first_frame_ms`` (the once-per-geometry cost that precedes the
 timed region).  ``cpu_baseline`` times the NumPy oracle (the pinned
@@ -224,21 +224,26 @@ def cpu_baseline_all_cores(cfg_name: str, mpx_per_frame: float, processes: int =
         return {"error": repr(exc)}
 
 
+LINE = 128  # bytes the memory side moves per L2 miss (see byte_accounting)
+
+
 def byte_accounting(plan, src_hw, device):
     """From the plan's own integer index map: algorithmic bytes per frame (3 B written per output pixel + 3 B read
-    per in-bounds sample) and the bytes that MUST cross HBM (every 64-byte source sector holding a sampled byte,
-    once, + the output)."""
+    per in-bounds sample) and the bytes that MUST cross HBM: every 128-byte source line holding a sampled byte, once,
+    + the output.  128 B is what the memory side moves per L2 miss on this chip whichever sectors are asked for
+    (experiments/exp_calib.hip: one dword per 128-B line takes the time and the FETCH_SIZE of both its sectors, one dword
+    per 256 B half of that), so a line is the unit a sample drags in."""
     import torch
 
     idx = plan.index_map(device=device).reshape(-1).long()
     valid = idx[idx >= 0]
     h, w = src_hw
-    n_sectors = (3 * h * w + 63) // 64
-    touched = torch.zeros(n_sectors, dtype=torch.bool, device=device)
-    touched[(3 * valid) // 64] = True
-    touched[(3 * valid + 2) // 64] = True
+    n_lines = (3 * h * w + LINE - 1) // LINE
+    touched = torch.zeros(n_lines, dtype=torch.bool, device=device)
+    touched[(3 * valid) // LINE] = True
+    touched[(3 * valid + 2) // LINE] = True
     out_bytes = 3 * plan.dst.height * plan.dst.width
-    return out_bytes + 3 * int(valid.numel()), out_bytes + 64 * int(touched.sum().item())
+    return out_bytes + 3 * int(valid.numel()), out_bytes + LINE * int(touched.sum().item())
 
 
 def copy_ceiling_gbs(lib, nat, device, stream) -> float:

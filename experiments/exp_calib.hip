@@ -60,6 +60,18 @@ __global__ __launch_bounds__(256) void calib_store_12(uint8_t* __restrict__ dst)
         __builtin_nontemporal_store(u3{w, (unsigned)lane, (unsigned)jr}, reinterpret_cast<u3*>(dst + off));
     }
 }
+// sparse reads: one dword at byte `off` of every `stride`-byte block (stride 128, off 0: the first 64-B sector of every
+// 128-B line; two launches with off 0 and off 64 in one kernel = both sectors).  Does the L2 fetch sectors or lines?
+template <int STRIDE, int SECOND>
+__global__ __launch_bounds__(256) void calib_sparse(const uint8_t* __restrict__ src, unsigned* sink, size_t n_blocks) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned acc = 0;
+    for (; i < n_blocks; i += (size_t)gridDim.x * 256) {
+        acc ^= *reinterpret_cast<const unsigned*>(src + i * STRIDE);
+        if (SECOND) acc ^= *reinterpret_cast<const unsigned*>(src + i * STRIDE + SECOND);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 int main() {
     const size_t bytes = 24576ull * 4096, dbytes = 3ull * 4096 * 4096;
     const int POOL = 6;
@@ -70,6 +82,11 @@ int main() {
     for (int i = 0; i < 12; i++) calib_dma_rows96<<<4096, 256, 4 * (64 * 96 + 64)>>>(srcs[i % POOL], sink);
     for (int i = 0; i < 12; i++) calib_gather_dword<<<4096, 256>>>(srcs[i % POOL], sink);
     for (int i = 0; i < 12; i++) calib_store_12<<<4096, 256>>>(dsts[i % POOL]);
+    // n_blocks * STRIDE <= bytes: the last block starts at bytes - STRIDE, its second dword at + 64 + 4 <= bytes
+    for (int i = 0; i < 12; i++) calib_sparse<128, 0><<<2048, 256>>>(srcs[i % POOL], sink, bytes / 128);
+    for (int i = 0; i < 12; i++) calib_sparse<128, 64><<<2048, 256>>>(srcs[i % POOL], sink, bytes / 128);
+    for (int i = 0; i < 12; i++) calib_sparse<256, 0><<<2048, 256>>>(srcs[i % POOL], sink, bytes / 256);
+    for (int i = 0; i < 12; i++) calib_sparse<64, 0><<<2048, 256>>>(srcs[i % POOL], sink, bytes / 64);
     CK(hipDeviceSynchronize());
     printf("known per launch: reads %zu B (all three read kernels), calib_store_12 writes %zu B\n", bytes, dbytes);
     return 0;
