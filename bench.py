@@ -110,6 +110,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip per-launch HIP events (roofline from wall time)")
     ap.add_argument("--event-every", type=int, default=4, help="HIP event pairs bracket groups of this many consecutive timed launches")
+    ap.add_argument("--sampling", choices=["nearest", "bilinear"], default="nearest",
+                    help="nearest = the reference's truncating sampler (the headline); bilinear = the opt-in 4-tap mode (pb_remap_bilinear_u8; no reference behaviour)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the (independent) launches are dealt to round-robin")
     return ap.parse_args()
 
@@ -346,9 +348,12 @@ def main():
     h = plan.handle
     groups_in_pool = pool // batch
 
+    bilinear = args.sampling == "bilinear"
+    remap_fn = lib.pb_remap_bilinear_u8 if bilinear else lib.pb_remap_u8
+
     def step(k):
         i = (k % groups_in_pool) * batch
-        rc = lib.pb_remap_u8(h, sp0 + i * sbytes, dp0 + i * dbytes, batch, sbytes, dbytes, sts[k % n_streams])
+        rc = remap_fn(h, sp0 + i * sbytes, dp0 + i * dbytes, batch, sbytes, dbytes, sts[k % n_streams])
         if rc:
             nat.check(rc)
 
@@ -418,13 +423,15 @@ def main():
         ref_alg = int(pins[cfg["pin"]]["algorithmic_bytes"])
         if alg_frame != ref_alg:
             raise SystemExit(f"bench.py: algorithmic bytes from the plan's index map ({alg_frame}) differ from the reference's ({ref_alg})")
+        if bilinear:  # four taps of 3 bytes per in-bounds sample instead of one (must-move: the same lines, give or take a rim)
+            alg_frame += 3 * ((alg_frame - 3 * dh * dw) // 3) * 3
         alg_launch = alg_frame * batch
         achieved = alg_launch / (launch_ms * 1e-3) / 1e9
         ceiling = copy_ceiling_gbs(lib, nat, device, sts[0])
         info = plan.info()
         traffic = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}_{info['window_budget']}.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not bilinear:
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 traffic_src = os.path.relpath(tpath, ROOT)
@@ -449,7 +456,7 @@ def main():
                 "frames_per_launch": batch,
                 "frames_resident_per_gpu": pool,
                 "streams": n_streams,
-                "sampling": "nearest (truncating), the reference's",
+                "sampling": "bilinear, 4 taps (opt-in mode, not the reference's sampler)" if bilinear else "nearest (truncating), the reference's",
                 "parallelism": f"frames sharded over {world} GPU(s); RCCL broadcast of the parameter block only",
             },
             "plan_create_ms": round(plan_create_ms, 3),
@@ -480,7 +487,7 @@ def main():
                 "plan": info,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not bilinear:  # (the CPU leg times the reference's nearest sampler)
             line["cpu_baseline"] = cpu_baseline(cfg, mpx_per_frame)
             extra = cpu_baseline_all_cores(args.config, mpx_per_frame)
             if extra:

@@ -82,159 +82,177 @@ __device__ __forceinline__ unsigned pb_bilinear_lds(const unsigned* win, float s
     return out;
 }
 
-// ONE: single-frame launch (no frame loop).  LEAN tiles take their taps from the LDS window the nearest mode
-// stages (same plan, same LDS-DMA loads); other tiles gather the taps from the frame.
-template <int SRC_KIND, bool ONE>
+// The four channels' arithmetic of one pixel: taps p00 p01 / p10 p11 (low 3 bytes), weights (tx, ty) -> packed RGB
+__device__ __forceinline__ unsigned pb_bilinear_mix(unsigned p00, unsigned p01, unsigned p10, unsigned p11, float tx, float ty) {
+    unsigned out = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float a = (float)((p00 >> (8 * ch)) & 0xFF), b = (float)((p01 >> (8 * ch)) & 0xFF);
+        const float c = (float)((p10 >> (8 * ch)) & 0xFF), d = (float)((p11 >> (8 * ch)) & 0xFF);
+        const float top = fmaf(tx, b - a, a), bot = fmaf(tx, d - c, c);
+        const float v = fmaf(ty, bot - top, top);
+        out |= ((unsigned)(int)rintf(fminf(fmaxf(v, 0.0f), 255.0f))) << (8 * ch);
+    }
+    return out;
+}
+
+// One wave per tile, launched like pb_hot_win_kernel: `table` is the plan's LAUNCH-ORDER table (the entry says which
+// tile it is), frames of a batch are a grid dimension.  LEAN tiles take their taps from the LDS window the nearest mode
+// stages (same plan, same LDS-DMA loads); DIRECT tiles gather them from the frame, two horizontally adjacent taps (6
+// consecutive bytes) per 8-byte load; other tiles tap by tap.
+template <int SRC_KIND>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
                                                                               const uint8_t* __restrict__ src,
-                                                                              uint8_t* __restrict__ dst, int n_frames_arg,
+                                                                              uint8_t* __restrict__ dst, const unsigned groups_per_frame,
                                                                               unsigned long long src_stride,
                                                                               unsigned long long dst_stride, int windows) {
-    const int n_frames = ONE ? 1 : n_frames_arg;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int tx, ty;
-    if (!pb_tile_of_wave(P, wave, tx, ty)) return;
+    unsigned wg = blockIdx.x;
+    if (wg >= groups_per_frame) {  // a batch: which frame
+        const unsigned f = wg / groups_per_frame;
+        wg -= f * groups_per_frame;
+        src += (unsigned long long)f * src_stride;
+        dst += (unsigned long long)f * dst_stride;
+    }
     PbTileEntry entry;
-    pb_load_entry(table + ((size_t)ty * pb_tiles_x(P) + tx), entry);
+    const unsigned vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)(wg * (unsigned)PB_TILE_WAVES + (unsigned)wave));  // four waves per workgroup: the launch table's slot order
+    pb_load_entry(table + vslot, entry);
     const PbTileEntry* __restrict__ e = &entry;
     const int flags = e->flags;
-    if (flags & PB_TILE_FAILED) return;
+    if (flags & (PB_TILE_SKIP | PB_TILE_FAILED)) return;  // failed tiles: pb_bilinear_fix_kernel
+    const int tx = e->tile_xy & 0xFFFF, ty = (int)((unsigned)e->tile_xy >> 16);
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
-    int xg = lane & 7, yb = lane >> 3;
+    const int xg = lane & 7, yb = lane >> 3;
     const int W = P.dst.width, H = P.dst.height;
     const int h = P.src.height, w = P.src.width;
     unsigned* win = pb_wave_window(P, wave);
     const unsigned rowbytes = 3u * (unsigned)w;
-    const unsigned safe_len = (rowbytes * (unsigned)h) & ~15u;
-    for (int f = 0; f < n_frames; ++f) {
-        const uint8_t* s = src + (unsigned long long)f * src_stride;
-        uint8_t* d = dst + (unsigned long long)f * dst_stride;
-        if (!ONE) {  // keep the per-pixel work inside the frame loop (hoisting it costs hundreds of registers)
-            asm volatile("" : "+v"(xg));
-            asm volatile("" : "+v"(yb));
+    const unsigned frame_bytes = rowbytes * (unsigned)h;
+    const unsigned safe_len = frame_bytes & ~15u;
+    const uint8_t* s = src;
+    uint8_t* d = dst;
+    const int x = X0 + 4 * xg;
+    if ((flags & PB_TILE_LEAN) && windows) {  // (windows == 0: frames LDS-DMA cannot address)
+        const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
+        const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+        pb_f2 fv[4][4];
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            pb_f2 a[5];
+            pb_collapse_row(e, yb + 8 * jr, a);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fv[jr][k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
         }
-        const int x = X0 + 4 * xg;
-        if ((flags & PB_TILE_LEAN) && windows) {  // (windows == 0: frames LDS-DMA cannot address)
-            const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
-            const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
-            pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
-            pb_f2 fv[4][4];
+        asm volatile("" ::: "memory");
+        pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pb_wave_sync();
 #pragma unroll
-            for (int jr = 0; jr < 4; ++jr) {
-                pb_f2 a[5];
-                pb_collapse_row(e, yb + 8 * jr, a);
+        for (int jr = 0; jr < 4; ++jr) {
+            unsigned a[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) fv[jr][k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            pb_wave_sync();
-#pragma unroll
-            for (int jr = 0; jr < 4; ++jr) {
-                unsigned a[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] = pb_bilinear_lds(win, fv[jr][k].x - 0.5f, fv[jr][k].y - 0.5f, pitch, a0);
-                // LEAN tiles lie fully inside the image
-                const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
-                if ((((uintptr_t)d + off) & 3u) == 0) {
-                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
-                        d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
-                        d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
-                    }
-                }
-            }
-            if (f + 1 < n_frames) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                pb_wave_sync();  // the window is refilled by the next frame's loads
-            }
-            continue;
-        }
-        if (flags & PB_TILE_DIRECT) {
-            // sparse window: the four taps straight from the frame, unguarded unaligned dword loads (the tile's
-            // bounding box, margin included, lies inside the frame with room for the last 4-byte read), one row
-            // group's 16 loads in flight together
-            const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
-#pragma unroll
-            for (int jr = 0; jr < 4; ++jr) {
-                pb_f2 c[5];
-                pb_collapse_row(e, yb + 8 * jr, c);
-                unsigned t[4][4];
-                float wy[4], wx[4];
+            for (int k = 0; k < 4; ++k) a[k] = pb_bilinear_lds(win, fv[jr][k].x - 0.5f, fv[jr][k].y - 0.5f, pitch, a0);
+            // LEAN tiles lie fully inside the image
+            const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
+            if ((((uintptr_t)d + off) & 3u) == 0) {
+                pb_store3<SRC_KIND == PB_KIND_CAMERA>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);
+            } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const pb_f2 fv = pb_eval_row(c, pb_tile_coord(4 * xg + k));
-                    const float sy = fv.x - 0.5f, sx = fv.y - 0.5f;
-                    const float fy0 = floorf(sy), fx0 = floorf(sx);
-                    wy[k] = sy - fy0;
-                    wx[k] = sx - fx0;
-                    const unsigned g = gbase + (unsigned)(int)fy0 * rowbytes + __umul24((unsigned)(int)fx0, 3u);
+                    d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+                    d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+                    d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+                }
+            }
+        }
+        return;
+    }
+    if (flags & (PB_TILE_LEAN | PB_TILE_DIRECT)) {
+        // the four taps straight from the frame, unguarded (the tile's bounding box, margin texel included, lies inside
+        // the frame with room for the last 4-byte read).  wide: an 8-byte load takes both taps of a row - allowed when
+        // even the box's last tap has 8 bytes of frame behind it; one row group's loads are in flight together
+        const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+        const bool wide = gbase + (unsigned)(e->win_rows - 1) * rowbytes + 3u * (unsigned)(e->win_cols - 1) + 8u <= frame_bytes;
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            pb_f2 c[5];
+            pb_collapse_row(e, yb + 8 * jr, c);
+            unsigned long long t8[4][2];
+            unsigned t[4][4];
+            float wy[4], wx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const pb_f2 fv = pb_eval_row(c, pb_tile_coord(4 * xg + k));
+                const float sy = fv.x - 0.5f, sx = fv.y - 0.5f;
+                const float fy0 = floorf(sy), fx0 = floorf(sx);
+                wy[k] = sy - fy0;
+                wx[k] = sx - fx0;
+                const unsigned g = gbase + (unsigned)(int)fy0 * rowbytes + __umul24((unsigned)(int)fx0, 3u);
+                if (wide) {
+                    __builtin_memcpy(&t8[k][0], s + g, 8);
+                    __builtin_memcpy(&t8[k][1], s + g + rowbytes, 8);
+                } else {
                     __builtin_memcpy(&t[k][0], s + g, 4);
                     __builtin_memcpy(&t[k][1], s + g + 3u, 4);
                     __builtin_memcpy(&t[k][2], s + g + rowbytes, 4);
                     __builtin_memcpy(&t[k][3], s + g + rowbytes + 3u, 4);
                 }
-                unsigned a[4];
+            }
+            unsigned a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (wide) {
+                    t[k][0] = (unsigned)t8[k][0];
+                    t[k][1] = (unsigned)(t8[k][0] >> 24);
+                    t[k][2] = (unsigned)t8[k][1];
+                    t[k][3] = (unsigned)(t8[k][1] >> 24);
+                }
+                a[k] = pb_bilinear_mix(t[k][0], t[k][1], t[k][2], t[k][3], wx[k], wy[k]);
+            }
+            const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
+            if ((((uintptr_t)d + off) & 3u) == 0) {
+                pb_store3<SRC_KIND == PB_KIND_CAMERA>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);
+            } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    unsigned out = 0;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        const float p = (float)((t[k][0] >> (8 * ch)) & 0xFF), q = (float)((t[k][1] >> (8 * ch)) & 0xFF);
-                        const float r = (float)((t[k][2] >> (8 * ch)) & 0xFF), u = (float)((t[k][3] >> (8 * ch)) & 0xFF);
-                        const float top = fmaf(wx[k], q - p, p), bot = fmaf(wx[k], u - r, r);
-                        const float v = fmaf(wy[k], bot - top, top);
-                        out |= ((unsigned)(int)rintf(fminf(fmaxf(v, 0.0f), 255.0f))) << (8 * ch);
-                    }
-                    a[k] = out;
+                    d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
+                    d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
+                    d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
                 }
-                const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
-                if ((((uintptr_t)d + off) & 3u) == 0) {
-                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));
-                } else {
+            }
+        }
+        return;
+    }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+    for (int jr = 0; jr < 4; ++jr) {
+        const int y = Y0 + yb + 8 * jr;
+        PbRowModel R;
+        pb_model_row(P, e, X0, Y0, yb + 8 * jr, 4 * xg, R);
+        unsigned a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const pb_f2 fv = pb_eval_row(R.a, pb_tile_coord(4 * xg + k));
+            unsigned px = 0;
+            // black where the nearest mode is black: invalid destination pixel / camera position outside the image
+            const float ay = (float)R.anchor_r + fv.x, ax = (float)R.anchor_c + fv.y;
+            bool live = !(flags & PB_TILE_BLACK) && !pb_row_px_invalid(R, k) && y < H && x + k < W;
+            if (SRC_KIND == PB_KIND_CAMERA) live = live && ay >= 0.0f && ay < (float)h && ax >= 0.0f && ax < (float)w;
+            if (live) px = pb_bilinear_taps<SRC_KIND>(P, s, fv.x - 0.5f, fv.y - 0.5f, R.anchor_r, R.anchor_c);
+            a[k] = px;
+        }
+        if (y < H) {
+            const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+            if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
+                pb_store3<SRC_KIND == PB_KIND_CAMERA>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (x + k < W) {
                         d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
                         d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
                         d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
                     }
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            const int y = Y0 + yb + 8 * jr;
-            PbRowModel R;
-            pb_model_row(P, e, X0, Y0, yb + 8 * jr, 4 * xg, R);
-            unsigned a[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const pb_f2 fv = pb_eval_row(R.a, pb_tile_coord(4 * xg + k));
-                unsigned px = 0;
-                // black where the nearest mode is black: invalid destination pixel / camera position outside the image
-                const float ay = (float)R.anchor_r + fv.x, ax = (float)R.anchor_c + fv.y;
-                bool live = !(flags & PB_TILE_BLACK) && !pb_row_px_invalid(R, k) && y < H && x + k < W;
-                if (SRC_KIND == PB_KIND_CAMERA) live = live && ay >= 0.0f && ay < (float)h && ax >= 0.0f && ax < (float)w;
-                if (live) px = pb_bilinear_taps<SRC_KIND>(P, s, fv.x - 0.5f, fv.y - 0.5f, R.anchor_r, R.anchor_c);
-                a[k] = px;
-            }
-            if (y < H) {
-                const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
-                if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
-                    __builtin_nontemporal_store(pb_pack_px4(a[0], a[1], a[2], a[3]), reinterpret_cast<pb_u32x3*>(d + off));
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (x + k < W) {
-                            d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
-                            d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
-                            d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
-                        }
-                }
             }
         }
     }

@@ -794,19 +794,21 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         return PB_OK;
     }
     if (pb_use_fast(plan)) {
-        const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
+        // launched like the nearest hot kernel: the plan's launch-order table, frames of a batch as a grid dimension;
         // LEAN tiles take their taps from LDS windows, except for frames LDS-DMA cannot address (not 16-byte aligned)
-        const bool one = n_frames == 1;
+        const unsigned gpf = plan->launch_groups;
+        const dim3 block(64 * PB_TILE_WAVES);
         const int windows = plan->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
                             ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
+        const int per_launch = (int)(0x7FFFFFFFu / gpf);
 #define PB_LAUNCH_BILINEAR(KIND)                                                                                                     \
     do {                                                                                                                             \
-        if (one)                                                                                                                     \
-            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, true>), grid, block, pb_window_lds_bytes(P), st, P, plan->table, src_dev, dst_dev, n_frames, \
-                               src_frame_stride, dst_frame_stride, windows);                                                         \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, false>), grid, block, pb_window_lds_bytes(P), st, P, plan->table, src_dev, dst_dev, n_frames, \
-                               src_frame_stride, dst_frame_stride, windows);                                                         \
+        for (int f0 = 0; f0 < n_frames; f0 += per_launch) {                                                                          \
+            const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;                                                  \
+            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, pb_window_lds_bytes(P), st, P, plan->ltable, \
+                               src_dev + (unsigned long long)f0 * src_frame_stride, dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, \
+                               (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows);                 \
+        }                                                                                                                            \
         if (plan->n_fail_tiles || plan->n_fix_px)                                                                                    \
             hipLaunchKernelGGL(pb_bilinear_fix_kernel<KIND>, dim3(4u * plan->n_fail_tiles + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK),  \
                                dim3(PB_BLOCK), 0, st, P, plan->fail_tiles, 0, src_dev, dst_dev, n_frames, src_frame_stride,          \
