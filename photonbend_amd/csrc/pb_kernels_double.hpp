@@ -26,6 +26,7 @@
 #include "pb_kernels_sep.hpp"
 #include "pb_kernels_tile.hpp"
 
+static_assert(PB_TILE_W_UNIT_BIT == 64, "PB_TILE_W_UNIT");
 #define PB_TILE_W_UNIT 64   // (left-eye entry) blend factors are exactly 1.0 for every pixel of the tile
 #define PB_TILE_W_ROW 128   // (left-eye entry) blend factors come from the row table
 #define PB_TILE_W_LAT 256   // (left-eye entry) blend factors from the stored per-pixel latitudes (slot aux_off)
@@ -219,6 +220,7 @@ __device__ __forceinline__ unsigned pb_double_fix_px(const PbDoubleFix& t, const
 template <int WMODE, bool ONE>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
                                                                             const PbTileEntry* __restrict__ table_r,
+                                                                            const PbTileEntry* __restrict__ ltable,
                                                                             const PbSepRow* __restrict__ rows,
                                                                             const double* __restrict__ lat_tab,
                                                                             const int32_t* __restrict__ fix_px,
@@ -245,10 +247,32 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     PbTileCtx C;
     C.lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = C.lane;
+    // the wave's slot of the plan's launch-order table (pb_launch_table_kernel): which tile, and - for a tile that sees ONE
+    // eye with weight exactly 1, most tiles of a stitch (28 260 of c5's 32 768) - that eye's entry, already in scalar
+    // registers: a plain camera-source tile, done by the single-source tile code with half the vector instructions of the
+    // two-eye path (PMC: 968 per wave against 405-445)
+    const unsigned vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)(group * (unsigned)PB_TILE_WAVES + (unsigned)wave));
     int tx, ty;
-    if (!pb_tile_of_wave(P, wave, tx, ty, group)) return;
-    const int lane = C.lane;  // (PB_TR)
-    PB_TR(0);
+    {
+        PbTileEntry entry;
+        pb_load_entry(ltable + vslot, entry);
+        if (entry.flags & PB_TILE_SKIP) return;
+        tx = entry.tile_xy & 0xFFFF;
+        ty = (int)((unsigned)entry.tile_xy >> 16);
+        PB_TR(0);
+        if (entry.flags & PB_TILE_SOLO) {
+            PB_TR(1);
+            pb_win_tile<PB_KIND_CAMERA, false>(P, &entry, entry.flags & (PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK), tx, ty, lane,
+                                               pb_wave_window(P, wave, 8), src, dst, frames, src_stride, dst_stride);
+#ifdef PB_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PB_TR(6);
+            PB_TR(7);
+#endif
+            return;
+        }
+    }
     const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
     const PbTileEntry* __restrict__ el = table_l + tile;
     const PbTileEntry* __restrict__ er = table_r + tile;
@@ -284,32 +308,6 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
             }
         }
         return;
-    }
-    // A tile that sees ONE eye - the other eye's samples fall outside its image circle (its tile is BLACK), unit blend
-    // weights, nothing on the fix lists - is a plain camera-source tile: its bytes are the live eye's samples (l + 0).
-    // Most tiles of a stitch are of this kind (28 260 of c5's 32 768), and the single-source tile code does them with
-    // half the vector instructions of the two-eye path (PMC: 968 per wave against 405-445).
-    {
-        const int nl = pb_lane_i(vl, PB_E_DWORD(fix_cnt)), nr = pb_lane_i(vr, PB_E_DWORD(fix_cnt));
-        const int plain = PB_TILE_LEAN | PB_TILE_DIRECT;
-        const bool solo_ok = (DL.flags & PB_TILE_W_UNIT) && nl == 0 && nr == 0;
-        const bool solo_l = solo_ok && (DR.flags & PB_TILE_BLACK) && (DL.flags & (plain | PB_TILE_BLACK));
-        const bool solo_r = solo_ok && !solo_l && (DL.flags & PB_TILE_BLACK) && (DR.flags & plain);
-        if (solo_l || solo_r) {
-            const unsigned ve = solo_l ? vl : vr;
-            PbTileEntry entry;
-            int* w = reinterpret_cast<int*>(&entry);
-#pragma unroll
-            for (int i = 0; i < 64; ++i) w[i] = __builtin_amdgcn_readlane((int)ve, i);
-            const int sflags = entry.flags & (plain | PB_TILE_BLACK);
-            pb_win_tile<PB_KIND_CAMERA, false>(P, &entry, sflags, tx, ty, lane, pb_wave_window(P, wave, 8), src, dst, frames, src_stride, dst_stride);
-#ifdef PB_TRACE
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PB_TR(6);
-            PB_TR(7);
-#endif
-            return;
-        }
     }
     const bool by_row = WMODE == 1 && (DL.flags & PB_TILE_W_ROW) != 0;
     const bool by_lat = WMODE == 2 && (DL.flags & PB_TILE_W_LAT) != 0;

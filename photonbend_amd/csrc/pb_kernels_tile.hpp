@@ -677,7 +677,8 @@ __global__ void pb_budget_kernel(PbTileEntry* __restrict__ table, const int32_t*
 // nullptr: grids that do not divide into super-tiles) virtual workgroup B is tile group B.
 __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
                                                               PbTileEntry* __restrict__ ltable, const int* __restrict__ unit_of,
-                                                              int units_per_xcd, unsigned n_slots, int unit_side) {
+                                                              int units_per_xcd, unsigned n_slots, int unit_side,
+                                                              const PbTileEntry* __restrict__ table_r = nullptr) {
     const unsigned v = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (v >= n_slots) return;
     const unsigned B = v >> 2, wave = v & 3u;
@@ -702,6 +703,25 @@ __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, 
     }
     const int* in = reinterpret_cast<const int*>(table + ((size_t)ty * pb_tiles_x(P) + tx));
     int w = in[lane];
+    if (table_r) {
+        // double-fisheye plan (table = the left eye's entries): a tile that sees ONE eye - the other eye's tile BLACK, unit
+        // blend weights, nothing on either fix list - is a plain camera-source tile; its slot carries the live eye's entry
+        // (PB_TILE_SOLO), which the hot kernel takes with scalar loads and runs through the single-source tile code.  Every
+        // other slot only names its tile: the two-eye path reads both entries itself.
+        const int wr = reinterpret_cast<const int*>(table_r + ((size_t)ty * pb_tiles_x(P) + tx))[lane];
+        const int FL = offsetof(PbTileEntry, flags) / 4, FC = offsetof(PbTileEntry, fix_cnt) / 4;
+        const int fl = __shfl(w, FL), fr = __shfl(wr, FL), nl = __shfl(w, FC), nr = __shfl(wr, FC);
+        const int plain = PB_TILE_LEAN | PB_TILE_DIRECT;
+        const bool solo_ok = (fl & PB_TILE_W_UNIT_BIT) && nl == 0 && nr == 0;
+        const bool solo_l = solo_ok && (fr & PB_TILE_BLACK) && (fl & (plain | PB_TILE_BLACK));
+        const bool solo_r = solo_ok && !solo_l && (fl & PB_TILE_BLACK) && (fr & plain);
+        if (solo_l || solo_r) {
+            if (solo_r) w = wr;
+            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK)) | PB_TILE_SOLO;
+        } else {
+            w = 0;
+        }
+    }
     if (lane == offsetof(PbTileEntry, tile_xy) / 4) w = (ty << 16) | tx;
     out[lane] = w;
 }

@@ -384,7 +384,7 @@ static int pb_clamp_budget(int budget) {
 // c2 +1...+10 %.  Synchronous.
 static int pb_build_launch_table(pb_plan* pl) {
     PbParams& P = pl->P;
-    if (!pl->fast_ready) return PB_OK;
+    if (!pl->fast_ready && !pl->dbl_ready) return PB_OK;  // (a double-fisheye plan: the left eye's table + PB_TILE_SOLO entries)
     const unsigned tiles_x = (P.dst.width + PB_TILE - 1) / PB_TILE, tiles_y = (P.dst.height + PB_TILE - 1) / PB_TILE;
     const unsigned gx = (tiles_x + 1) / 2, gy = (tiles_y + 1) / 2;
     static const unsigned U = [] { const char* e = getenv("PB_UNIT"); const int v = e ? atoi(e) : 4; return (v == 2 || v == 8 || v == 16) ? (unsigned)v : 4u; }();  // workgroups per unit side
@@ -399,7 +399,7 @@ static int pb_build_launch_table(pb_plan* pl) {
         n_groups = 8u * (unsigned)units_per_xcd * U * U;
         std::vector<unsigned> row_seq(sgy);
         for (unsigned r = 0; r < sgy; ++r) row_seq[r] = r;
-        if (order_mode == 0 && sgy >= 4) {
+        if (order_mode == 0 && sgy >= 4 && !pl->dbl_ready) {  // (double sources: the left eye's classes say nothing about a row's cost)
             // a row's cost from its tiles' classes and window widths: a wave's measured life (experiments/diag_trace.py, c2) is
             // 3 us on a black tile, 10 on a window tile, 9.5 + 0.03 per source column on a direct-gather tile
             std::vector<int32_t> flags(pl->n_tiles), wcols(pl->n_tiles);
@@ -447,7 +447,8 @@ static int pb_build_launch_table(pb_plan* pl) {
             return pb_fail(PB_ERR_HIP, "launch table: upload failed");
         }
     }
-    hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, pl->ltable, unit_dev, units_per_xcd, n_slots, (int)U);
+    hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, pl->ltable, unit_dev, units_per_xcd, n_slots, (int)U,
+                       pl->dbl_ready ? pl->table_r : nullptr);
     const hipError_t e = hipDeviceSynchronize();
     (void)hipFree(unit_dev);
     PB_HIP(e);
@@ -730,17 +731,17 @@ static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t*
     if (!src_frame_stride) src_frame_stride = 3ull * P.src.height * P.src.width;
     if (!dst_frame_stride) dst_frame_stride = 3ull * npx;
     const bool windowable = ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;  // LDS-DMA row segments
-    if (plan->dbl_ready && plan->mode != PB_MODE_FAITHFUL && plan->mode != PB_MODE_FAST_DIRECT && windowable) {
-        const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
+    if (plan->dbl_ready && plan->ltable && plan->mode != PB_MODE_FAITHFUL && plan->mode != PB_MODE_FAST_DIRECT && windowable) {
+        const dim3 block(64 * PB_TILE_WAVES);
         // one launch per frame: failed tiles and fix pixels go through the plan's stored faithful taps
         const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
         static const int fpw_env = [] { const char* e = getenv("PB_DOUBLE_FPW"); return e ? atoi(e) : 0; }();
         const int fpw = fpw_env > 0 ? fpw_env : PB_DOUBLE_FRAMES_PER_WAVE;
-        const unsigned gpf = (grid.x + 7u) & ~7u;
+        const unsigned gpf = plan->launch_groups;  // workgroups per frame of the plan's launch-order table
         const unsigned chunks = (unsigned)((n_frames + fpw - 1) / fpw);
         const dim3 bgrid(gpf * chunks);  // (h*w < 2^29 and n_frames an int: far below the grid limit for any batch that fits memory)
 #define PB_LAUNCH_DOUBLE(WMODE, ONE)                                                                                              \
-    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, ONE>), bgrid, block, pb_window_lds_bytes(P, 8), st, P, plan->table, plan->table_r, rows, plan->lat_tab, \
+    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, ONE>), bgrid, block, pb_window_lds_bytes(P, 8), st, P, plan->table, plan->table_r, plan->ltable, rows, plan->lat_tab, \
                        plan->fix_px, plan->dbl_px_fix, plan->dbl_tile_fix, src_dev, dst_dev, n_frames, src_frame_stride,           \
                        dst_frame_stride, gpf, fpw)
         const bool one = n_frames == 1 || fpw == 1;
