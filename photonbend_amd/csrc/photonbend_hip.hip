@@ -397,43 +397,54 @@ static int pb_build_launch_table(pb_plan* pl) {
         const unsigned sgx = gx / U, sgy = gy / U, ns = sgx * sgy;
         units_per_xcd = (int)((ns + 7u) / 8u);
         n_groups = 8u * (unsigned)units_per_xcd * U * U;
-        std::vector<unsigned> row_seq(sgy);
-        for (unsigned r = 0; r < sgy; ++r) row_seq[r] = r;
-        if (order_mode == 0 && sgy >= 4 && !pl->dbl_ready) {  // (double sources: the left eye's classes say nothing about a row's cost)
-            // a row's cost from its tiles' classes and window widths: a wave's measured life (experiments/diag_trace.py, c2) is
-            // 3 us on a black tile, 10 on a window tile, 9.5 + 0.03 per source column on a direct-gather tile
-            std::vector<int32_t> flags(pl->n_tiles), wcols(pl->n_tiles);
-            PB_HIP(hipMemcpy2D(flags.data(), sizeof(int32_t), reinterpret_cast<const uint8_t*>(pl->table) + offsetof(PbTileEntry, flags), sizeof(PbTileEntry),
-                               sizeof(int32_t), pl->n_tiles, hipMemcpyDeviceToHost));
-            PB_HIP(hipMemcpy2D(wcols.data(), sizeof(int32_t), reinterpret_cast<const uint8_t*>(pl->table) + offsetof(PbTileEntry, win_cols), sizeof(PbTileEntry),
-                               sizeof(int32_t), pl->n_tiles, hipMemcpyDeviceToHost));
-            std::vector<float> row_cost(sgy, 0.f);
-            for (unsigned ty = 0; ty < tiles_y; ++ty) {
-                float c = 0.f;
-                for (unsigned tx = 0; tx < tiles_x; ++tx) {
-                    const int f = flags[(size_t)ty * tiles_x + tx];
-                    c += (f & PB_TILE_BLACK) ? 0.3f : (f & PB_TILE_LEAN) ? 0.9f : (f & PB_TILE_DIRECT) ? std::min(2.0f, 0.85f + 0.0027f * (float)wcols[(size_t)ty * tiles_x + tx]) : (f & PB_TILE_FAILED) ? 1.3f : 1.0f;
-                }
-                row_cost[ty / (2 * U)] += c;
+        // the walk: rows of super-tiles top to bottom, XCD = position in the walk mod 8 (plain), unless the plan's tiles say
+        // that work is unevenly spread - then the launch starts on its heaviest part and ENDS on its cheapest, which drains fast:
+        //   rows differ (max / min > 1.3; a fisheye output's black-cornered edges against its dense centre, a panorama's
+        //   pole rows against its rim rows): from the heaviest row outwards on two fronts, heavier neighbour first - the chip
+        //   still walks through whole rows together (c2 44.1 -> 41.8 us, c1 14.1 -> 13.0);
+        //   rows alike but super-tiles differ (max / mean > 1.5; clusters of failed and direct-gather tiles): super-tiles
+        //   heaviest first, dealt round-robin (c3 37.9 -> 35.1 us, batches 32.0 -> 30.7).
+        // Cost of a tile from its class and window: a wave's measured life (experiments/diag_trace.py) is 3 us on a black tile,
+        // 4.2 + 0.4 per KiB of window on a window tile, 9.5 + 0.03 per source column on a direct-gather tile.
+        std::vector<unsigned> seq(ns);  // the walk: super-tile ids in launch order
+        for (unsigned S = 0; S < ns; ++S) seq[S] = S;
+        if (order_mode == 0 && sgy >= 4 && !pl->dbl_ready) {  // (double sources: the left eye's classes say nothing about a tile's cost)
+            std::vector<unsigned> fixed(ns, 0u);
+            unsigned* cost_dev = nullptr;
+            PB_HIP(hipMalloc((void**)&cost_dev, ns * sizeof(unsigned)));
+            (void)hipMemsetAsync(cost_dev, 0, ns * sizeof(unsigned), 0);
+            hipLaunchKernelGGL(pb_unit_cost_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->n_tiles, tiles_x, 2u * U, sgx, cost_dev);
+            const hipError_t ce = hipMemcpy(fixed.data(), cost_dev, ns * sizeof(unsigned), hipMemcpyDeviceToHost);
+            (void)hipFree(cost_dev);
+            PB_HIP(ce);
+            std::vector<float> row_cost(sgy, 0.f), unit_cost(ns, 0.f);
+            for (unsigned S = 0; S < ns; ++S) {
+                unit_cost[S] = (float)fixed[S] / 1024.0f;
+                row_cost[S / sgx] += unit_cost[S];
             }
-            const unsigned top = (unsigned)(std::max_element(row_cost.begin(), row_cost.end()) - row_cost.begin());
-            if (row_cost[top] > 1.5f * std::max(row_cost[0], row_cost[sgy - 1])) {
+            const float rmax = *std::max_element(row_cost.begin(), row_cost.end()), rmin = *std::min_element(row_cost.begin(), row_cost.end());
+            const float umax = *std::max_element(unit_cost.begin(), unit_cost.end());
+            float usum = 0.f;
+            for (float c : unit_cost) usum += c;
+            if (rmax > 1.3f * rmin) {
+                const unsigned top = (unsigned)(std::max_element(row_cost.begin(), row_cost.end()) - row_cost.begin());
                 int up = (int)top - 1;
                 unsigned down = top + 1, k = 0;
+                std::vector<unsigned> row_seq(sgy);
                 row_seq[k++] = top;
                 while (k < sgy) {
                     const bool take_down = down < sgy && (up < 0 || row_cost[down] >= row_cost[(unsigned)up]);
                     row_seq[k++] = take_down ? down++ : (unsigned)up--;
                 }
+                for (unsigned k2 = 0; k2 < sgy; ++k2)
+                    for (unsigned i = 0; i < sgx; ++i) seq[k2 * sgx + i] = row_seq[k2] * sgx + i;
+            } else if (umax * (float)ns > 1.5f * usum) {
+                std::stable_sort(seq.begin(), seq.end(), [&](unsigned a, unsigned b) { return unit_cost[a] > unit_cost[b]; });
             }
         }
         unit_of.assign((size_t)8 * units_per_xcd, -1);
         std::vector<int> filled(8, 0);
-        for (unsigned k = 0; k < sgy; ++k)
-            for (unsigned i = 0; i < sgx; ++i) {
-                const unsigned S = row_seq[k] * sgx + i, x = (k * sgx + i) & 7u;  // XCD = position in the walk, mod 8
-                unit_of[(size_t)x * units_per_xcd + filled[x]++] = (int)S;
-            }
+        for (unsigned p = 0; p < ns; ++p) unit_of[(size_t)(p & 7u) * units_per_xcd + filled[p & 7u]++] = (int)seq[p];  // XCD = position in the walk, mod 8
     }
     const unsigned n_slots = 4u * n_groups;
     (void)hipFree(pl->ltable);
