@@ -725,19 +725,22 @@ __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, 
     if (lane == offsetof(PbTileEntry, tile_xy) / 4) w = (ty << 16) | tx;
     out[lane] = w;
 }
+__device__ __forceinline__ float pb_tile_cost(const PbTileEntry& e) {
+    const int f = e.flags;
+    return (f & PB_TILE_BLACK) ? 0.3f
+         : (f & PB_TILE_LEAN) ? 0.55f + 0.055f * (float)(e.win_rows * 16 * e.win_n16) / 1024.0f
+         : (f & PB_TILE_DIRECT) ? fminf(2.0f, 0.85f + 0.0027f * (float)e.win_cols)
+         : (f & PB_TILE_FAILED) ? 1.5f : 1.0f;
+}
 // Plan creation: the cost of every super-tile for the launch order (fixed point, 1/1024: integer sums are order-independent).
 // A wave's measured life (experiments/diag_trace.py): 3 us on a black tile, 4.2 + 0.4 per KiB of window on a window tile,
 // 9.5 + 0.03 per source column on a direct-gather tile - here relative to a direct-gather tile of ordinary width.
 __global__ void pb_unit_cost_kernel(const PbTileEntry* __restrict__ table, unsigned n_tiles, unsigned tiles_x, unsigned unit_tiles,
-                                    unsigned units_x, unsigned* __restrict__ unit_cost) {
+                                    unsigned units_x, unsigned* __restrict__ unit_cost, const PbTileEntry* __restrict__ table_r = nullptr) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
-    const PbTileEntry& e = table[t];
-    const int f = e.flags;
-    const float c = (f & PB_TILE_BLACK) ? 0.3f
-                  : (f & PB_TILE_LEAN) ? 0.55f + 0.055f * (float)(e.win_rows * 16 * e.win_n16) / 1024.0f
-                  : (f & PB_TILE_DIRECT) ? fminf(2.0f, 0.85f + 0.0027f * (float)e.win_cols)
-                  : (f & PB_TILE_FAILED) ? 1.5f : 1.0f;
+    float c = pb_tile_cost(table[t]);
+    if (table_r) c += pb_tile_cost(table_r[t]) - 0.3f;  // double-fisheye source: both eyes' work (a one-eye tile costs its live eye's)
     const unsigned ty = t / tiles_x, tx = t - ty * tiles_x;
     atomicAdd(&unit_cost[(ty / unit_tiles) * units_x + tx / unit_tiles], (unsigned)(c * 1024.0f + 0.5f));
 }
