@@ -408,7 +408,8 @@ static int pb_build_launch_table(pb_plan* pl) {
         // 4.2 + 0.4 per KiB of window on a window tile, 9.5 + 0.03 per source column on a direct-gather tile.
         std::vector<unsigned> seq(ns);  // the walk: super-tile ids in launch order
         for (unsigned S = 0; S < ns; ++S) seq[S] = S;
-        if (order_mode == 0 && sgy >= 4 && !pl->dbl_ready) {  // (double sources keep the plain walk: the cost-driven one measured 1.5 % slower on c5)
+        std::vector<float> unit_cost;
+        if (order_mode == 0 && sgy >= 4) {
             std::vector<unsigned> fixed(ns, 0u);
             unsigned* cost_dev = nullptr;
             PB_HIP(hipMalloc((void**)&cost_dev, ns * sizeof(unsigned)));
@@ -418,7 +419,8 @@ static int pb_build_launch_table(pb_plan* pl) {
             const hipError_t ce = hipMemcpy(fixed.data(), cost_dev, ns * sizeof(unsigned), hipMemcpyDeviceToHost);
             (void)hipFree(cost_dev);
             PB_HIP(ce);
-            std::vector<float> row_cost(sgy, 0.f), unit_cost(ns, 0.f);
+            std::vector<float> row_cost(sgy, 0.f);
+            unit_cost.assign(ns, 0.f);
             for (unsigned S = 0; S < ns; ++S) {
                 unit_cost[S] = (float)fixed[S] / 1024.0f;
                 row_cost[S / sgx] += unit_cost[S];
@@ -427,7 +429,9 @@ static int pb_build_launch_table(pb_plan* pl) {
             const float umax = *std::max_element(unit_cost.begin(), unit_cost.end());
             float usum = 0.f;
             for (float c : unit_cost) usum += c;
-            if (rmax > 1.3f * rmin) {
+            if (pl->dbl_ready) {
+                // double-fisheye sources keep the plain walk (two fronts measured 1.5 % slower on c5); their problem is another one, below
+            } else if (rmax > 1.3f * rmin) {
                 const unsigned top = (unsigned)(std::max_element(row_cost.begin(), row_cost.end()) - row_cost.begin());
                 int up = (int)top - 1;
                 unsigned down = top + 1, k = 0;
@@ -445,7 +449,47 @@ static int pb_build_launch_table(pb_plan* pl) {
         }
         unit_of.assign((size_t)8 * units_per_xcd, -1);
         std::vector<int> filled(8, 0);
-        for (unsigned p = 0; p < ns; ++p) unit_of[(size_t)(p & 7u) * units_per_xcd + filled[p & 7u]++] = (int)seq[p];  // XCD = position in the walk, mod 8
+        if (pl->dbl_ready && sgx % 8 == 0 && !unit_cost.empty()) {
+            // A stitch's expensive tiles - the seams where both eyes contribute, the eyes' rims - stand in COLUMNS of the
+            // output, and "XCD = column mod 8" hands whole seams to the same XCDs row after row: the chip waits for them
+            // (c5 76.5 us; super-tiles dealt at random 66.6).  Rows are still walked together and a column keeps its XCD from
+            // row to row (vertical neighbours share an L2), but after every row the busiest XCD hands a column to the idlest
+            // when it is more than half a super-tile ahead: c5 76.5 -> 64.6 us, c5shard 68.9 -> 54.7.  (Single sources: the
+            // same exchange measured +-0 on c2 / c3 and costs c1 6 % under the plain walk - not applied.)
+            std::vector<int> owner(sgx);
+            for (unsigned i = 0; i < sgx; ++i) owner[i] = (int)(i & 7u);
+            float total[8] = {0, 0, 0, 0, 0, 0, 0, 0}, all = 0.f;
+            for (float c : unit_cost) all += c;
+            const float thresh = 0.5f * all / (float)ns;
+            for (unsigned r = 0; r < sgy; ++r) {
+                for (unsigned i = 0; i < sgx; ++i) {
+                    const int x = owner[i];
+                    unit_of[(size_t)x * units_per_xcd + filled[x]++] = (int)(r * sgx + i);
+                    total[x] += unit_cost[r * sgx + i];
+                }
+                if (r + 1 == sgy) break;
+                float ahead[8];  // totals as they will stand after the exchanges decided so far
+                for (unsigned x = 0; x < 8; ++x) ahead[x] = total[x];
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int a = (int)(std::max_element(ahead, ahead + 8) - ahead), b = (int)(std::min_element(ahead, ahead + 8) - ahead);
+                    if (ahead[a] - ahead[b] <= thresh) break;
+                    float best = 0.f;
+                    int bi = -1, bj = -1;
+                    for (unsigned i = 0; i < sgx; ++i)
+                        for (unsigned j = 0; j < sgx; ++j)
+                            if (owner[i] == a && owner[j] == b) {
+                                const float gain = unit_cost[(r + 1) * sgx + i] - unit_cost[(r + 1) * sgx + j];  // what `a` sheds next row
+                                if (gain > best) { best = gain; bi = (int)i; bj = (int)j; }
+                            }
+                    if (bi < 0) break;
+                    std::swap(owner[bi], owner[bj]);
+                    ahead[a] -= best;
+                    ahead[b] += best;
+                }
+            }
+        } else {
+            for (unsigned p = 0; p < ns; ++p) unit_of[(size_t)(p & 7u) * units_per_xcd + filled[p & 7u]++] = (int)seq[p];  // XCD = position in the walk, mod 8
+        }
     }
     const unsigned n_slots = 4u * n_groups;
     (void)hipFree(pl->ltable);
