@@ -76,7 +76,7 @@ print('distinct CU keys:', len(np.unique(cu_key)))
 order = np.argsort(starts)
 print('wave starts (us after first) deciles:', [round(us(np.percentile(starts - t0, q)), 1) for q in range(0, 101, 10)])
 # per-XCD view (HW_REG_XCC_ID of the wave): does one XCD finish late?
-if case.src[0] != 'double':
+if True:
     xcd = T[:, 14] & 15; wgid = T[:, 14] >> 8
     print('XCC_ID == workgroup & 7 for %.1f %% of waves' % (100.0 * ((wgid & 7) == xcd)[starts > 0].mean()))
     for x in range(8):

@@ -261,6 +261,10 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
         tx = entry.tile_xy & 0xFFFF;
         ty = (int)((unsigned)entry.tile_xy >> 16);
         PB_TR(0);
+#ifdef PB_TRACE
+        if (lane == 0 && blockIdx.x / pb_trace_wpf == pb_trace_frame)
+            pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + 14] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u) | ((unsigned long long)blockIdx.x << 8);  // HW_REG_XCC_ID, workgroup
+#endif
         if (entry.flags & PB_TILE_SOLO) {
             PB_TR(1);
             pb_win_tile<PB_KIND_CAMERA, false>(P, &entry, entry.flags & (PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK), tx, ty, lane,
