@@ -328,20 +328,14 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
 #undef PB_LAUNCH_WIN
         return;
     }
-    const bool staged = windowed;
-    if (P.src.kind == PB_KIND_PANO) {
-        if (!staged)
+    // the direct-gather hot kernel + the fix kernel (index maps, PB_MODE_FAST_DIRECT, frames LDS-DMA cannot address)
+    if (P.src.kind == PB_KIND_PANO)
         hipLaunchKernelGGL((pb_hot_kernel<PB_KIND_PANO, OUT>), grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, idx_out);
-        if (fix_blocks)
-            hipLaunchKernelGGL((pb_fix_kernel<OUT>), dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, pl->fail_tiles, (int)pl->n_fail_tiles,
-                               pl->fix_px, (int)pl->n_fix_px, pl->idx_tab, pl->fix_idx, src, dst, n_frames, ss, ds, idx_out);
-    } else {
-        if (!staged)
+    else
         hipLaunchKernelGGL((pb_hot_kernel<PB_KIND_CAMERA, OUT>), grid, block, 0, st, P, pl->table, src, dst, n_frames, ss, ds, idx_out);
-        if (fix_blocks)
-            hipLaunchKernelGGL((pb_fix_kernel<OUT>), dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, pl->fail_tiles, (int)pl->n_fail_tiles,
-                               pl->fix_px, (int)pl->n_fix_px, pl->idx_tab, pl->fix_idx, src, dst, n_frames, ss, ds, idx_out);
-    }
+    if (fix_blocks)
+        hipLaunchKernelGGL((pb_fix_kernel<OUT>), dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, pl->fail_tiles, (int)pl->n_fail_tiles,
+                           pl->fix_px, (int)pl->n_fix_px, pl->idx_tab, pl->fix_idx, src, dst, n_frames, ss, ds, idx_out);
 }
 
 template <int KIND>
