@@ -393,17 +393,17 @@ static int pb_build_launch_table(pb_plan* pl) {
         n_groups = 8u * (unsigned)units_per_xcd * U * U;
         // the walk: rows of super-tiles top to bottom, XCD = position in the walk mod 8 (plain), unless the plan's tiles say
         // that work is unevenly spread - then the launch starts on its heaviest part and ENDS on its cheapest, which drains fast:
-        //   rows differ (max / min > 1.3; a fisheye output's black-cornered edges against its dense centre, a panorama's
+        //   rows differ (max / min > 1.45; a fisheye output's black-cornered edges against its dense centre, a panorama's
         //   pole rows against its rim rows): from the heaviest row outwards on two fronts, heavier neighbour first - the chip
         //   still walks through whole rows together (c2 44.1 -> 41.8 us, c1 14.1 -> 13.0);
-        //   rows alike but super-tiles differ (max / mean > 1.5; clusters of failed and direct-gather tiles): super-tiles
+        //   rows alike but super-tiles differ (max / mean > 1.7; clusters of failed and direct-gather tiles): super-tiles
         //   heaviest first, dealt round-robin (c3 37.9 -> 35.1 us, batches 32.0 -> 30.7).
         // Cost of a tile from its class and window: a wave's measured life (experiments/diag_trace.py) is 3 us on a black tile,
         // 4.2 + 0.4 per KiB of window on a window tile, 9.5 + 0.03 per source column on a direct-gather tile.
         std::vector<unsigned> seq(ns);  // the walk: super-tile ids in launch order
         for (unsigned S = 0; S < ns; ++S) seq[S] = S;
         std::vector<float> unit_cost;
-        if (order_mode == 0 && sgy >= 4) {
+        if (order_mode == 0 && sgy >= 4 && ns >= 128u) {  // (fewer than 16 super-tiles per XCD: too coarse to reorder - a 3072x2048 output measured 3-4 % slower)
             std::vector<unsigned> fixed(ns, 0u);
             unsigned* cost_dev = nullptr;
             PB_HIP(hipMalloc((void**)&cost_dev, ns * sizeof(unsigned)));
@@ -425,7 +425,7 @@ static int pb_build_launch_table(pb_plan* pl) {
             for (float c : unit_cost) usum += c;
             if (pl->dbl_ready) {
                 // double-fisheye sources keep the plain walk (two fronts measured 1.5 % slower on c5); their problem is another one, below
-            } else if (rmax > 1.3f * rmin) {
+            } else if (rmax > 1.45f * rmin) {
                 const unsigned top = (unsigned)(std::max_element(row_cost.begin(), row_cost.end()) - row_cost.begin());
                 int up = (int)top - 1;
                 unsigned down = top + 1, k = 0;
@@ -437,7 +437,7 @@ static int pb_build_launch_table(pb_plan* pl) {
                 }
                 for (unsigned k2 = 0; k2 < sgy; ++k2)
                     for (unsigned i = 0; i < sgx; ++i) seq[k2 * sgx + i] = row_seq[k2] * sgx + i;
-            } else if (umax * (float)ns > 1.5f * usum) {
+            } else if (umax * (float)ns > 1.7f * usum) {
                 std::stable_sort(seq.begin(), seq.end(), [&](unsigned a, unsigned b) { return unit_cost[a] > unit_cost[b]; });
             }
         }
