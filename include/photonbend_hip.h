@@ -105,8 +105,11 @@ void pb_plan_destroy(pb_plan* plan);
  *   flags       PB_PLAN_DEFER  no device work at creation: the plan is a parameter block and its launches run the
  *                              faithful float64 kernel (the cheapest way to remap ONE image of a geometry, the
  *                              reference CLI's case) until pb_plan_prepare builds the fast path;
- *               PB_PLAN_TUNE   after preparation, pick the LDS window budget by timing four candidates on scratch
- *                              frames (allocates frame-sized scratch, tens of frames' worth of GPU time; opt-in).
+ *               PB_PLAN_TUNE   after preparation, pick the LDS window budget (four candidates) and then the launch order
+ *                              (the policy's walk against plain / heaviest rows first / heaviest super-tiles first) by
+ *                              timing launches on scratch frames (allocates frame-sized scratch, about a hundred frames'
+ *                              worth of GPU time; opt-in).  Both decide paths and order only, never a byte; a serialized
+ *                              plan remembers them.
  *   win_budget  bytes of LDS window per wave for the hot kernels (multiple of 16 in [4224, 12288]; clamped);
  *               0 = the library default (7168).  It decides which PATH a tile takes, never its pixels.
  * Creation never times anything or allocates frame-sized memory unless PB_PLAN_TUNE is given. */

@@ -62,6 +62,8 @@ struct pb_plan {
     // the hot kernel's launch-order copy of `table` (rebuilt with every budget change; derived, never serialized)
     PbTileEntry* ltable = nullptr;
     unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
+    int walk = 0;                // launch-order rule: 0 = by policy (pb_build_launch_table), 1 = plain, 2 = rows from the heaviest outwards,
+                                 // 3 = super-tiles heaviest first; PB_PLAN_TUNE may pick 1-3 by timing, a serialized plan remembers it
     double prepare_ms = 0.0, tune_ms = 0.0;  // host wall time of the device preparation / of the optional budget tuning
 };
 
@@ -403,7 +405,8 @@ static int pb_build_launch_table(pb_plan* pl) {
         std::vector<unsigned> seq(ns);  // the walk: super-tile ids in launch order
         for (unsigned S = 0; S < ns; ++S) seq[S] = S;
         std::vector<float> unit_cost;
-        if (order_mode == 0 && sgy >= 4 && ns >= 128u) {  // (fewer than 16 super-tiles per XCD: too coarse to reorder - a 3072x2048 output measured 3-4 % slower)
+        const int walk = order_mode == 1 ? 1 : pl->walk;  // (PB_ORDER=1 forces the plain walk)
+        if (walk != 1 && sgy >= 4 && (ns >= 128u || walk != 0)) {  // (fewer than 16 super-tiles per XCD: too coarse to reorder - a 3072x2048 output measured 3-4 % slower)
             std::vector<unsigned> fixed(ns, 0u);
             unsigned* cost_dev = nullptr;
             PB_HIP(hipMalloc((void**)&cost_dev, ns * sizeof(unsigned)));
@@ -423,9 +426,9 @@ static int pb_build_launch_table(pb_plan* pl) {
             const float umax = *std::max_element(unit_cost.begin(), unit_cost.end());
             float usum = 0.f;
             for (float c : unit_cost) usum += c;
-            if (pl->dbl_ready) {
+            if (walk == 0 && pl->dbl_ready) {
                 // double-fisheye sources keep the plain walk (two fronts measured 1.5 % slower on c5); their problem is another one, below
-            } else if (rmax > 1.45f * rmin) {
+            } else if (walk == 2 || (walk == 0 && rmax > 1.45f * rmin)) {
                 const unsigned top = (unsigned)(std::max_element(row_cost.begin(), row_cost.end()) - row_cost.begin());
                 int up = (int)top - 1;
                 unsigned down = top + 1, k = 0;
@@ -437,13 +440,13 @@ static int pb_build_launch_table(pb_plan* pl) {
                 }
                 for (unsigned k2 = 0; k2 < sgy; ++k2)
                     for (unsigned i = 0; i < sgx; ++i) seq[k2 * sgx + i] = row_seq[k2] * sgx + i;
-            } else if (umax * (float)ns > 1.7f * usum) {
+            } else if (walk == 3 || (walk == 0 && umax * (float)ns > 1.7f * usum)) {
                 std::stable_sort(seq.begin(), seq.end(), [&](unsigned a, unsigned b) { return unit_cost[a] > unit_cost[b]; });
             }
         }
         unit_of.assign((size_t)8 * units_per_xcd, -1);
         std::vector<int> filled(8, 0);
-        if (pl->dbl_ready && sgx % 8 == 0 && !unit_cost.empty()) {
+        if (pl->dbl_ready && walk == 0 && sgx % 8 == 0 && !unit_cost.empty()) {
             // A stitch's expensive tiles - the seams where both eyes contribute, the eyes' rims - stand in COLUMNS of the
             // output, and "XCD = column mod 8" hands whole seams to the same XCDs row after row: the chip waits for them
             // (c5 76.5 us; super-tiles dealt at random 66.6).  Rows are still walked together and a column keeps its XCD from
@@ -576,11 +579,35 @@ static int pb_tune_window_budget(pb_plan* pl) {
                     if (rep > 0 && ms < t_min[c]) t_min[c] = ms;
                 }
             }
-        // the fastest candidate; ties within 1 % go to the larger windows
-        int bi = 0;
-        for (int c = 1; c < 4; ++c)
-            if (t_min[c] < t_min[bi] * 0.99f) bi = c;
+        // the library default unless another budget is at least 3 % faster (a handful of launches is a noisy yardstick)
+        int bi = 3;
+        for (int c = 0; c < 3; ++c)
+            if (t_min[c] < t_min[3] * 0.97f && t_min[c] < t_min[bi]) bi = c;
         if (!failed) best = cand[bi];
+        // then the launch order under the chosen budget: the policy's walk against the three fixed ones; a fixed walk must
+        // beat the policy by 3 % to replace it
+        if (!failed && pb_apply_budget(pl, best) == PB_OK) {
+            float t_walk[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+            for (int pass = 0; pass < 2 && !failed; ++pass)
+                for (int wk = 0; wk < 4 && !failed; ++wk) {
+                    pl->walk = wk;
+                    if (pb_build_launch_table(pl) != PB_OK) { failed = true; break; }
+                    for (int rep = 0; rep < 5; ++rep) {
+                        (void)hipEventRecord(e0, 0);
+                        const int slot = launch_no++ % n_scratch;
+                        if (pb_remap_launch(pl, src + slot * sb16, dst + slot * db16, 1, 0, 0, 0) != PB_OK) { failed = true; break; }
+                        (void)hipEventRecord(e1, 0);
+                        if (hipEventSynchronize(e1) != hipSuccess) { failed = true; break; }
+                        float ms = 0.f;
+                        (void)hipEventElapsedTime(&ms, e0, e1);
+                        if (rep > 0 && ms < t_walk[wk]) t_walk[wk] = ms;
+                    }
+                }
+            int bw = 0;
+            for (int wk = 1; wk < 4; ++wk)
+                if (t_walk[wk] < t_walk[bw] * 0.97f && t_walk[wk] < t_walk[0] * 0.97f) bw = wk;
+            pl->walk = failed ? 0 : bw;
+        }
     } while (0);
     (void)hipDeviceSynchronize();
     (void)hipGetLastError();
@@ -1180,7 +1207,7 @@ int pb_plan_serialize(const pb_plan* plan_c, void* buf, size_t capacity, size_t*
     h.version = PB_BLOB_VERSION;
     h.params_size = (uint32_t)sizeof(PbParams);
     h.entry_size = (uint32_t)sizeof(PbTileEntry);
-    h.fast_ready = pl->fast_ready; h.sep_ready = pl->sep_ready; h.dbl_ready = pl->dbl_ready;
+    h.fast_ready = pl->fast_ready; h.sep_ready = pl->sep_ready; h.dbl_ready = pl->dbl_ready; h.reserved = pl->walk;
     h.n_tiles = pl->n_tiles; h.n_fail_tiles = pl->n_fail_tiles; h.n_fix_px = pl->n_fix_px; h.n_lean_tiles = pl->n_lean_tiles;
     h.n_black_tiles = pl->n_black_tiles; h.n_direct_tiles = pl->n_direct_tiles; h.n_row_weight_tiles = pl->n_row_weight_tiles;
     h.n_lat_tiles = pl->n_lat_tiles; h.diff_pixels = pl->diff_pixels;
@@ -1215,6 +1242,7 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
     if (!pl) return pb_fail(PB_ERR_INVALID, "out of host memory");
     memcpy(&pl->P, in + sizeof(PbBlobHeader), sizeof(PbParams));
     pl->fast_ready = h.fast_ready; pl->sep_ready = h.sep_ready; pl->dbl_ready = h.dbl_ready;
+    pl->walk = (h.reserved >= 0 && h.reserved <= 3) ? h.reserved : 0;
     pl->n_tiles = h.n_tiles; pl->n_fail_tiles = h.n_fail_tiles; pl->n_fix_px = h.n_fix_px; pl->n_lean_tiles = h.n_lean_tiles;
     pl->n_black_tiles = h.n_black_tiles; pl->n_direct_tiles = h.n_direct_tiles; pl->n_row_weight_tiles = h.n_row_weight_tiles;
     pl->n_lat_tiles = h.n_lat_tiles; pl->diff_pixels = h.diff_pixels;
