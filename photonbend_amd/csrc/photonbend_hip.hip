@@ -405,6 +405,7 @@ static int pb_build_launch_table(pb_plan* pl) {
         std::vector<unsigned> seq(ns);  // the walk: super-tile ids in launch order
         for (unsigned S = 0; S < ns; ++S) seq[S] = S;
         std::vector<float> unit_cost;
+        bool row_walk = true;  // seq is a sequence of whole rows
         const int walk = order_mode == 1 ? 1 : pl->walk;  // (PB_ORDER=1 forces the plain walk)
         if (walk != 1 && sgy >= 4 && (ns >= 128u || walk != 0)) {  // (fewer than 16 super-tiles per XCD: too coarse to reorder - a 3072x2048 output measured 3-4 % slower)
             std::vector<unsigned> fixed(ns, 0u);
@@ -441,18 +442,27 @@ static int pb_build_launch_table(pb_plan* pl) {
                 for (unsigned k2 = 0; k2 < sgy; ++k2)
                     for (unsigned i = 0; i < sgx; ++i) seq[k2 * sgx + i] = row_seq[k2] * sgx + i;
             } else if (walk == 3 || (walk == 0 && umax * (float)ns > 1.7f * usum)) {
+                row_walk = false;
                 std::stable_sort(seq.begin(), seq.end(), [&](unsigned a, unsigned b) { return unit_cost[a] > unit_cost[b]; });
             }
         }
         unit_of.assign((size_t)8 * units_per_xcd, -1);
         std::vector<int> filled(8, 0);
-        if (pl->dbl_ready && walk == 0 && sgx % 8 == 0 && !unit_cost.empty()) {
+        float imbalance = 1.f;  // busiest / idlest XCD if every column of super-tiles kept "XCD = column mod 8"
+        if (!unit_cost.empty() && sgx % 8 == 0) {
+            float tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (unsigned S = 0; S < ns; ++S) tot[(S % sgx) & 7u] += unit_cost[S];
+            imbalance = *std::max_element(tot, tot + 8) / std::max(1e-6f, *std::min_element(tot, tot + 8));
+        }
+        if (walk == 0 && row_walk && sgx % 8 == 0 && !unit_cost.empty() && (pl->dbl_ready || imbalance > 1.15f)) {
             // A stitch's expensive tiles - the seams where both eyes contribute, the eyes' rims - stand in COLUMNS of the
             // output, and "XCD = column mod 8" hands whole seams to the same XCDs row after row: the chip waits for them
             // (c5 76.5 us; super-tiles dealt at random 66.6).  Rows are still walked together and a column keeps its XCD from
             // row to row (vertical neighbours share an L2), but after every row the busiest XCD hands a column to the idlest
-            // when it is more than half a super-tile ahead: c5 76.5 -> 64.6 us, c5shard 68.9 -> 54.7.  (Single sources: the
-            // same exchange measured +-0 on c2 / c3 and costs c1 6 % under the plain walk - not applied.)
+            // when it is more than half a super-tile ahead: c5 76.5 -> 64.6 us, c5shard 68.9 -> 54.7.  Single sources get the
+            // exchange only when their columns are that uneven too (busiest / idlest XCD > 1.15 under "column mod 8": a panorama
+            // from a 200-degree fisheye, black columns beyond the field of view, 26.7 -> 25.8 us); on even columns it measured
+            // +-0 (c2, c3) or worse (c1 +6 % under the plain walk).
             std::vector<int> owner(sgx);
             for (unsigned i = 0; i < sgx; ++i) owner[i] = (int)(i & 7u);
             float total[8] = {0, 0, 0, 0, 0, 0, 0, 0}, all = 0.f;
@@ -461,8 +471,9 @@ static int pb_build_launch_table(pb_plan* pl) {
             for (unsigned r = 0; r < sgy; ++r) {
                 for (unsigned i = 0; i < sgx; ++i) {
                     const int x = owner[i];
-                    unit_of[(size_t)x * units_per_xcd + filled[x]++] = (int)(r * sgx + i);
-                    total[x] += unit_cost[r * sgx + i];
+                    const unsigned S = (seq[r * sgx] / sgx) * sgx + i;  // row r of the walk, column i
+                    unit_of[(size_t)x * units_per_xcd + filled[x]++] = (int)S;
+                    total[x] += unit_cost[S];
                 }
                 if (r + 1 == sgy) break;
                 float ahead[8];  // totals as they will stand after the exchanges decided so far
@@ -475,7 +486,8 @@ static int pb_build_launch_table(pb_plan* pl) {
                     for (unsigned i = 0; i < sgx; ++i)
                         for (unsigned j = 0; j < sgx; ++j)
                             if (owner[i] == a && owner[j] == b) {
-                                const float gain = unit_cost[(r + 1) * sgx + i] - unit_cost[(r + 1) * sgx + j];  // what `a` sheds next row
+                                const unsigned nr = seq[(r + 1) * sgx] / sgx;
+                                const float gain = unit_cost[nr * sgx + i] - unit_cost[nr * sgx + j];  // what `a` sheds next row
                                 if (gain > best) { best = gain; bi = (int)i; bj = (int)j; }
                             }
                     if (bi < 0) break;
