@@ -23,6 +23,12 @@ independent (frames shard, nothing pixel-sized crosses xGMI); the only collectiv
 parameter block from rank 0 and the barriers / max-reduce that bracket the timed region.  Rank 0 prints ONE
 JSON line.
 
+At N = 1 the line also carries ``configs``: c1, c3, c5, c4shard and c5shard measured in the SAME process right after the
+headline (plan, frame pool beyond the Infinity Cache, HIP-event timed launches, algorithmic / must-move bytes from the plan's own
+index map checked against the reference's figure), plus ``single_image_ms`` (a new geometry's warm plan + first frame) and
+``faithful_kernel_ms`` (the float64 chain, what a deferred plan runs) for the headline config - so that one driver-run line shows
+every kernel the design document talks about (cross-check: profiles/r03_*_kernel_stats.csv).
+
 ``roofline`` prices the kernel's ALGORITHMIC bytes (3 B written per output pixel + 3 B read per in-bounds source
 sample; recomputed here from the plan's own index map and checked against tests/golden/full.json, which holds
 the reference's figure) against the 8 TB/s HBM3E peak, using per-launch HIP-event durations taken on the launch
@@ -113,6 +119,7 @@ def parse_args():
     ap.add_argument("--sampling", choices=["nearest", "bilinear"], default="nearest",
                     help="nearest = the reference's truncating sampler (the headline); bilinear = the opt-in 4-tap mode (pb_remap_bilinear_u8; no reference behaviour)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the (independent) launches are dealt to round-robin")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configs measured in the same process)")
     return ap.parse_args()
 
 
@@ -246,6 +253,133 @@ def byte_accounting(plan, src_hw, device):
     touched[(3 * valid + 2) // LINE] = True
     out_bytes = 3 * plan.dst.height * plan.dst.width
     return out_bytes + 3 * int(valid.numel()), out_bytes + LINE * int(touched.sum().item())
+
+
+def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0, pool_bytes=320 << 20):
+    """One config measured like the headline, inside this process: its plan at the pinned budget, a pool of distinct frames
+    larger than the 256 MiB Infinity Cache, `steps` launches in groups of 4 between HIP event pairs on the launch stream.
+    Returns the entry of the line's ``configs`` block."""
+    import torch
+
+    cfg = CONFIGS[name]
+    batch = batch or cfg["batch"]
+    d, rots, s = build_projs(cfg)
+    budget = BENCH_BUDGET[name]
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    plan = nat.Plan(d, rots, s, budget=budget)
+    torch.cuda.synchronize(device)
+    plan_ms = (time.perf_counter() - t0) * 1e3
+    sh, sw, dh, dw = s.height, s.width, d.height, d.width
+    sbytes, dbytes = 3 * sh * sw, 3 * dh * dw
+    pool = max(2 * batch, pool_bytes // (sbytes + dbytes) + 1)
+    pool = (pool + batch - 1) // batch * batch
+    srcs = torch.empty((pool, sh, sw, 3), dtype=torch.uint8, device=device)
+    for f in range(pool):
+        nat.synth_frame(sh, sw, frame=1000 + f, seed=0, circle_mask=cfg["mask"], out=srcs[f])
+    dsts = torch.empty((pool, dh, dw, 3), dtype=torch.uint8, device=device)
+    sp0, dp0, h = srcs.data_ptr(), dsts.data_ptr(), plan.handle
+    groups_in_pool = pool // batch
+
+    def step(k):
+        i = (k % groups_in_pool) * batch
+        rc = lib.pb_remap_u8(h, sp0 + i * sbytes, dp0 + i * dbytes, batch, sbytes, dbytes, stream)
+        if rc:
+            nat.check(rc)
+
+    for k in range(warmup):
+        step(k)
+    every = 4
+    n_groups = max(1, steps // every)
+    ev = []
+    for _ in range(2 * n_groups):
+        e = ctypes.c_void_p()
+        nat.check(lib.pb_event_create(ctypes.byref(e)))
+        ev.append(e)
+    torch.cuda.synchronize(device)
+    for g in range(n_groups):
+        lib.pb_event_record(ev[2 * g], stream)
+        for k in range(every):
+            step(g * every + k)
+        lib.pb_event_record(ev[2 * g + 1], stream)
+    torch.cuda.synchronize(device)
+    ms = ctypes.c_float()
+    durs = []
+    for g in range(n_groups):
+        nat.check(lib.pb_event_elapsed_ms(ev[2 * g], ev[2 * g + 1], ctypes.byref(ms)))
+        durs.append(ms.value / every / batch)
+    for e in ev:
+        lib.pb_event_destroy(e)
+    alg, must = byte_accounting(plan, (sh, sw), device)
+    pins = json.load(open(os.path.join(ROOT, "tests", "golden", "full.json")))
+    ref_alg = int(pins[cfg["pin"]]["algorithmic_bytes"])
+    if alg != ref_alg:
+        raise SystemExit(f"bench.py: {name}: algorithmic bytes from the plan's index map ({alg}) differ from the reference's ({ref_alg})")
+    per_frame_ms = float(np.mean(durs))
+    info = plan.info()
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{name}_{info['window_budget']}.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
+            if traffic and tj.get("frames_per_launch", 1) > 1:
+                traffic = traffic / tj["frames_per_launch"]
+        except Exception:
+            traffic = None
+    out = {
+        "workload": cfg["text"],
+        "frames_per_launch": batch,
+        "frames_resident": pool,
+        "kernel_ms_per_frame": round(per_frame_ms, 5),
+        "kernel_ms_per_frame_p10": round(float(np.percentile(durs, 10)), 5),
+        "kernel_ms_per_frame_p90": round(float(np.percentile(durs, 90)), 5),
+        "mpx_per_s": round(dh * dw / 1e6 / (per_frame_ms * 1e-3), 1),
+        "algorithmic_bytes_per_frame": alg,
+        "must_move_bytes_per_frame": must,
+        "frac": round(alg / (per_frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "attainable_frac": round(alg / must, 4),
+        "traffic_bytes_per_frame": traffic,
+        "plan_create_warm_ms": round(plan_ms, 3),
+        "tiles": {k: info[k] for k in ("tiles", "lean_tiles", "direct_tiles", "black_tiles", "fix_tiles")},
+        "window_budget": info["window_budget"],
+        "launches_timed": n_groups * every,
+    }
+    del srcs, dsts, plan
+    torch.cuda.empty_cache()
+    return out
+
+
+def headline_extras(lib, nat, d, rots, s, cfg, device, stream, budget):
+    """single_image_ms: what ONE image of a new geometry costs (warm plan creation + its first frame, device-resident
+    input); faithful_kernel_ms: the float64 chain of the same geometry (what a deferred plan runs)."""
+    import torch
+
+    src = nat.synth_frame(s.height, s.width, frame=77, seed=0, circle_mask=cfg["mask"])
+    out = torch.empty((d.height, d.width, 3), dtype=torch.uint8, device=device)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    plan = nat.Plan(d, rots, s, budget=budget)
+    nat.check(lib.pb_remap_u8(plan.handle, src.data_ptr(), out.data_ptr(), 1, 0, 0, stream))
+    torch.cuda.synchronize(device)
+    single_ms = (time.perf_counter() - t0) * 1e3
+    plan.set_mode(nat.MODE_FAITHFUL)
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    nat.check(lib.pb_event_create(ctypes.byref(e0)))
+    nat.check(lib.pb_event_create(ctypes.byref(e1)))
+    for _ in range(2):
+        nat.check(lib.pb_remap_u8(plan.handle, src.data_ptr(), out.data_ptr(), 1, 0, 0, stream))
+    lib.pb_event_record(e0, stream)
+    for _ in range(8):
+        nat.check(lib.pb_remap_u8(plan.handle, src.data_ptr(), out.data_ptr(), 1, 0, 0, stream))
+    lib.pb_event_record(e1, stream)
+    nat.check(lib.pb_event_sync(e1))
+    ms = ctypes.c_float()
+    nat.check(lib.pb_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+    lib.pb_event_destroy(e0)
+    lib.pb_event_destroy(e1)
+    return round(single_ms, 3), round(ms.value / 8, 5)
+
 
 
 def copy_ceiling_gbs(lib, nat, device, stream) -> float:
@@ -487,6 +621,20 @@ def main():
                 "plan": info,
             },
         }
+        line["ranks_seen"] = dist.get_world_size() if dist.is_initialized() else 1
+        line["collective_backend"] = (dist.get_backend() if dist.is_initialized() else None)
+        if world == 1 and not bilinear and not args.no_configs and args.config == "c2":
+            # the other BASELINE configs, same process, same box, seconds: one driver-run line shows every kernel
+            del srcs, dsts
+            torch.cuda.empty_cache()
+            single_ms, faithful_ms = headline_extras(lib, nat, d, rots, s, cfg, device, sts[0], budget)
+            line["single_image_ms"] = single_ms
+            line["single_image_note"] = "warm plan creation (thresholds, tile models, certification, launch table) + the first frame of a NEW geometry, device-resident input; a deferred plan instead runs faithful_kernel_ms with no preparation"
+            line["faithful_kernel_ms"] = faithful_ms
+            block = {}
+            for name in ("c1", "c3", "c5", "c4shard", "c5shard"):
+                block[name] = measure_config(lib, nat, name, device, sts[0])
+            line["configs"] = block
         if world == 1 and not args.no_cpu_baseline and not bilinear:  # (the CPU leg times the reference's nearest sampler)
             line["cpu_baseline"] = cpu_baseline(cfg, mpx_per_frame)
             extra = cpu_baseline_all_cores(args.config, mpx_per_frame)

@@ -36,7 +36,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define PB_ABI_VERSION 2
+#define PB_ABI_VERSION 3
 #define PB_MAX_ROTATIONS 8
 
 typedef enum pb_status {
@@ -154,6 +154,10 @@ int pb_plan_src_shape(const pb_plan* plan, int* height, int* width);
 /* bytes of LDS window per wave the plan's hot launches use (it decides which path a tile takes, never its
  * pixels); 0 without device state */
 int pb_plan_window_budget(const pb_plan* plan);
+/* 1 when `plan` was made for exactly this request (same projections, same rotation bits), 0 when not, negative on bad
+ * arguments (ABI 3).  What a cache of serialized plans checks after pb_plan_deserialize: the blob's checksum says it is
+ * intact, not that it belongs to the geometry the caller has in mind. */
+int pb_plan_matches(const pb_plan* plan, const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src);
 
 /* Remap n_frames frames that share the plan's geometry.  Frame f is read at
  * src_dev + f * src_frame_stride and written at dst_dev + f * dst_frame_stride

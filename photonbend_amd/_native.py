@@ -18,7 +18,7 @@ import torch  # noqa: F401  (must precede the CDLL below - see module docstring)
 
 from .build import LIB_PATH
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PB_MAX_ROTATIONS = 8
 PLAN_DEFER, PLAN_TUNE = 1, 2
 MODE_AUTO, MODE_FAITHFUL, MODE_FAST, MODE_FAST_DIRECT = 0, 1, 2, 3
@@ -74,6 +74,7 @@ SIGNATURES = {
     "pb_plan_dst_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_plan_src_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_plan_window_budget": (C.c_int, [_VP]),
+    "pb_plan_matches": (C.c_int, [_VP, C.POINTER(pb_proj), C.POINTER(C.c_double), C.c_int, C.POINTER(pb_proj)]),
     "pb_remap_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
     "pb_remap_bilinear_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
     "pb_index_map_i32": (C.c_int, [_VP, _VP, _VP, _VP]),
@@ -191,16 +192,19 @@ class Plan:
         return buf.raw[: n.value]
 
     @classmethod
-    def deserialize(cls, blob: bytes, dst: pb_proj, src: pb_proj, n_rot: int) -> "Plan":
+    def deserialize(cls, blob: bytes, dst: pb_proj, rotations, src: pb_proj) -> "Plan":
+        """Restores a serialized plan and checks that it was made for exactly this request (projections and rotation
+        bits): a cache file name is not proof of what the file holds."""
+        rots = np.ascontiguousarray(np.asarray(list(rotations), dtype=np.float64).reshape(-1, 9))
         h = _VP()
         raw = bytes(blob)
         check(load().pb_plan_deserialize(raw, len(raw), C.byref(h)))
-        plan = cls._adopt(h, dst, src, n_rot)
-        hh, ww = C.c_int(), C.c_int()
-        check(load().pb_plan_dst_shape(h, C.byref(hh), C.byref(ww)))
-        sh, sw = C.c_int(), C.c_int()
-        check(load().pb_plan_src_shape(h, C.byref(sh), C.byref(sw)))
-        if (hh.value, ww.value, sh.value, sw.value) != (dst.height, dst.width, src.height, src.width):
+        plan = cls._adopt(h, dst, src, rots.shape[0])  # (owns the handle: destroyed with `plan` if the check below raises)
+        rp = rots.ctypes.data_as(C.POINTER(C.c_double)) if rots.shape[0] else None
+        same = load().pb_plan_matches(h, C.byref(dst), rp, rots.shape[0], C.byref(src))
+        if same < 0:
+            check(same)
+        if same != 1:
             raise PbError("the serialized plan belongs to another geometry")
         return plan
 

@@ -54,26 +54,28 @@ def _disk_cache_path(key) -> Union[str, None]:
     return os.path.join(root, f"plan_{digest}.pbplan")
 
 
-def _prepare(plan: nat.Plan, key) -> nat.Plan:
-    """Fast path for `plan` (a deferred plan): from the disk cache when there is one, else built and certified now."""
+def _prepare(plan: nat.Plan, key, rotations) -> nat.Plan:
+    """A PREPARED plan for the geometry of `plan` (a deferred plan): from the disk cache when there is one, else built and
+    certified now.  Always a NEW object - the deferred one may be in use by other threads (its launches run the faithful
+    kernel) and is never mutated; the caller swaps the cache entry."""
     path = _disk_cache_path(key)
     if path and os.path.exists(path):
         try:
             with open(path, "rb") as f:
-                return nat.Plan.deserialize(f.read(), plan.dst, plan.src, plan.n_rot)
+                return nat.Plan.deserialize(f.read(), plan.dst, rotations, plan.src)
         except (OSError, nat.PbError):
             pass  # stale or foreign blob: rebuild
-    plan.prepare()
+    fresh = nat.Plan(plan.dst, rotations, plan.src)
     if path:
         try:
-            os.makedirs(os.path.dirname(path), exist_ok=True)
+            os.makedirs(os.path.dirname(path), mode=0o700, exist_ok=True)  # plans drive unguarded device loads: keep the directory private
             tmp = f"{path}.{os.getpid()}.tmp"
             with open(tmp, "wb") as f:
-                f.write(plan.serialize())
+                f.write(fresh.serialize())
             os.replace(tmp, path)
         except (OSError, nat.PbError):
             pass
-    return plan
+    return fresh
 
 
 def _plan_for(dst: nat.pb_proj, rotations, src: nat.pb_proj, device=None, eager: bool = True) -> nat.Plan:
@@ -101,7 +103,7 @@ def _plan_for(dst: nat.pb_proj, rotations, src: nat.pb_proj, device=None, eager:
                     _PLAN_CACHE.popitem(last=False)  # evict ONE entry, the least recently used
             entry[1] += 1
             if not entry[2] and (eager or entry[1] >= 2) and torch.cuda.is_available():
-                entry[0] = _prepare(entry[0], key)
+                entry[0] = _prepare(entry[0], key, rotations)
                 entry[2] = True
         _PLAN_CACHE.move_to_end(key)
         return entry[0]

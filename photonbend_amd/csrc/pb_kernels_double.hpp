@@ -265,6 +265,10 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
         if (lane == 0 && blockIdx.x / pb_trace_wpf == pb_trace_frame)
             pb_trace[(size_t)(ty * pb_tiles_x(P) + tx) * 16 + 14] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u) | ((unsigned long long)blockIdx.x << 8);  // HW_REG_XCC_ID, workgroup
 #endif
+#ifdef PB_ABLATION  // timing experiments only: 256 = skip the two-eye tiles, 512 = skip the one-eye (SOLO) tiles
+        if ((P.exp_flags & 256) && !(entry.flags & PB_TILE_SOLO)) return;
+        if ((P.exp_flags & 512) && (entry.flags & PB_TILE_SOLO)) return;
+#endif
         if (entry.flags & PB_TILE_SOLO) {
             PB_TR(1);
             pb_win_tile<PB_KIND_CAMERA, false>(P, &entry, entry.flags & (PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK), tx, ty, lane,

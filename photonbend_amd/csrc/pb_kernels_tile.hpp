@@ -361,6 +361,20 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             const uint8_t* s = src + (unsigned long long)f * src_stride;
             uint8_t* d = dst + (unsigned long long)f * dst_stride;
             unsigned la[4][4];
+#ifdef PB_ABLATION  // VALU sensitivity (wrong pixels): bit 1 = one collapse instead of four, bit 2 = no polynomial at all
+            if (P.exp_flags & 3) {
+                pb_f2 a[5];
+                pb_collapse_row(e, yb, a);
+#pragma unroll
+                for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const pb_f2 fv = (P.exp_flags & 2) ? a[(jr + k) % 5] : pb_eval_row(a, u[k]);
+                        const unsigned dr = (unsigned)(int)fv.x % (unsigned)nrows, dc = (unsigned)(int)fv.y % (unsigned)e->win_cols;
+                        la[jr][k] = __umul24(dr, pitch) + (__umul24(dc, 3u) + a0);
+                    }
+            } else
+#endif
 #pragma unroll
             for (int jr = 0; jr < 4; ++jr) {
                 pb_f2 a[5];
@@ -577,8 +591,12 @@ __device__ __forceinline__ void pb_failed_tile(const PbParams& P, const PbTileEn
 // prefetched - the entry's scalar round trip disappears from the timeline but the frame gets slower, the workgroups
 // become too coarse for the hardware's dealing; the four waves of a workgroup sharing one source window; aligned
 // 8-byte loads in the direct-gather tiles.)
+// The parameter block reaches this kernel through a pointer to the plan's device copy (120 bytes of kernel arguments instead of
+// 1216): measured on MI355X (round 3, experiments/session_r3_g.sh, three alternating pairs of processes) c2 40.6-41.2 -> 39.8-40.2 us,
+// c1 13.9-14.7 -> 13.7-13.9, c3 +-0, the all-tiles-skipped launch of 4096 workgroups 5.9-7.1 -> 5.9-6.7.  The double-fisheye kernel
+// keeps the block by value: by pointer measured 1.4 % SLOWER there (58.4-58.9 -> 59.5-59.8 us).
 template <int SRC_KIND>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams* __restrict__ Pp, const PbTileEntry* __restrict__ table,
                                                                          const uint8_t* __restrict__ src,
                                                                          uint8_t* __restrict__ dst, const unsigned groups_per_frame,
                                                                          unsigned long long src_stride,
@@ -586,6 +604,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
                                                                          const int32_t* __restrict__ idx_tab,
                                                                          const int32_t* __restrict__ fix_px,
                                                                          const int32_t* __restrict__ fix_idx) {
+    const PbParams& P = *Pp;
     // every kernel argument the tile prologue needs, in one scalar round trip (the compiler would otherwise fetch
     // the table pointer only after the tile index is known: a second dependent trip per wave)
     asm volatile("" ::"s"(table), "s"(P.dst.width), "s"(P.dst.height), "s"(P.src.width), "s"(P.src.height), "s"(P.win_budget), "s"(groups_per_frame));
@@ -1054,3 +1073,4 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const Pb
         fail_tiles[atomicAdd(&counters[1], 1u)] = tile;
     }
 }
+

@@ -61,11 +61,32 @@ struct pb_plan {
     int32_t* saved_r = nullptr;
     // the hot kernel's launch-order copy of `table` (rebuilt with every budget change; derived, never serialized)
     PbTileEntry* ltable = nullptr;
+    PbParams* P_dev = nullptr;   // device copy of P as the hot launches see it (refreshed with every budget change)
     unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
     int walk = 0;                // launch-order rule: 0 = by policy (pb_build_launch_table), 1 = plain, 2 = rows from the heaviest outwards,
                                  // 3 = super-tiles heaviest first; PB_PLAN_TUNE may pick 1-3 by timing, a serialized plan remembers it
     double prepare_ms = 0.0, tune_ms = 0.0;  // host wall time of the device preparation / of the optional budget tuning
 };
+
+// Experiment knobs (environment variables) exist in the -DPB_ABLATION diagnostic build only (experiments/); the product
+// library reads no environment.
+#ifdef PB_ABLATION
+static int pb_knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+static inline int pb_knob(const char*, int dflt) { return dflt; }
+#endif
+
+// -DPB_ABLATION only: PB_FAIL_LTABLE_ALLOC=n makes the n-th launch-table allocation of the process fail (tests of the error path)
+static bool pb_test_alloc_fails() {
+#ifdef PB_ABLATION
+    static int countdown = pb_knob("PB_FAIL_LTABLE_ALLOC", 0);
+    if (countdown > 0 && --countdown == 0) return true;
+#endif
+    return false;
+}
 
 static thread_local std::string g_err;
 static int pb_fail(int code, const std::string& msg) {
@@ -303,7 +324,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
     const unsigned fix_blocks = 4u * pl->n_fail_tiles + (pl->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
     // the windowed kernel needs 16-byte aligned frames (LDS-DMA row segments); PB_MODE_FAST_DIRECT and
     // unaligned frames take the direct-gather hot kernel + the fix kernel
-    const bool windowed = OUT == 0 && pl->ltable && pl->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
+    const bool windowed = OUT == 0 && pl->ltable && pl->P_dev && pl->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
                           ((((uintptr_t)src) | ss) & 15u) == 0;
     if (windowed) {
         // one launch per frame: failed tiles and fix pixels are looked up in the plan's exact-index tables by the
@@ -311,9 +332,9 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
         // frames are a grid dimension, frame-major; a frame's share of the grid is a multiple of 8 workgroups so that a
         // tile group keeps its XCD residue in every frame
         const unsigned gpf = pl->launch_groups;
-        static const unsigned wpw = [] { const char* e = getenv("PB_WPW"); const int v = e ? atoi(e) : PB_WAVES_PER_WG; return (v == 1 || v == 2) ? (unsigned)v : 4u; }();
+        static const unsigned wpw = [] { const int v = pb_knob("PB_WPW", PB_WAVES_PER_WG); return (v == 1 || v == 2) ? (unsigned)v : 4u; }();
         const dim3 wblock(64u * wpw);
-        const size_t lds = pb_window_lds_bytes(P) / PB_TILE_WAVES * wpw;
+        const size_t lds = pb_window_lds_bytes(P) / PB_TILE_WAVES * wpw + (size_t)pb_knob("PB_LDS_PAD", 0);  // (the pad: occupancy experiments, -DPB_ABLATION only)
         const unsigned wpf = gpf * (4u / wpw);
         const int per_launch = (int)(0x7FFFFFFFu / wpf);  // grid limit: absurdly long batches go in several launches
         for (int f0 = 0; f0 < n_frames; f0 += per_launch) {
@@ -322,7 +343,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
             const uint8_t* sf = src + (unsigned long long)f0 * ss;
             uint8_t* df = dst + (unsigned long long)f0 * ds;
 #define PB_LAUNCH_WIN(KIND)                                                                                                   \
-    hipLaunchKernelGGL((pb_hot_win_kernel<KIND>), bgrid, wblock, lds, st, P, pl->ltable, sf, df, gpf, ss, ds, pl->idx_tab, \
+    hipLaunchKernelGGL((pb_hot_win_kernel<KIND>), bgrid, wblock, lds, st, (const PbParams*)pl->P_dev, pl->ltable, sf, df, gpf, ss, ds, pl->idx_tab, \
                        pl->fix_px, pl->fix_idx)
             if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_WIN(PB_KIND_PANO);
             else PB_LAUNCH_WIN(PB_KIND_CAMERA);
@@ -383,9 +404,9 @@ static int pb_build_launch_table(pb_plan* pl) {
     if (!pl->fast_ready && !pl->dbl_ready) return PB_OK;  // (a double-fisheye plan: the left eye's table + PB_TILE_SOLO entries)
     const unsigned tiles_x = (P.dst.width + PB_TILE - 1) / PB_TILE, tiles_y = (P.dst.height + PB_TILE - 1) / PB_TILE;
     const unsigned gx = (tiles_x + 1) / 2, gy = (tiles_y + 1) / 2;
-    static const unsigned U = [] { const char* e = getenv("PB_UNIT"); const int v = e ? atoi(e) : 4; return (v == 2 || v == 8 || v == 16) ? (unsigned)v : 4u; }();  // workgroups per unit side
+    static const unsigned U = [] { const int v = pb_knob("PB_UNIT", 4); return (v == 2 || v == 8 || v == 16) ? (unsigned)v : 4u; }();  // workgroups per unit side
     const bool units = gx % U == 0 && gy % U == 0 && (gx / U) * (gy / U) >= 16u;
-    static const int order_mode = [] { const char* e = getenv("PB_ORDER"); return e ? atoi(e) : 0; }();
+    static const int order_mode = pb_knob("PB_ORDER", 0);
     std::vector<int> unit_of;
     int units_per_xcd = 0;
     unsigned n_groups = (gx * gy + 7u) & ~7u;
@@ -410,13 +431,23 @@ static int pb_build_launch_table(pb_plan* pl) {
         if (walk != 1 && sgy >= 4 && (ns >= 128u || walk != 0)) {  // (fewer than 16 super-tiles per XCD: too coarse to reorder - a 3072x2048 output measured 3-4 % slower)
             std::vector<unsigned> fixed(ns, 0u);
             unsigned* cost_dev = nullptr;
-            PB_HIP(hipMalloc((void**)&cost_dev, ns * sizeof(unsigned)));
+            if (hipMalloc((void**)&cost_dev, ns * sizeof(unsigned)) != hipSuccess) {
+                (void)hipFree(pl->ltable);  // (the old table may be classified under another budget)
+                pl->ltable = nullptr;
+                pl->launch_groups = 0;
+                return pb_fail(PB_ERR_HIP, "launch table: out of device memory");
+            }
             (void)hipMemsetAsync(cost_dev, 0, ns * sizeof(unsigned), 0);
             hipLaunchKernelGGL(pb_unit_cost_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->n_tiles, tiles_x, 2u * U, sgx, cost_dev,
                                pl->dbl_ready ? pl->table_r : nullptr);
             const hipError_t ce = hipMemcpy(fixed.data(), cost_dev, ns * sizeof(unsigned), hipMemcpyDeviceToHost);
             (void)hipFree(cost_dev);
-            PB_HIP(ce);
+            if (ce != hipSuccess) {
+                (void)hipFree(pl->ltable);
+                pl->ltable = nullptr;
+                pl->launch_groups = 0;
+                return pb_fail(PB_ERR_HIP, std::string("launch table: ") + hipGetErrorString(ce));
+            }
             std::vector<float> row_cost(sgy, 0.f);
             unit_cost.assign(ns, 0.f);
             for (unsigned S = 0; S < ns; ++S) {
@@ -500,23 +531,32 @@ static int pb_build_launch_table(pb_plan* pl) {
             for (unsigned p = 0; p < ns; ++p) unit_of[(size_t)(p & 7u) * units_per_xcd + filled[p & 7u]++] = (int)seq[p];  // XCD = position in the walk, mod 8
         }
     }
+    // the new table is built aside and replaces the plan's only when it is complete: a failure leaves the plan WITHOUT a
+    // launch table (ltable == nullptr, launch_groups == 0 - its launches then take the direct-gather kernels), never with a
+    // half-written one or one classified under another budget
     const unsigned n_slots = 4u * n_groups;
     (void)hipFree(pl->ltable);
     pl->ltable = nullptr;
-    PB_HIP(hipMalloc((void**)&pl->ltable, (size_t)n_slots * sizeof(PbTileEntry)));
+    pl->launch_groups = 0;
+    PbTileEntry* fresh = nullptr;
     int* unit_dev = nullptr;
-    if (units) {
-        PB_HIP(hipMalloc((void**)&unit_dev, unit_of.size() * sizeof(int)));
-        if (hipMemcpy(unit_dev, unit_of.data(), unit_of.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(unit_dev);
-            return pb_fail(PB_ERR_HIP, "launch table: upload failed");
-        }
+    hipError_t e = pb_test_alloc_fails() ? hipErrorOutOfMemory : hipMalloc((void**)&fresh, (size_t)n_slots * sizeof(PbTileEntry));
+    if (e == hipSuccess && units) {
+        e = hipMalloc((void**)&unit_dev, unit_of.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(unit_dev, unit_of.data(), unit_of.size() * sizeof(int), hipMemcpyHostToDevice);
     }
-    hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, pl->ltable, unit_dev, units_per_xcd, n_slots, (int)U,
-                       pl->dbl_ready ? pl->table_r : nullptr);
-    const hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, fresh, unit_dev, units_per_xcd, n_slots, (int)U,
+                           pl->dbl_ready ? pl->table_r : nullptr);
+        e = hipDeviceSynchronize();
+    }
     (void)hipFree(unit_dev);
-    PB_HIP(e);
+    if (e != hipSuccess) {
+        (void)hipFree(fresh);
+        (void)hipGetLastError();
+        return pb_fail(PB_ERR_HIP, std::string("launch table: ") + hipGetErrorString(e));
+    }
+    pl->ltable = fresh;
     pl->launch_groups = n_groups;
     return PB_OK;
 }
@@ -550,6 +590,8 @@ static int pb_apply_budget(pb_plan* pl, int budget) {
     PB_HIP(e);
     pl->n_lean_tiles = res[0];
     pl->n_direct_tiles = res[1];
+    if (!pl->P_dev) PB_HIP(hipMalloc((void**)&pl->P_dev, sizeof(PbParams)));
+    PB_HIP(hipMemcpy(pl->P_dev, &P, sizeof(PbParams), hipMemcpyHostToDevice));
     return pb_build_launch_table(pl);
 }
 
@@ -634,6 +676,29 @@ static int pb_tune_window_budget(pb_plan* pl) {
     return best;
 }
 
+// the parameter block of a request, as pb_plan_create_ex fills it before any device work
+static void pb_params_of_request(PbParams& P, const PbEnd& dst, const double* rot3x3, int n_rot, const PbEnd& src) {
+    memset(&P, 0, sizeof(PbParams));
+    P.dst = dst;
+    P.src = src;
+    P.n_rot = n_rot;
+    for (int k = 0; k < n_rot; ++k)
+        for (int e = 0; e < 9; ++e) P.R[k][e] = rot3x3[9 * k + e];
+    pb_derive(P);
+}
+// everything of a parameter block that follows from the request alone (not: budget, experiment flags, validity thresholds)
+static bool pb_same_request(const PbParams& a, const PbParams& b) {
+    PbParams x = a, y = b;
+    for (PbParams* p : {&x, &y}) {
+        p->win_budget = 0;
+        p->exp_flags = 0;
+        p->thresholds_ready = 0;
+        p->fast_tiles = 0;
+        for (int i = 0; i < 2; ++i) p->inv_lo[i] = p->inv_hi[i] = 0;
+    }
+    return memcmp(&x, &y, sizeof(PbParams)) == 0;
+}
+
 static double pb_now_ms() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -650,12 +715,13 @@ static int pb_plan_prepare_full(pb_plan* pl, unsigned flags, int win_budget) {
     }
     const double t0 = pb_now_ms();
     int rc = pb_plan_prepare_on_device(pl);
-    if (rc != PB_OK) return rc;
-    int budget = win_budget > 0 ? win_budget : PB_DEFAULT_WIN_BUDGET;
-    if (win_budget <= 0) {
-        const char* forced = getenv("PB_WIN_BUDGET");
-        if (forced && atoi(forced) > 0) budget = atoi(forced);
+    if (rc != PB_OK) {
+        pl->fast_ready = 0;  // (pb_plan_prepare_on_device has released the tables): the plan is unprepared again and may be retried
+        pl->device = -1;
+        return rc;
     }
+    int budget = win_budget > 0 ? win_budget : PB_DEFAULT_WIN_BUDGET;
+    if (win_budget <= 0 && pb_knob("PB_WIN_BUDGET", 0) > 0) budget = pb_knob("PB_WIN_BUDGET", 0);
     rc = pb_apply_budget(pl, budget);
     if (rc != PB_OK) return rc;
     PB_HIP(hipDeviceSynchronize());
@@ -705,16 +771,10 @@ int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const
     if (win_budget < 0) return pb_fail(PB_ERR_INVALID, "negative window budget");
     pb_plan* pl = new (std::nothrow) pb_plan();
     if (!pl) return pb_fail(PB_ERR_INVALID, "out of host memory");
-    memset(&pl->P, 0, sizeof(PbParams));
-    pl->P.dst = pb_to_end(dst);
-    pl->P.src = pb_to_end(src);
-    pl->P.n_rot = n_rot;
-    for (int k = 0; k < n_rot; ++k)
-        for (int e = 0; e < 9; ++e) pl->P.R[k][e] = rot3x3[9 * k + e];
-    pb_derive(pl->P);
+    pb_params_of_request(pl->P, pb_to_end(dst), rot3x3, n_rot, pb_to_end(src));
     pl->P.win_budget = PB_WINLDS_MAX;
     pl->P.exp_flags = PB_DEFAULT_EXP;
-    if (const char* ex = getenv("PB_EXP")) pl->P.exp_flags = atoi(ex);
+    pl->P.exp_flags = pb_knob("PB_EXP", PB_DEFAULT_EXP);
     pl->mode = PB_MODE_AUTO;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
@@ -728,6 +788,16 @@ int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const
     }
     *out = pl;
     return PB_OK;
+}
+
+int pb_plan_matches(const pb_plan* plan, const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src) {
+    std::string why;
+    if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (!pb_end_ok(dst, why, PB_ROLE_DST) || !pb_end_ok(src, why, PB_ROLE_SRC)) return pb_fail(PB_ERR_INVALID, why);
+    if (n_rot < 0 || n_rot > PB_MAX_ROTATIONS || (n_rot > 0 && !rot3x3)) return pb_fail(PB_ERR_INVALID, "bad rotation arguments");
+    PbParams Q;
+    pb_params_of_request(Q, pb_to_end(dst), rot3x3, n_rot, pb_to_end(src));
+    return pb_same_request(Q, plan->P) ? 1 : 0;
 }
 
 int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, pb_plan** out) {
@@ -778,6 +848,7 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->saved_l);
     (void)hipFree(plan->saved_r);
     (void)hipFree(plan->ltable);
+    (void)hipFree(plan->P_dev);
     delete plan;
 }
 
@@ -829,13 +900,13 @@ static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t*
         const dim3 block(64 * PB_TILE_WAVES);
         // one launch per frame: failed tiles and fix pixels go through the plan's stored faithful taps
         const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
-        static const int fpw_env = [] { const char* e = getenv("PB_DOUBLE_FPW"); return e ? atoi(e) : 0; }();
+        static const int fpw_env = pb_knob("PB_DOUBLE_FPW", 0);
         const int fpw = fpw_env > 0 ? fpw_env : PB_DOUBLE_FRAMES_PER_WAVE;
         const unsigned gpf = plan->launch_groups;  // workgroups per frame of the plan's launch-order table
         const unsigned chunks = (unsigned)((n_frames + fpw - 1) / fpw);
         const dim3 bgrid(gpf * chunks);  // (h*w < 2^29 and n_frames an int: far below the grid limit for any batch that fits memory)
 #define PB_LAUNCH_DOUBLE(WMODE, ONE)                                                                                              \
-    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, ONE>), bgrid, block, pb_window_lds_bytes(P, 8), st, P, plan->table, plan->table_r, plan->ltable, rows, plan->lat_tab, \
+    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, ONE>), bgrid, block, pb_window_lds_bytes(P, 8) + (size_t)pb_knob("PB_LDS_PAD", 0), st, P, plan->table, plan->table_r, plan->ltable, rows, plan->lat_tab, \
                        plan->fix_px, plan->dbl_px_fix, plan->dbl_tile_fix, src_dev, dst_dev, n_frames, src_frame_stride,           \
                        dst_frame_stride, gpf, fpw)
         const bool one = n_frames == 1 || fpw == 1;
@@ -888,7 +959,7 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         PB_HIP(hipGetLastError());
         return PB_OK;
     }
-    if (pb_use_fast(plan)) {
+    if (pb_use_fast(plan) && plan->ltable && plan->launch_groups > 0) {
         // launched like the nearest hot kernel: the plan's launch-order table, frames of a batch as a grid dimension;
         // LEAN tiles take their taps from LDS windows, except for frames LDS-DMA cannot address (not 16-byte aligned)
         const unsigned gpf = plan->launch_groups;
@@ -1167,7 +1238,7 @@ struct PbBlobHeader {
     uint64_t checksum;  // of everything after the header
 };
 const uint32_t PB_BLOB_MAGIC = 0x4C504250u;  // "PBPL"
-const uint32_t PB_BLOB_VERSION = 2;
+const uint32_t PB_BLOB_VERSION = 3;
 
 struct PbSection {
     void** ptr;
@@ -1265,7 +1336,15 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
     pl->n_lat_tiles = h.n_lat_tiles; pl->diff_pixels = h.diff_pixels;
     pl->mode = PB_MODE_AUTO;
     const bool tiles = pl->fast_ready || pl->dbl_ready;
-    bool ok = (!tiles || pl->n_tiles == pb_num_tiles(pl->P)) && pl->n_fail_tiles <= 2u * pl->n_tiles + 1u &&
+    // the derived half of the parameter block must be what THIS build derives from the blob's own request (a blob whose tables
+    // were made for other constants is foreign, whatever its checksum says)
+    bool ok = pl->P.n_rot >= 0 && pl->P.n_rot <= PB_MAX_ROTATIONS;
+    if (ok) {
+        PbParams Q;
+        pb_params_of_request(Q, pl->P.dst, &pl->P.R[0][0], pl->P.n_rot, pl->P.src);
+        ok = pb_same_request(Q, pl->P);
+    }
+    ok = ok && (!tiles || pl->n_tiles == pb_num_tiles(pl->P)) && pl->n_fail_tiles <= 2u * pl->n_tiles + 1u &&
               pl->P.win_budget >= PB_DIRECT_LDS_BYTES && pl->P.win_budget <= PB_WINLDS_MAX && (pl->P.win_budget & 15) == 0 &&
               pl->P.n_rot >= 0 && pl->P.n_rot <= PB_MAX_ROTATIONS;
     // section presence is decided by pointers on the writing side: reproduce it from the recorded sizes
@@ -1298,6 +1377,10 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
         g_err = std::string("plan upload failed: ") + hipGetErrorString(hipGetLastError());
         pb_plan_destroy(pl);
         return rc;
+    }
+    if (hipMalloc((void**)&pl->P_dev, sizeof(PbParams)) != hipSuccess || hipMemcpy(pl->P_dev, &pl->P, sizeof(PbParams), hipMemcpyHostToDevice) != hipSuccess) {
+        pb_plan_destroy(pl);
+        return pb_fail(PB_ERR_HIP, "plan upload failed: parameter block");
     }
     rc = pb_build_launch_table(pl);  // derived state: rebuilt, not stored
     if (rc != PB_OK) {

@@ -84,3 +84,11 @@ def pb_plan(case: Case):
 
     src, cmap = pb_chain(case, image=np.zeros((case.src[1], case.src[2], 3), np.uint8))
     return _plan_for(cmap.dst_proj, cmap.rotations, src._proj())
+
+
+def pb_plan_private(case: Case, **kw):
+    """A plan of its own (not the facade's shared cache entry): for tests that re-budget or re-mode a plan."""
+    from photonbend_amd import _native as nat
+
+    src, cmap = pb_chain(case, image=np.zeros((case.src[1], case.src[2], 3), np.uint8))
+    return nat.Plan(cmap.dst_proj, cmap.rotations, src._proj(), **kw)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def test_plan_info_and_modes_c2_like():
     case = Case("mid", cam(1024, 1024, "equidistant", 360, inscribed(1024)), pano(1024, 2048))
-    plan = H.pb_plan(case)
+    plan = H.pb_plan_private(case)
     plan.set_window_budget(12288)  # the statistics below are those of the largest window budget
     info = plan.info()
     assert info["fast_path"] and info["tiles"] == 32 * 32
@@ -182,8 +182,7 @@ def test_window_budget_only_moves_tiles_between_paths(case):
     want = None
     b0 = None
     leans = []
-    src, cmap = H.pb_chain(case, image=np.zeros((case.src[1], case.src[2], 3), np.uint8))
-    plan = nat.Plan(cmap.dst_proj, cmap.rotations, src._proj(), budget=12288)
+    plan = H.pb_plan_private(case, budget=12288)
     for budget in (12288, 8176, 6144, 4224):
         plan.set_window_budget(budget)
         info = plan.info()

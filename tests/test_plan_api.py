@@ -100,7 +100,7 @@ def test_deferred_prepare_serialize_roundtrip(case):
     plan.prepare()  # idempotent
     assert plan.info() == info
     blob = plan.serialize()
-    twin = nat.Plan.deserialize(blob, d, s, len(rots))
+    twin = nat.Plan.deserialize(blob, d, rots, s)
     assert twin.info() == info
     assert torch.equal(twin.remap(frames), faithful) and torch.equal(twin.remap(frames[1]), faithful[1])
     twin.set_window_budget(12288)  # the certified flags travel with the blob
@@ -109,9 +109,20 @@ def test_deferred_prepare_serialize_roundtrip(case):
     bad = bytearray(blob)
     bad[len(bad) // 2] ^= 0x40
     with pytest.raises(nat.PbError, match="corrupt"):
-        nat.Plan.deserialize(bytes(bad), d, s, len(rots))
+        nat.Plan.deserialize(bytes(bad), d, rots, s)
     with pytest.raises(nat.PbError):
-        nat.Plan.deserialize(blob[:-7], d, s, len(rots))
+        nat.Plan.deserialize(blob[:-7], d, rots, s)
+    # an intact blob of ANOTHER request (one more rotation; another field of view) is refused: the cache's file name is no proof
+    other = list(rots) + [np.eye(3)]
+    with pytest.raises(nat.PbError, match="another geometry"):
+        nat.Plan.deserialize(blob, d, other, s)
+    if d.kind != nat.KIND_PANO:
+        import copy
+
+        d2 = copy.copy(d)
+        d2.fov = d.fov * 0.999
+        with pytest.raises(nat.PbError, match="another geometry"):
+            nat.Plan.deserialize(blob, d2, rots, s)
 
 
 @pytest.mark.gpu
