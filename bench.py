@@ -441,12 +441,16 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     coll_device = device if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    force_dist = os.environ.get("PB_FORCE_DIST") == "1"  # a group of ONE rank: the RCCL broadcast really runs on a 1-GPU box
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
+        kw = {} if "RANK" in os.environ else {"rank": 0, "world_size": 1}
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
+            dist.init_process_group(backend="nccl", device_id=device, **kw)  # RCCL over xGMI
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, **kw)
 
     # rank 0 owns the parameters; everyone else receives the block over RCCL
     block = None
@@ -493,7 +497,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -535,7 +539,7 @@ def main():
     sync_all()
 
     t = torch.tensor([dt], dtype=torch.float64, device=coll_device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
@@ -641,7 +645,7 @@ def main():
             if extra:
                 line["cpu_baseline"]["all_cores"] = extra
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -113,6 +113,36 @@ def ref_index(case: Case, cmap):
     return il.astype(np.int32), ir.astype(np.int32)
 
 
+def gen_full_raw():
+    """Adds to full.json, for the double-fisheye configs, the reference's output on the UNMASKED synthetic frame (both
+    eyes' taps carry data everywhere: outside the circles the two samples ADD and wrap mod 256, projection.py:439-460) -
+    an index error of either eye that black-on-black would hide changes these bytes.  The other pins are left as they are."""
+    path = os.path.join(GOLD, "full.json")
+    with open(path) as f:
+        pins = json.load(f)
+    for case in full_cases():
+        if case.src[0] != "double":
+            continue
+        _, cmap, _, _ = ref_map(case)
+        kind, h, w, *_ = case.src
+        frame = synth_frame(h, w, frame=0, seed=0, circle_mask=0)
+        src = ref_obj(case.src, frame)
+        u8 = src.process_coordinate_map(np.copy(cmap))
+        want = orc.remap(orc_proj(case.dst), orc_proj(case.src), frame, [tuple(map(to_radians, r)) for r in case.rotations])
+        assert np.array_equal(u8, want), f"{case.name} raw: oracle != reference"
+        H, W = u8.shape[:2]
+        pos = np.random.default_rng(pins[case.name]["sample_seed"]).integers(0, H * W, size=65536)
+        pins[case.name]["raw_frame_sha256"] = sha(frame)
+        pins[case.name]["raw_u8_sha256"] = sha(u8)
+        pins[case.name]["raw_u8_samples"] = [int(v) for v in u8.reshape(-1, 3)[pos[:2048]].ravel()]
+        pins[case.name]["raw_nonzero_bytes"] = int(np.count_nonzero(u8))
+        print(f"  {case.name} raw: {pins[case.name]['raw_nonzero_bytes']} non-zero bytes, sha {pins[case.name]['raw_u8_sha256'][:16]}")
+        del cmap, u8, frame
+    with open(path, "w") as f:
+        json.dump(pins, f, indent=1)
+    print("full.json updated (raw pins of the double-fisheye configs)")
+
+
 def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
@@ -365,13 +395,14 @@ if __name__ == "__main__":
     ap.add_argument("--lens", action="store_true")
     ap.add_argument("--small", action="store_true")
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--full-raw", action="store_true", help="only add the unmasked-frame pins of the double-fisheye configs to full.json")
     ap.add_argument("--mapproj", action="store_true")
     ap.add_argument("--cli", action="store_true")
     ap.add_argument("--real", action="store_true")
     ap.add_argument("--mid", action="store_true")
     ap.add_argument("--generic", action="store_true")
     a = ap.parse_args()
-    everything = not (a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic)
+    everything = not (a.full_raw or a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic)
     os.makedirs(GOLD, exist_ok=True)
     if a.lens or everything:
         gen_lens()
@@ -383,6 +414,8 @@ if __name__ == "__main__":
         gen_generic()
     if a.full or everything:
         gen_full()
+    if a.full or a.full_raw or everything:
+        gen_full_raw()
     if a.mapproj or everything:
         gen_mapproj()
     if a.cli or everything:

@@ -64,5 +64,25 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, d
     return out
 
 
+DIAG_LIB_PATH = os.path.join(HERE, "libphotonbend_hip_diag.so")
+
+
+def build_diagnostic(force: bool = False, verbose: bool = False) -> str:
+    """The -DPB_ABLATION build of the same sources (never the product: loaded only through PB_LIB_PATH by experiments/ and by
+    the error-path test): it alone reads the experiment knobs and the allocation-failure hook from the environment."""
+    if not force and os.path.exists(DIAG_LIB_PATH) and not _stale_against(DIAG_LIB_PATH):
+        return DIAG_LIB_PATH
+    return build_library(force=True, verbose=verbose, out=DIAG_LIB_PATH, defines=("PB_ABLATION",))
+
+
+def _stale_against(path: str) -> bool:
+    t = os.path.getmtime(path)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "photonbend_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    if "--diag" in sys.argv:
+        print(build_diagnostic(force=True, verbose=True))

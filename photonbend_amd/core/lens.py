@@ -6,7 +6,10 @@ callables that (a) work on the host for scalars/arrays exactly like the
 reference's (they are needed there: f_distance = magnitude / forward(fov / 2) is
 a host-side scalar, projection.py:141-144) and (b) carry a ``pb_lens`` id, which
 is what the HIP kernels dispatch on.  A Lens built from user callables has no
-id; the GPU path rejects it loudly instead of silently evaluating on the CPU.
+id: its functions are evaluated by the host on planes the device supplies (the
+exact radius mesh of a destination, the latitude plane of a source) and the
+device does everything else - index map, gather, blend (PB_LENS_CUSTOM,
+pb_index_from_map_i32's distance planes; projection.py of this package).
 """
 
 from __future__ import annotations

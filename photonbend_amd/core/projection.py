@@ -320,6 +320,9 @@ class _GpuProjection:
                 raise NotImplementedError("bilinear sampling needs a lazy coordinate map (a recipe), not a materialised array")
             if not rgb8 or custom_src:
                 raise NotImplementedError("bilinear sampling takes uint8 (H, W, 3) images and built-in lenses")
+            if len(coordinate_map.rotations) > nat.PB_MAX_ROTATIONS:
+                # (such a chain leaves the fused plan for the materialised-map kernels, which sample nearest-by-truncation only)
+                raise NotImplementedError(f"bilinear sampling takes at most {nat.PB_MAX_ROTATIONS} chained rotations")
         on_device = isinstance(self.image, torch.Tensor)
         fused = rgb8 and not custom_src
         img = _device_image(self.image, h, w) if fused else _device_bytes(self.image)

@@ -172,9 +172,9 @@ __device__ __forceinline__ pb_u32x3 pb_pack_px4(unsigned a0, unsigned a1, unsign
 //   Other tiles: generic path - validity thresholds, wrap, per-pixel "inside the window" test with an
 //   unaligned global load as fallback.
 // Requires frame pointers and strides that are multiples of 16 bytes (else pb_hot_kernel is used).
-// LDS window per wave: the plan builder classifies with the largest budget and then picks, per plan, the budget
-// that runs fastest (smaller windows = more workgroups per CU, but more tiles on the direct-gather path);
-// the hot kernels take it from PbParams::win_budget and use dynamic LDS.
+// LDS window per wave: the plan builder classifies with the largest budget (PB_WINLDS_MAX); the budget in use - the library
+// default of 7168 bytes, the caller's choice, or PB_PLAN_TUNE's pick by timing - only moves tiles between the window and the
+// direct-gather path (pb_budget_kernel); the hot kernels take it from PbParams::win_budget and use dynamic LDS.
 #define PB_WINLDS_MAX 12288
 #define PB_DIRECT_LDS_BYTES (33 * 32 * 4)  // regrouping buffer of a DIRECT tile: the smallest usable budget
 #define PB_WINLDS_BYTES PB_WINLDS_MAX  // classification budget of the plan builder

@@ -396,9 +396,10 @@ static int pb_clamp_budget(int budget) {
 // next is the plan's choice: a launch that ENDS on its cheapest rows drains faster.  Where the rows differ (a fisheye
 // output: black corners above and below, the dense centre between), the walk starts at the heaviest row and moves
 // outwards on two fronts, heavier neighbour first: c2 44.1 -> 41.8 us (ending on the centre rows instead: 46.7).  Rows
-// of even cost keep the plain top-to-bottom order (two fronts cost c3 10 %, c1 2 %).  PB_ORDER=1 forces top-to-bottom.
-// Cost-aware orders of SUPER-TILES (heavy / light alternating, heaviest first, black last, balanced XCDs) all lost:
-// c2 +1...+10 %.  Synchronous.
+// of even cost keep the plain top-to-bottom order (two fronts cost c3 10 %, c1 2 %) unless their SUPER-TILES differ (clusters of
+// failed and direct-gather tiles): then the super-tiles go heaviest first, dealt round-robin (c3 37.9 -> 35.1 us).  Double-fisheye
+// plans walk top to bottom and let columns of super-tiles change XCD when one XCD runs ahead (the policy is spelled out where it
+// is applied, below).  -DPB_ABLATION builds: PB_ORDER=1 forces top-to-bottom.  Synchronous.
 static int pb_build_launch_table(pb_plan* pl) {
     PbParams& P = pl->P;
     if (!pl->fast_ready && !pl->dbl_ready) return PB_OK;  // (a double-fisheye plan: the left eye's table + PB_TILE_SOLO entries)

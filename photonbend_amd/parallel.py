@@ -65,8 +65,10 @@ def unpack_params(block: np.ndarray) -> Tuple[nat.pb_proj, List[np.ndarray], nat
 def broadcast_params(block, device=None, src: int = 0) -> np.ndarray:
     """Broadcast the parameter block from rank ``src`` (RCCL when the process
     group is nccl and ``device`` is a GPU; gloo on CPU).  Without an initialised
-    process group this is the identity (single process)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    process group this is the identity (single process); with one - a group of
+    ONE rank included - the collective really runs, so a single-GPU box exercises
+    the same RCCL call an 8-GPU node makes."""
+    if not (dist.is_available() and dist.is_initialized()):
         if block is None:
             raise nat.PbError("no parameter block on a single-process run")
         return np.asarray(block, dtype=np.float64)
@@ -94,8 +96,9 @@ def remap_batch_sharded(dst_proj, rotations, src_proj, load_frame, n_frames: int
 
     ``load_frame(i)`` returns frame i as a uint8 CUDA tensor (h, w, 3).  Rank 0's
     parameters win (broadcast); returns (frame indices, list of output tensors).
-    Frames are launched ``chunk`` at a time so the per-pixel index math is
-    amortised over the chunk (pb_remap_u8's n_frames)."""
+    Frames are launched ``chunk`` at a time: one pb_remap_u8 call = ONE kernel
+    launch whose grid spans the chunk's frames (the launch ramp and drain are paid
+    once per chunk; the index math is simply repeated per frame)."""
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank() if world > 1 else 0
     block = pack_params(dst_proj, rotations, src_proj) if rank == 0 else None

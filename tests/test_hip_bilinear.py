@@ -86,3 +86,19 @@ def test_bilinear_api_and_noise_frame():
     grey = pb.PanoramaImage(np.zeros((16, 32), np.uint8))
     with pytest.raises(NotImplementedError):  # the opt-in mode takes uint8 RGB only
         grey.process_coordinate_map(cmap, interpolation="bilinear")
+
+
+def test_bilinear_rejects_chains_beyond_one_fused_plan():
+    """nine rotations leave the fused plan for the materialised-map kernels, which only truncate - bilinear used to come
+    back nearest-sampled without a word.  It raises now; the same chain in the nearest mode still works."""
+    import photonbend_amd as pb
+
+    frame = synth_frame(64, 128, frame=3)
+    dst = pb.CameraImage(np.zeros((48, 48, 3), np.uint8), pb.utils.to_radians(180), pb.equidistant())
+    cmap = dst.get_coordinate_map()
+    for k in range(9):
+        cmap = pb.Rotation(0.1 * k, -0.05 * k, 0.02).rotate_coordinate_map(cmap)
+    src = pb.PanoramaImage(frame)
+    with pytest.raises(NotImplementedError, match="chained rotations"):
+        src.process_coordinate_map(cmap, interpolation="bilinear")
+    assert src.process_coordinate_map(cmap).shape == (48, 48, 3)

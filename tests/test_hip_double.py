@@ -88,3 +88,99 @@ def test_double_unaligned_and_strided():
         for f in range(3):
             assert torch.equal(dbuf[f * ds : f * ds + n_dst].reshape(H_, W_, 3), want[f]), (pad, f)
             assert int(dbuf[f * ds + n_dst : (f + 1) * ds].sum()) == 0
+
+
+# ---- the two-eye hot kernel at FULL size (c5 was pinned by bytes on the masked frame only) -------------
+def _self_index_frames(h, w, eye):
+    """Two frames whose texels encode their own linear index + 1 (three bytes in frame 0, the fourth in frame 1's red
+    channel); eye = 'l' / 'r' keeps one eye and zeroes the other half of the side-by-side frame."""
+    lin = torch.arange(1, h * w + 1, dtype=torch.int64, device="cuda").reshape(h, w)
+    keep = torch.zeros((h, w), dtype=torch.bool, device="cuda")
+    if eye == "l":
+        keep[:, : w // 2] = True
+    else:
+        keep[:, w // 2 :] = True
+    lin = torch.where(keep, lin, torch.zeros_like(lin)).reshape(-1)
+    lo = torch.stack([lin & 255, (lin >> 8) & 255, (lin >> 16) & 255], dim=1).to(torch.uint8).reshape(h, w, 3)
+    hi = torch.stack([(lin >> 24) & 255, torch.zeros_like(lin), torch.zeros_like(lin)], dim=1).to(torch.uint8).reshape(h, w, 3)
+    return torch.stack([lo, hi])
+
+
+def double_taps_through_hot_kernel(plan, h, w):
+    """(left, right) int32 (H, W) taps as the two-eye HOT kernel sampled them, valid where that eye's blend factor is exactly
+    1.0: with the other eye's half of the frame zeroed the blend (l * 1.0 + 0 * fr).astype(uint8) returns the live eye's texel,
+    and a texel that spells its own index gives the index back (0 = the tap was black or out of bounds -> -1)."""
+    taps = []
+    plan.set_mode(nat.MODE_FAST)
+    for eye in ("l", "r"):
+        out = plan.remap(_self_index_frames(h, w, eye)).to(torch.int64)
+        rec = out[0, ..., 0] | (out[0, ..., 1] << 8) | (out[0, ..., 2] << 16) | (out[1, ..., 0] << 24)
+        taps.append((rec - 1).to(torch.int32))
+        del out
+    plan.set_mode(nat.MODE_AUTO)
+    return taps
+
+
+def _check_taps(plan, h, w):
+    Hd, Wd = plan.dst.height, plan.dst.width
+    idx, wts = plan.index_map(weights=True)
+    idx = idx.reshape(2, Hd, Wd)
+    wts = wts.reshape(2, Hd, Wd)
+    got = double_taps_through_hot_kernel(plan, h, w)
+    n_checked = 0
+    for e in (0, 1):
+        # a tap counts where its factor is exactly 1 and the OTHER eye's factor is finite (0 * inf = NaN -> 0 in the cast)
+        unit = (wts[e] == 1.0) & torch.isfinite(wts[1 - e])
+        bad = int(((got[e] != idx[e]) & unit).sum())
+        assert bad == 0, f"eye {e}: {bad} taps of the hot kernel differ from pb_index_map_i32"
+        n_checked += int(unit.sum())
+    return n_checked, idx
+
+
+@pytest.mark.parametrize("name", ["c5_180", "c5_195"])
+def test_full_size_c5_taps_of_the_hot_double_kernel_and_raw_pins(name):
+    """The indices of BOTH eyes recovered from the benchmarked two-eye kernel itself (one-eye and two-eye tiles alike) equal
+    the index-map launch and the reference's SHA-256; the UNMASKED frame - data outside the circles, where the two samples add
+    and wrap - reproduces the reference's bytes; one 4-frame launch equals four single launches and the golden on frame 0."""
+    import hashlib
+
+    import numpy as np
+    from tests.cases import full_cases
+
+    case = [c for c in full_cases() if c.name == name][0]
+    pin = H.load_full()[name]
+    plan = H.pb_plan(case)
+    _, h, w, *_ = case.src
+    n_checked, idx = _check_taps(plan, h, w)
+    assert n_checked > 2 * 0.9 * plan.dst.height * plan.dst.width  # the merge band is thin: nearly every tap is checked
+    sha = lambda t: hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest()
+    assert sha(idx[0]) == pin["idx_l_sha256"] and sha(idx[1]) == pin["idx_r_sha256"]
+    del idx
+    # unmasked frame: the reference's bytes
+    raw = nat.synth_frame(h, w, frame=0, seed=0, circle_mask=0)
+    assert sha(raw) == pin["raw_frame_sha256"]
+    out = plan.remap(raw)
+    got = out.reshape(-1, 3).cpu().numpy()
+    pos = np.random.default_rng(pin["sample_seed"]).integers(0, got.shape[0], size=65536)
+    assert np.array_equal(got[pos[:2048]].ravel(), np.array(pin["raw_u8_samples"], dtype=np.uint8))
+    assert int(np.count_nonzero(got)) == pin["raw_nonzero_bytes"]
+    assert hashlib.sha256(got.tobytes()).hexdigest() == pin["raw_u8_sha256"]
+    del got, out, raw
+    # one 4-frame launch == four single launches; frame 0 == the golden
+    frames = torch.stack([nat.synth_frame(h, w, frame=f, seed=0, circle_mask=case.mask) for f in range(4)])
+    batched = plan.remap(frames)
+    for f in range(4):
+        assert torch.equal(plan.remap(frames[f]), batched[f]), f
+    assert hashlib.sha256(batched[0].cpu().numpy().tobytes()).hexdigest() == pin["u8_sha256"]
+    assert not torch.equal(batched[0], batched[1])
+
+
+@pytest.mark.parametrize("case", [CASES[1], CASES[4], CASES[6], CASES[8]], ids=lambda c: c.name)
+def test_taps_of_the_hot_double_kernel_mid_size(case):
+    """The same recovery at 0.5 K with rotations (latitude-table weights), fisheye and double-fisheye destinations."""
+    plan = H.pb_plan(case)
+    _, h, w, *_ = case.src
+    if (h * w * 3) % 16:
+        pytest.skip("the windowed kernel needs 16-byte aligned frames")
+    n_checked, _ = _check_taps(plan, h, w)
+    assert n_checked > 0

@@ -87,3 +87,41 @@ def test_random_geometry_matches_oracle(case):
     assert outside == 0, f"{outside} pixels differ from the oracle outside the fragile set ({int(bad.sum())} in total)"
     # fragile-set flips are allowed by the bar but must stay rare; report if any
     assert int(bad.sum()) <= max(4, bad.size // 2000), f"{int(bad.sum())} fragile-set differences"
+
+
+# ---- the same random geometries at 8 x the size: hundreds of LEAN / DIRECT / failed tiles each, every launch path --------
+def scaled_case(k: int, scale: int = 8) -> Case:
+    """random_case(5000 + k) with every image dimension (and magnitude) multiplied; half of the sources get a width that is
+    a multiple of 16 pixels (source rows the LDS-DMA windows can stage).  (experiments/fast_vs_faithful_sweep.py's recipe.)"""
+    rng = np.random.default_rng(5000 + k)
+    case = random_case(rng, k)
+
+    def up(p):
+        kind, h, w, lens, fov, mag = p
+        return (kind, h * scale, w * scale, lens, fov, None if mag is None else mag * scale)
+
+    case = Case(f"big{k}", up(case.dst), up(case.src), case.rotations, case.mask)
+    if rng.random() < 0.5:
+        kind, h, w, lens, fov, mag = case.src
+        w16 = max(32, (w // 16) * 16)
+        case = Case(case.name, case.dst, (kind, h if kind != "pano" else w16 // 2, w16, lens, fov, mag if kind != "camera" or mag is None else min(mag, 0.75 * min(h, w16))),
+                    case.rotations, case.mask)
+    return case
+
+
+BIG = [scaled_case(k) for k in range(16)]
+
+
+@pytest.mark.parametrize("case", BIG, ids=lambda c: f"{c.name}:{c.dst[0]}{c.dst[1]}x{c.dst[2]}<-{c.src[0]}{c.src[1]}x{c.src[2]}:r{len(c.rotations)}")
+def test_random_geometries_8x_fast_equals_faithful(case):
+    """0.3-2.4 K geometries (these were checked only by an experiment script): the windowed hot kernel, the
+    direct-gather kernels and a 2-frame batch against the float64 kernel, byte for byte."""
+    plan = H.pb_plan_private(case)
+    _, h, w, *_ = case.src
+    frames = torch.stack([nat.synth_frame(h, w, frame=f) for f in range(2)])
+    plan.set_mode(nat.MODE_FAITHFUL)
+    want = plan.remap(frames).clone()
+    for mode in (nat.MODE_FAST, nat.MODE_FAST_DIRECT):
+        plan.set_mode(mode)
+        assert torch.equal(plan.remap(frames), want), mode
+        assert torch.equal(plan.remap(frames[1]), want[1]), mode
