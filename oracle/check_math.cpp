@@ -1,0 +1,95 @@
+// check_math.cpp - TEST INFRASTRUCTURE (oracle/): the device math of photonbend_amd/csrc/pb_math.hpp compiled for the HOST and
+// compared, bit for bit, with this machine's glibc (what the reference reaches through NumPy: SURVEY 2) and with the
+// correctly rounded value (libquadmath, 113-bit).  Prints one line per function: arguments, mismatches against glibc,
+// mismatches against correct rounding, glibc's own mismatches against correct rounding.
+//   g++ -O2 -ffp-contract=off -mfma -o oracle/_ref/check_math oracle/check_math.cpp -lquadmath && oracle/_ref/check_math [n]
+#include <quadmath.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../photonbend_amd/csrc/pb_math.hpp"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() {
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return rng_state;
+}
+static double uni() { return (double)(rnd() >> 11) * 0x1p-53; }
+static bool same(double a, double b) { return memcmp(&a, &b, 8) == 0 || (a != a && b != b); }
+
+int main(int argc, char** argv) {
+    const long n = argc > 1 ? atol(argv[1]) : 2000000;
+    const double pi = 3.141592653589793;
+    long bad_g = 0, bad_q = 0, g_q = 0;
+    // ---- sine / cosine: longitudes in [-pi, pi], latitudes in [0, pi], lens arguments (halves, 0.713 x), small values
+    for (long i = 0; i < n; ++i) {
+        double x;
+        switch (i & 3) {
+            case 0: x = (2.0 * uni() - 1.0) * pi; break;
+            case 1: x = uni() * pi; break;
+            case 2: x = uni() * pi * 0.713; break;
+            default: x = ldexp(2.0 * uni() - 1.0, -(int)(rnd() % 40)); break;
+        }
+        double s, c;
+        pb_sincos_cr(x, &s, &c);
+        const double gs = sin(x), gc = cos(x);
+        const double qs = (double)sinq((__float128)x), qc = (double)cosq((__float128)x);
+        bad_g += !same(s, gs) + !same(c, gc);
+        bad_q += !same(s, qs) + !same(c, qc);
+        g_q += !same(gs, qs) + !same(gc, qc);
+    }
+    printf("sincos  n=%ld values=%ld  vs_glibc=%ld  vs_correctly_rounded=%ld  glibc_vs_correctly_rounded=%ld\n", n, 2 * n, bad_g, bad_q, g_q);
+    // ---- atan2: pixel-centre offsets (half-integers) as a destination's mesh gives them, and unit-vector components as a
+    // rotation gives them
+    bad_g = bad_q = g_q = 0;
+    for (long i = 0; i < n; ++i) {
+        double y, x;
+        if (i & 1) {
+            y = (double)((long)(rnd() % 8192) - 4096) + 0.5;
+            x = (double)((long)(rnd() % 8192) - 4096) + 0.5;
+        } else {
+            const double lat = uni() * pi, lon = (2.0 * uni() - 1.0) * pi;
+            x = cos(lon) * sin(lat);
+            y = sin(lon) * sin(lat);
+            if (rnd() & 1) x *= uni();
+        }
+        const double r = pb_atan2_cr(y, x), g = atan2(y, x), q = (double)atan2q((__float128)y, (__float128)x);
+        bad_g += !same(r, g);
+        bad_q += !same(r, q);
+        g_q += !same(g, q);
+    }
+    printf("atan2   n=%ld values=%ld  vs_glibc=%ld  vs_correctly_rounded=%ld  glibc_vs_correctly_rounded=%ld\n", n, n, bad_g, bad_q, g_q);
+    // ---- atan (lens inverses): radii in focal-length units
+    bad_g = bad_q = g_q = 0;
+    for (long i = 0; i < n; ++i) {
+        const double x = (i & 1) ? uni() * 4.0 : ldexp(uni(), -(int)(rnd() % 30));
+        const double r = pb_atan_cr(x), g = atan(x), q = (double)atanq((__float128)x);
+        bad_g += !same(r, g);
+        bad_q += !same(r, q);
+        g_q += !same(g, q);
+    }
+    printf("atan    n=%ld values=%ld  vs_glibc=%ld  vs_correctly_rounded=%ld  glibc_vs_correctly_rounded=%ld\n", n, n, bad_g, bad_q, g_q);
+    // ---- special values keep the platform's results
+    const double sp[] = {0.0, -0.0, 1.0, -1.0, 0.5, INFINITY, -INFINITY, NAN, 1e300, -1e-300, 4e-320};
+    long bad_s = 0;
+    for (double y : sp)
+        for (double x : sp)
+            if (!same(pb_atan2_cr(y, x), atan2(y, x))) {
+                ++bad_s;
+                printf("  atan2(%g, %g): %a vs glibc %a\n", y, x, pb_atan2_cr(y, x), atan2(y, x));
+            }
+    for (double x : sp) bad_s += !same(pb_atan_cr(x), atan(x));
+    for (double x : sp) {
+        double s, c;
+        pb_sincos_cr(x, &s, &c);
+        bad_s += !same(s, sin(x)) + !same(c, cos(x));
+    }
+    printf("special values: %ld mismatches against glibc\n", bad_s);
+    return 0;
+}

@@ -318,7 +318,7 @@ __device__ __forceinline__ unsigned pb_bilinear_eye(const PbParams& P, const uin
     const int h = P.src.height, w = P.src.width;
     const double dist = pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
     double sl, cl;
-    sincos(lon, &sl, &cl);
+    pb_sincos_cr(lon, &sl, &cl);  // np.exp(lon * 1j)
     const double f0 = ((sl * dist) * -1.0) + P.src_cy, f1 = (cl * dist) + cx;
     const bool live = f0 == f0 && f1 == f1 && fabs(f0) < 1.0e9 && fabs(f1) < 1.0e9 && f0 >= 0.0 && f0 < (double)h && f1 >= 0.0 && f1 < (double)we;
     if (!live) return 0u;

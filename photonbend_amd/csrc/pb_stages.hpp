@@ -1,8 +1,12 @@
 // pb_stages.hpp - the three per-pixel stages of photonbend's remap, as device
 // functions for ONE output pixel, in "faithful" float64: every IEEE-exact
 // operation (add, mul, div, sqrt, fma) is replayed in the reference's order with
-// contraction disabled (-ffp-contract=off), transcendentals come from the device
-// libm, and the NumPy cast quirks are spelled out.
+// contraction disabled (-ffp-contract=off), and the NumPy cast quirks are spelled out.
+// Transcendentals: sin / cos / atan2 - glibc's in the reference (np.sin, np.cos, np.exp(1j x), np.log(complex).imag) - are the
+// correctly rounded functions of pb_math.hpp (99.9 % bit-equal with glibc 2.35, which is itself correctly rounded on all but
+// ~1 argument in 1000), and so is atan (np.arctan: NumPy's SIMD path, correctly rounded on all but 7 arguments in 10 000);
+// asin / acos / tan stay with the device libm: NumPy's versions on the reference's host (SIMD asin / acos, glibc tan) are
+// 8-17 % away from correct rounding, so exactness would take THEIR algorithms, which are not the reference's to give.
 //
 //   stage A  dst_coord()      pixel (i, j) -> (lat, lon, invalid)
 //            CameraImage._compute_latitude_longitude  projection.py:171-194
@@ -14,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "pb_math.hpp"
 #include "pb_params.hpp"
 
 struct PbCoord {
@@ -47,10 +52,10 @@ __device__ __forceinline__ int pb_floor_mod(long long a, int n) {
 __device__ __forceinline__ double pb_lens_forward(int lens, double theta, double rect_max) {
     switch (lens) {
         case PB_LENS_EQUIDISTANT: return theta;                          // lens.py:187
-        case PB_LENS_EQUISOLID: return 2.0 * sin(theta / 2.0);           // lens.py:240-243
+        case PB_LENS_EQUISOLID: return 2.0 * pb_sin_cr(theta / 2.0);     // lens.py:240-243
         case PB_LENS_STEREOGRAPHIC: return 2.0 * tan(theta / 2.0);       // lens.py:142-145
-        case PB_LENS_ORTHOGRAPHIC: return sin(theta);                    // lens.py:285
-        case PB_LENS_THOBY: return 1.47 * sin(0.713 * theta);            // lens.py:332-335
+        case PB_LENS_ORTHOGRAPHIC: return pb_sin_cr(theta);              // lens.py:285
+        case PB_LENS_THOBY: return 1.47 * pb_sin_cr(0.713 * theta);      // lens.py:332-335
         default: {                                                       // lens.py:97-103
             double t = tan(theta);
             return (theta < 0.0 || theta > rect_max) ? __builtin_nan("") : t;
@@ -64,17 +69,16 @@ __device__ __forceinline__ double pb_lens_inverse(int lens, double r) {
             double t = 2.0 * asin(r / 2.0);
             return (t != t) ? 0.0 : t;
         }
-        case PB_LENS_STEREOGRAPHIC: return 2.0 * atan(r / 2.0);          // lens.py:121-124
+        case PB_LENS_STEREOGRAPHIC: return 2.0 * pb_atan_cr(r / 2.0);    // lens.py:121-124
         case PB_LENS_ORTHOGRAPHIC: return asin(r);                       // lens.py:261
         case PB_LENS_THOBY: return asin(r / 1.47) / 0.713;               // lens.py:305
-        default: return atan(r);                                         // lens.py:71
+        default: return pb_atan_cr(r);                                   // lens.py:71
     }
 }
 
-// atan2 as np.log(complex).imag gives it (glibc atan2).  The octant
-// lines |x| == |y| and the axes must come out correctly rounded because there the
-// pre-truncation longitude coordinate of a pano source is an exact integer
-// (SURVEY 7 hard part 2); the device libm is used elsewhere.
+// atan2 as np.log(complex).imag gives it (glibc atan2): correctly rounded (pb_math.hpp).  That covers the
+// octant lines |x| == |y| and the axes, where the pre-truncation longitude coordinate of a pano source is an exact integer
+// (SURVEY 7 hard part 2) - they keep their shortcut only for speed.
 __device__ __forceinline__ double pb_atan2(double y, double x) {
     const double ax = fabs(x), ay = fabs(y);
     if (ax == ay && ax != 0.0 && ax < __builtin_inf()) {
@@ -83,7 +87,7 @@ __device__ __forceinline__ double pb_atan2(double y, double x) {
         double r = (x > 0.0) ? q : q3;
         return (y < 0.0) ? -r : r;
     }
-    return atan2(y, x);
+    return pb_atan2_cr(y, x);
 }
 
 // ---- stage A ---------------------------------------------------------------------
@@ -223,10 +227,9 @@ __device__ __forceinline__ PbCoord pb_rotate(const double* __restrict__ R, PbCoo
         c.lon = 0.0;
         return c;
     }
-    const double yy = cos(c.lat);
-    const double s = sin(c.lat);
-    double sl, cl;
-    sincos(c.lon, &sl, &cl);
+    double s, yy, sl, cl;
+    pb_sincos_cr(c.lat, &s, &yy);   // np.cos(lat), np.sin(lat)   rotation.py:129-131
+    pb_sincos_cr(c.lon, &sl, &cl);  // np.exp(lon * 1j)
     const double x = cl * s, z = sl * s;  // rotation.py:130-132
     // accumulation order of the BLAS behind np.matmul (probe)
     const double vx = fma(R[2], z, fma(R[0], x, R[1] * yy));
@@ -254,7 +257,7 @@ __device__ __forceinline__ bool pb_src_camera_pos(const PbParams& P, double lat,
                                                   double cx, int& py, int& px) {
     const double dist = pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
     double sl, cl;
-    sincos(lon, &sl, &cl);
+    pb_sincos_cr(lon, &sl, &cl);  // np.exp(lon * 1j)   projection.py:252
     const double re = cl * dist, im = sl * dist;
     const long long y = pb_cvt_i64((im * -1.0) + cy);
     const long long x = pb_cvt_i64(re + cx);

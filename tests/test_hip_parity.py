@@ -112,6 +112,14 @@ def test_materialised_maps_within_ulps(case, capsys):
                       f"max {int(d.max())} ulp, {int((d > 1).sum())} of {d.size} values beyond 1 ulp, "
                       f"max away from the poles {int(well.max()) if well.size else 0} ulp", end="")
             assert ok.all(), f"stage {k} {name}: max {d.max()} ulp"
+            if k == 0:
+                # round 3: sin / cos / atan2 / atan of the device chain are correctly rounded (pb_math.hpp) like glibc's and
+                # np.arctan on all but ~1 argument in 1000: longitudes and atan / identity latitudes agree to the bit or to 1 ulp;
+                # asin-based lenses (equisolid, orthographic: 1 ulp; thoby: asin(r / 1.47) / 0.713, 2 ulp) meet NumPy's SIMD asin,
+                # which is itself 8 % away from correct rounding
+                limit = 0 if name == "lon" and lens == "pano" else (1 if name == "lon" or lens in ("equidistant", "stereographic", "rectilinear", "pano") else 2)
+                assert int(d.max()) <= limit, f"stage 0 {name} ({lens}): {int(d.max())} ulp > {limit}"
+                assert int((d > 0).sum()) <= max(2, d.size // 100) or lens in ("equisolid", "orthographic", "thoby"), f"stage 0 {name}: {int((d > 0).sum())} values differ"
 
 
 @pytest.mark.parametrize("case", [c for c in small_cases() if c.keep_map], ids=lambda c: c.name)

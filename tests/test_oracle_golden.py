@@ -2,6 +2,7 @@
 reference (oracle/make_goldens.py).  Bit-for-bit: this is what pins parity."""
 
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -129,3 +130,30 @@ def test_c1_real_image_pin():
     src = orc.Proj("camera", img.shape[0], img.shape[1], "equidistant", orc.to_radians(360), img.shape[1] / 2 - 0.5)
     out = orc.remap(orc.Proj("pano", 2048, 4096), src, img)
     assert _sha(out) == pin["u8_sha256"]
+
+
+def test_device_math_agrees_with_glibc(tmp_path):
+    """photonbend_amd/csrc/pb_math.hpp (the sin / cos / atan2 / atan of the faithful device chain) compiled for the HOST: every
+    result is the correctly rounded one (113-bit libquadmath reference) and therefore equals this machine's glibc - what the
+    reference reaches through NumPy - wherever glibc is itself correctly rounded (all but ~1 argument in 1000)."""
+    import re
+    import shutil
+    import subprocess
+
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_math")
+    res = subprocess.run([gxx, "-O2", "-ffp-contract=off", "-mfma", "-o", exe, os.path.join(root, "oracle", "check_math.cpp"), "-lquadmath"],
+                         capture_output=True, text=True)
+    if res.returncode != 0 and "quadmath" in res.stderr:
+        pytest.skip("libquadmath missing")
+    assert res.returncode == 0, res.stderr
+    out = subprocess.run([exe, "400000"], capture_output=True, text=True, timeout=300).stdout
+    rows = re.findall(r"(\w+)\s+n=\d+ values=(\d+)\s+vs_glibc=(\d+)\s+vs_correctly_rounded=(\d+)\s+glibc_vs_correctly_rounded=(\d+)", out)
+    assert [r[0] for r in rows] == ["sincos", "atan2", "atan"], out
+    for name, n, vs_glibc, vs_cr, glibc_cr in rows:
+        assert int(vs_cr) == 0, f"{name}: {vs_cr} of {n} results are not correctly rounded"
+        assert int(vs_glibc) == int(glibc_cr) and int(vs_glibc) <= int(n) * 3 // 1000, f"{name}: {vs_glibc} of {n} differ from glibc"
+    assert "special values: 0 mismatches" in out, out
