@@ -255,7 +255,7 @@ def byte_accounting(plan, src_hw, device):
     return out_bytes + 3 * int(valid.numel()), out_bytes + LINE * int(touched.sum().item())
 
 
-def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0, pool_bytes=320 << 20):
+def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0, pool_bytes=320 << 20, bilinear=False):
     """One config measured like the headline, inside this process: its plan at the pinned budget, a pool of distinct frames
     larger than the 256 MiB Infinity Cache, `steps` launches in groups of 4 between HIP event pairs on the launch stream.
     Returns the entry of the line's ``configs`` block."""
@@ -281,9 +281,11 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
     sp0, dp0, h = srcs.data_ptr(), dsts.data_ptr(), plan.handle
     groups_in_pool = pool // batch
 
+    fn = lib.pb_remap_bilinear_u8 if bilinear else lib.pb_remap_u8
+
     def step(k):
         i = (k % groups_in_pool) * batch
-        rc = lib.pb_remap_u8(h, sp0 + i * sbytes, dp0 + i * dbytes, batch, sbytes, dbytes, stream)
+        rc = fn(h, sp0 + i * sbytes, dp0 + i * dbytes, batch, sbytes, dbytes, stream)
         if rc:
             nat.check(rc)
 
@@ -310,6 +312,12 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
         durs.append(ms.value / every / batch)
     for e in ev:
         lib.pb_event_destroy(e)
+    if bilinear:  # the opt-in 4-tap mode (no reference behaviour): time only
+        per_frame_ms = float(np.mean(durs))
+        del srcs, dsts, plan
+        torch.cuda.empty_cache()
+        return {"workload": cfg["text"] + " - OPT-IN bilinear sampling (pb_remap_bilinear_u8; not the reference's sampler)", "frames_per_launch": batch,
+                "kernel_ms_per_frame": round(per_frame_ms, 5), "mpx_per_s": round(dh * dw / 1e6 / (per_frame_ms * 1e-3), 1), "launches_timed": n_groups * every}
     alg, must = byte_accounting(plan, (sh, sw), device)
     pins = json.load(open(os.path.join(ROOT, "tests", "golden", "full.json")))
     ref_alg = int(pins[cfg["pin"]]["algorithmic_bytes"])
@@ -638,6 +646,7 @@ def main():
             block = {}
             for name in ("c1", "c3", "c5", "c4shard", "c5shard"):
                 block[name] = measure_config(lib, nat, name, device, sts[0])
+            block["c5_bilinear"] = measure_config(lib, nat, "c5", device, sts[0], steps=40, warmup=4, bilinear=True)
             line["configs"] = block
         if world == 1 and not args.no_cpu_baseline and not bilinear:  # (the CPU leg times the reference's nearest sampler)
             line["cpu_baseline"] = cpu_baseline(cfg, mpx_per_frame)

@@ -9,7 +9,8 @@
 // outside [0, h) x [0, w)) stay black.  A double-fisheye source is the reference's own blend (projection.py:439-460) of
 // the two eyes' BILINEAR samples: each eye is sampled like a camera source on its half of the frame (the right eye on
 // the mirrored half, taps clamped to the eye), rounded to uint8, then (l * fl + r * fr).astype(uint8) with the
-// reference's factors - pb_bilinear_double_kernel, float64 coordinates per pixel.
+// reference's factors - pb_bilinear_double_hot_kernel from the per-eye tile models of the nearest mode's plan (round 3),
+// pb_bilinear_double_kernel (float64 coordinates per pixel) for plans without tile tables.
 //
 //   pb_bilinear_hot_kernel   modelled tiles: float32 tile models give f (error ~1e-5 px, no fix list needed: there
 //                            is no truncation to protect), exact integer validity thresholds; LEAN tiles read their
@@ -343,25 +344,277 @@ __device__ __forceinline__ unsigned pb_bilinear_eye(const PbParams& P, const uin
     return out;
 }
 
+// one output pixel of the double-fisheye bilinear mode from the float64 chain (the mode's definition on the device)
+__device__ __forceinline__ unsigned pb_bilinear_double_px(const PbParams& P, int i, int j, const uint8_t* __restrict__ s) {
+    PbCoord c = pb_dst_coord(P, i, j);
+    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    if (c.inv) return 0u;
+    const double lat_r = (c.lat * -1.0) + PB_PI;  // projection.py:426-427
+    const double fl = pb_merge_factor(P, c.lat), fr = pb_merge_factor(P, lat_r);
+    const unsigned l = pb_bilinear_eye(P, s, c.lat, c.lon, P.src_eye_w, P.src_cx, 0, false);
+    const unsigned r = pb_bilinear_eye(P, s, lat_r, c.lon, P.src_eye_w_right, P.src_cx_r, P.src_eye_w, true);
+    return pb_blend_u8(l & 0xFF, r & 0xFF, fl, fr) | (pb_blend_u8((l >> 8) & 0xFF, (r >> 8) & 0xFF, fl, fr) << 8) |
+           (pb_blend_u8((l >> 16) & 0xFF, (r >> 16) & 0xFF, fl, fr) << 16);
+}
+
 __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_kernel(const PbParams P, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                       int n_frames, unsigned long long src_stride, unsigned long long dst_stride) {
     const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
     if (p >= (unsigned)P.dst.height * (unsigned)P.dst.width) return;
     const int i = p / (unsigned)P.dst.width, j = p - (unsigned)i * (unsigned)P.dst.width;
-    PbCoord c = pb_dst_coord(P, i, j);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
-    const double lat_r = (c.lat * -1.0) + PB_PI;  // projection.py:426-427
-    const double fl = pb_merge_factor(P, c.lat), fr = pb_merge_factor(P, lat_r);
     for (int f = 0; f < n_frames; ++f) {
-        const uint8_t* s = src + (unsigned long long)f * src_stride;
-        unsigned v = 0;
-        if (!c.inv) {
-            const unsigned l = pb_bilinear_eye(P, s, c.lat, c.lon, P.src_eye_w, P.src_cx, 0, false);
-            const unsigned r = pb_bilinear_eye(P, s, lat_r, c.lon, P.src_eye_w_right, P.src_cx_r, P.src_eye_w, true);
-            v = pb_blend_u8(l & 0xFF, r & 0xFF, fl, fr) | (pb_blend_u8((l >> 8) & 0xFF, (r >> 8) & 0xFF, fl, fr) << 8) |
-                (pb_blend_u8((l >> 16) & 0xFF, (r >> 16) & 0xFF, fl, fr) << 16);
-        }
+        const unsigned v = pb_bilinear_double_px(P, i, j, src + (unsigned long long)f * src_stride);
         uint8_t* o = dst + (unsigned long long)f * dst_stride + 3ull * p;
+        o[0] = (uint8_t)(v & 0xFF);
+        o[1] = (uint8_t)((v >> 8) & 0xFF);
+        o[2] = (uint8_t)((v >> 16) & 0xFF);
+    }
+}
+
+// ---- double-fisheye source through the per-eye tile models (round 3) -----------------------------------------------------
+// The bilinear taps of ONE eye for a lane's 16 pixels (4 consecutive pixels x 4 rows, as everywhere), from the eye's tile
+// entry of the nearest mode's plan.  Coordinates are the model's, in FRAME space: the right eye's model already runs over
+// the mirrored half (its column coordinate is w - x_eye), and bilinear interpolation commutes with the mirror, so the taps
+// are the frame's texels floor(s), floor(s) + 1 of either eye - clamped to the eye's own columns [cmin, cmax) and to the
+// frame's rows, as the definition clamps them to the eye's image.  Three paths, like the single-source kernel:
+//   window   LEAN tile whose box (margin texel = the taps' reach included) lies inside the eye: the nearest mode's LDS window;
+//   direct   plain tile inside the eye: unguarded 8-byte loads of both taps of a row;
+//   clamped  a plain tile at the edge of its eye: taps clamped one by one.
+// Tiles that are not plain for an eye that sees them (partly outside the eye's image, partly invalid) are NOT served here: the
+// nearest mode's certification lets their models be sloppy where almost no pixel samples (the truncation absorbs it), which a
+// bilinear tap does not forgive - such tiles go to the float64 pass whole (pb_bilinear_double_fix_kernel, the plan's list).
+__device__ __forceinline__ unsigned pb_bilinear_taps_clamped(const uint8_t* __restrict__ s, int h, int w, int cmin, int cmax, float sy, float sx, int by, int bx) {
+    const float fy0 = floorf(sy), fx0 = floorf(sx);
+    const float ty = sy - fy0, tx = sx - fx0;
+    int r0 = by + (int)fy0, c0 = bx + (int)fx0;
+    int r1 = r0 + 1, c1 = c0 + 1;
+    r0 = min(max(r0, 0), h - 1);
+    r1 = min(max(r1, 0), h - 1);
+    c0 = min(max(c0, cmin), cmax - 1);
+    c1 = min(max(c1, cmin), cmax - 1);
+    return pb_bilinear_mix(pb_load_px(s, r0 * w + c0), pb_load_px(s, r0 * w + c1), pb_load_px(s, r1 * w + c0), pb_load_px(s, r1 * w + c1), tx, ty);
+}
+
+template <int EYE>
+__device__ __forceinline__ void pb_bilinear_eye_vals(const PbParams& P, const PbTileEntry* __restrict__ e, const int flags, const int X0, const int Y0,
+                                                     const int lane, unsigned* win, const int windows, const uint8_t* __restrict__ s, unsigned v[16]) {
+    const int xg = lane & 7, yb = lane >> 3;
+    const int h = P.src.height, w = P.src.width;
+    const unsigned rowbytes = 3u * (unsigned)w, frame_bytes = rowbytes * (unsigned)h, safe_len = frame_bytes & ~15u;
+    int cmin, cmax;
+    pb_src_col_range<EYE>(P, cmin, cmax);
+    if (!(flags & (PB_TILE_LEAN | PB_TILE_DIRECT))) {  // BLACK (callers never pass anything else that is not plain)
+#pragma unroll
+        for (int n = 0; n < 16; ++n) v[n] = 0u;
+        return;
+    }
+    const bool inside = e->win_c0 >= cmin && e->win_c0 + e->win_cols <= cmax;
+    if (inside && (flags & PB_TILE_LEAN) && windows) {
+        const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
+        const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+        pb_f2 fv[4][4];
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            pb_f2 a[5];
+            pb_collapse_row(e, yb + 8 * jr, a);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fv[jr][k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
+        }
+        asm volatile("" ::: "memory");
+        pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pb_wave_sync();
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[jr * 4 + k] = pb_bilinear_lds(win, fv[jr][k].x - 0.5f, fv[jr][k].y - 0.5f, pitch, a0);
+        pb_wave_sync();  // the window may be refilled (the other eye)
+        return;
+    }
+    if (inside) {
+        const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+        const bool wide = gbase + (unsigned)(e->win_rows - 1) * rowbytes + 3u * (unsigned)(e->win_cols - 1) + 8u <= frame_bytes;
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            pb_f2 c[5];
+            pb_collapse_row(e, yb + 8 * jr, c);
+            unsigned long long t8[4][2];
+            unsigned t[4][4];
+            float wy[4], wx[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const pb_f2 fv = pb_eval_row(c, pb_tile_coord(4 * xg + k));
+                const float sy = fv.x - 0.5f, sx = fv.y - 0.5f;
+                const float fy0 = floorf(sy), fx0 = floorf(sx);
+                wy[k] = sy - fy0;
+                wx[k] = sx - fx0;
+                const unsigned g = gbase + (unsigned)(int)fy0 * rowbytes + __umul24((unsigned)(int)fx0, 3u);
+                if (wide) {
+                    __builtin_memcpy(&t8[k][0], s + g, 8);
+                    __builtin_memcpy(&t8[k][1], s + g + rowbytes, 8);
+                } else {
+                    __builtin_memcpy(&t[k][0], s + g, 4);
+                    __builtin_memcpy(&t[k][1], s + g + 3u, 4);
+                    __builtin_memcpy(&t[k][2], s + g + rowbytes, 4);
+                    __builtin_memcpy(&t[k][3], s + g + rowbytes + 3u, 4);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (wide) {
+                    t[k][0] = (unsigned)t8[k][0];
+                    t[k][1] = (unsigned)(t8[k][0] >> 24);
+                    t[k][2] = (unsigned)t8[k][1];
+                    t[k][3] = (unsigned)(t8[k][1] >> 24);
+                }
+                v[jr * 4 + k] = pb_bilinear_mix(t[k][0], t[k][1], t[k][2], t[k][3], wx[k], wy[k]);
+            }
+        }
+        return;
+    }
+    // a plain tile at the edge of its eye: every pixel is live (that is what plain means), the taps are clamped one by one
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+        pb_f2 c[5];
+        pb_collapse_row(e, yb + 8 * jr, c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const pb_f2 fv = pb_eval_row(c, pb_tile_coord(4 * xg + k));
+            v[jr * 4 + k] = pb_bilinear_taps_clamped(s, h, w, cmin, cmax, fv.x - 0.5f, fv.y - 0.5f, e->anchor_r, e->anchor_c);
+        }
+    }
+}
+
+// One wave per tile, launched like pb_hot_double_kernel over the plan's launch-order table (frames of a batch: a grid
+// dimension).  A tile that sees ONE eye with weight exactly 1 (PB_TILE_SOLO: its slot carries the live eye's entry) is that
+// eye's bilinear sample; a two-eye tile samples the left eye, then the right eye (through the same LDS window), and blends
+// with the tile's weight class like the nearest mode - UNIT: the integer sum, ROW: the row table, LAT: the stored latitudes.
+// Failed tiles and the plan's fix pixels take the float64 chain (pb_bilinear_double_fix_kernel, behind this launch).
+template <int WMODE>
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_double_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
+                                                                                     const PbTileEntry* __restrict__ table_r,
+                                                                                     const PbTileEntry* __restrict__ ltable,
+                                                                                     const PbSepRow* __restrict__ rows,
+                                                                                     const double* __restrict__ lat_tab,
+                                                                                     const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                                     const unsigned groups_per_frame, unsigned long long src_stride,
+                                                                                     unsigned long long dst_stride, int windows) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned wg = blockIdx.x;
+    if (wg >= groups_per_frame) {
+        const unsigned f = wg / groups_per_frame;
+        wg -= f * groups_per_frame;
+        src += (unsigned long long)f * src_stride;
+        dst += (unsigned long long)f * dst_stride;
+    }
+    const unsigned vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)(wg * (unsigned)PB_TILE_WAVES + (unsigned)wave));
+    PbTileEntry entry;
+    pb_load_entry(ltable + vslot, entry);
+    if (entry.flags & PB_TILE_SKIP) return;
+    const int tx = entry.tile_xy & 0xFFFF, ty = (int)((unsigned)entry.tile_xy >> 16);
+    const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
+    const int xg = lane & 7, yb = lane >> 3;
+    const int W = P.dst.width, H = P.dst.height;
+    unsigned* win = pb_wave_window(P, wave, 8);
+    unsigned a[16];
+    if (entry.flags & PB_TILE_SOLO) {
+        if (entry.flags & PB_TILE_EYE_R)
+            pb_bilinear_eye_vals<PB_KIND_EYE_R>(P, &entry, entry.flags, X0, Y0, lane, win, windows, src, a);
+        else
+            pb_bilinear_eye_vals<PB_KIND_EYE_L>(P, &entry, entry.flags, X0, Y0, lane, win, windows, src, a);
+    } else {
+        const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
+        pb_load_entry(table_l + tile, entry);
+        const int fl0 = entry.flags, lat_slot = entry.aux_off;
+        const int served = PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK;
+        if ((fl0 & PB_TILE_FAILED) || !(fl0 & served)) return;  // failed, or not plain for the left eye: the float64 pass's (pb_bilinear_tile_list_kernel)
+        unsigned al[16];
+        pb_bilinear_eye_vals<PB_KIND_EYE_L>(P, &entry, fl0, X0, Y0, lane, win, windows, src, al);
+        pb_load_entry(table_r + tile, entry);
+        if (!(entry.flags & served)) return;
+        pb_bilinear_eye_vals<PB_KIND_EYE_R>(P, &entry, entry.flags, X0, Y0, lane, win, windows, src, a);
+        const bool by_row = WMODE == 1 && (fl0 & PB_TILE_W_ROW) != 0;
+        const bool by_lat = WMODE == 2 && (fl0 & PB_TILE_W_LAT) != 0;
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            double wl = 1.0, wr = 1.0;
+            if (by_row) {
+                const PbSepRow R = rows[min(Y0 + yb + 8 * jr, H - 1)];
+                wl = R.f_l;
+                wr = R.f_r;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (by_lat) {
+                    const double t = lat_tab[(size_t)lat_slot * PB_LAT_TILE_DOUBLES + (yb + 8 * jr) * PB_TILE + 4 * xg + k];
+                    wl = pb_merge_factor(P, t);
+                    wr = pb_merge_factor(P, (t * -1.0) + PB_PI);
+                }
+                a[jr * 4 + k] = pb_sep_blend(al[jr * 4 + k], a[jr * 4 + k], wl, wr);
+            }
+        }
+    }
+    const int x = X0 + 4 * xg;
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+        const int y = Y0 + yb + 8 * jr;
+        if (y >= H) continue;
+        const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+        if (x + 3 < W && (((uintptr_t)dst + off) & 3u) == 0) {
+            pb_store3<false>(pb_pack_px4(a[jr * 4], a[jr * 4 + 1], a[jr * 4 + 2], a[jr * 4 + 3]), dst + off);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (x + k < W) {
+                    dst[off + 3 * k + 0] = (uint8_t)(a[jr * 4 + k] & 0xFF);
+                    dst[off + 3 * k + 1] = (uint8_t)((a[jr * 4 + k] >> 8) & 0xFF);
+                    dst[off + 3 * k + 2] = (uint8_t)((a[jr * 4 + k] >> 16) & 0xFF);
+                }
+        }
+    }
+}
+
+// Plan creation (double-fisheye plans): the tiles pb_bilinear_double_hot_kernel does not serve - an eye sees the tile but the
+// tile is not plain for it - listed once (the budget only moves tiles between LEAN and DIRECT, never in or out of this list).
+__global__ void pb_bilinear_tile_list_kernel(const PbTileEntry* __restrict__ table_l, const PbTileEntry* __restrict__ table_r, unsigned n_tiles,
+                                             int32_t* __restrict__ list, unsigned* __restrict__ count) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int fl = table_l[t].flags, fr = table_r[t].flags;
+    const int served = PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK;
+    if ((fl | fr) & PB_TILE_FAILED) return;  // on the fail list already
+    if (!(fl & served) || !(fr & served)) list[atomicAdd(count, 1u)] = (int32_t)t;
+}
+
+// behind pb_bilinear_double_hot_kernel: the plan's failed tiles and the tiles of the list above (4 blocks each), then the fix
+// pixels (either eye's list), from the float64 chain
+__global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_fix_kernel(const PbParams P, const int32_t* __restrict__ fail_tiles, int n_fail_only,
+                                                                          const int32_t* __restrict__ more_tiles, int n_fail_tiles,
+                                                                          const int32_t* __restrict__ fix_px, int n_fix_px,
+                                                                          const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int n_frames,
+                                                                          unsigned long long src_stride, unsigned long long dst_stride) {
+    int i, j;
+    // n_fail_tiles: both lists together; the first n_fail_only entries come from fail_tiles
+    if ((int)blockIdx.x < 4 * n_fail_tiles) {
+        const int k = blockIdx.x >> 2;
+        const int t = k < n_fail_only ? fail_tiles[k] : more_tiles[k - n_fail_only];
+        const int ty = t / pb_tiles_x(P), tx = t - ty * pb_tiles_x(P);
+        const int local = (blockIdx.x & 3) * 256 + threadIdx.x;
+        i = ty * PB_TILE + (local >> 5);
+        j = tx * PB_TILE + (local & 31);
+        if (i >= P.dst.height || j >= P.dst.width) return;
+    } else {
+        const unsigned item = (blockIdx.x - 4u * (unsigned)n_fail_tiles) * PB_BLOCK + threadIdx.x;
+        if (item >= (unsigned)n_fix_px) return;
+        const unsigned p = (unsigned)fix_px[item];
+        i = p / (unsigned)P.dst.width;
+        j = p - (unsigned)i * (unsigned)P.dst.width;
+    }
+    const size_t p = (size_t)i * P.dst.width + j;
+    for (int f = 0; f < n_frames; ++f) {
+        const unsigned v = pb_bilinear_double_px(P, i, j, src + (unsigned long long)f * src_stride);
+        uint8_t* o = dst + (unsigned long long)f * dst_stride + 3 * p;
         o[0] = (uint8_t)(v & 0xFF);
         o[1] = (uint8_t)((v >> 8) & 0xFF);
         o[2] = (uint8_t)((v >> 16) & 0xFF);

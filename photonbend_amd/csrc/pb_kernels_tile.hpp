@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, 
         const bool solo_r = solo_ok && !solo_l && (fl & PB_TILE_BLACK) && (fr & plain);
         if (solo_l || solo_r) {
             if (solo_r) w = wr;
-            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK)) | PB_TILE_SOLO;
+            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK)) | PB_TILE_SOLO | (solo_r ? PB_TILE_EYE_R : 0);
         } else {
             w = 0;
         }

@@ -61,6 +61,8 @@ struct pb_plan {
     int32_t* saved_r = nullptr;
     // the hot kernel's launch-order copy of `table` (rebuilt with every budget change; derived, never serialized)
     PbTileEntry* ltable = nullptr;
+    int32_t* bil_tiles = nullptr;  // double-fisheye plans: tiles the bilinear tile kernel leaves to the float64 pass (an eye sees them, not plain for it)
+    unsigned n_bil_tiles = 0;
     PbParams* P_dev = nullptr;   // device copy of P as the hot launches see it (refreshed with every budget change)
     unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
     int walk = 0;                // launch-order rule: 0 = by policy (pb_build_launch_table), 1 = plain, 2 = rows from the heaviest outwards,
@@ -167,6 +169,29 @@ static bool pb_fast_possible(const PbParams& P) {
            P.src.height < (1 << 24);
 }
 
+// double-fisheye plans: the bilinear mode's float64 tile list (pb_bilinear_tile_list_kernel); derived state, not serialized
+static int pb_build_bilinear_list(pb_plan* pl) {
+    unsigned* cnt = nullptr;
+    (void)hipFree(pl->bil_tiles);
+    pl->bil_tiles = nullptr;
+    pl->n_bil_tiles = 0;
+    PB_HIP(hipMalloc((void**)&cnt, sizeof(unsigned)));
+    hipError_t e = hipMemset(cnt, 0, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&pl->bil_tiles, (size_t)(pl->n_tiles ? pl->n_tiles : 1) * sizeof(int32_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pb_bilinear_tile_list_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->table_r, pl->n_tiles, pl->bil_tiles, cnt);
+        e = hipMemcpy(&pl->n_bil_tiles, cnt, sizeof(unsigned), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(cnt);
+    if (e != hipSuccess) {
+        (void)hipFree(pl->bil_tiles);
+        pl->bil_tiles = nullptr;
+        pl->n_bil_tiles = 0;
+        return pb_fail(PB_ERR_HIP, std::string("bilinear tile list: ") + hipGetErrorString(e));
+    }
+    return PB_OK;
+}
+
 // Runs once per plan on the current device (synchronously, default stream):
 //  1. validity thresholds of a camera / double destination by bisection with the exact predicate;
 //  2. per-tile polynomial models (pb_model_kernel);
@@ -244,6 +269,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                     if (hipDeviceSynchronize() != hipSuccess) { rc = PB_ERR_HIP; break; }
                 }
             }
+            pl->n_tiles = ntiles;
+            if (pb_build_bilinear_list(pl) != PB_OK) { rc = PB_ERR_HIP; break; }
             pl->n_lean_tiles = res[4];
             pl->n_black_tiles = res[5];
             pl->n_direct_tiles = res[6];
@@ -304,8 +331,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         (void)hipFree(pl->table); (void)hipFree(pl->fail_tiles); (void)hipFree(pl->fix_px); (void)hipFree(pl->idx_tab); (void)hipFree(pl->fix_idx);
         pl->idx_tab = nullptr; pl->fix_idx = nullptr;
         (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols); (void)hipFree(pl->table_r); (void)hipFree(pl->lat_tab);
-        (void)hipFree(pl->dbl_tile_fix); (void)hipFree(pl->dbl_px_fix);
-        pl->dbl_tile_fix = nullptr; pl->dbl_px_fix = nullptr;
+        (void)hipFree(pl->dbl_tile_fix); (void)hipFree(pl->dbl_px_fix); (void)hipFree(pl->bil_tiles);
+        pl->dbl_tile_fix = nullptr; pl->dbl_px_fix = nullptr; pl->bil_tiles = nullptr; pl->n_bil_tiles = 0;
         pl->table_r = nullptr; pl->lat_tab = nullptr; pl->sep_ready = 0; pl->dbl_ready = 0;
         pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr; pl->sep_rows = nullptr; pl->sep_cols = nullptr;
     }
@@ -850,6 +877,7 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->saved_r);
     (void)hipFree(plan->ltable);
     (void)hipFree(plan->P_dev);
+    (void)hipFree(plan->bil_tiles);
     delete plan;
 }
 
@@ -955,8 +983,34 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         return pb_fail(PB_ERR_INVALID, "src_frame_stride smaller than a frame");
     hipStream_t st = (hipStream_t)stream;
     if (P.src.kind == PB_KIND_DOUBLE) {
-        hipLaunchKernelGGL(pb_bilinear_double_kernel, dim3(pb_blocks(npx)), dim3(PB_BLOCK), 0, st, P, src_dev, dst_dev, n_frames, src_frame_stride,
-                           dst_frame_stride);
+        if (plan->dbl_ready && plan->ltable && plan->launch_groups > 0 && plan->bil_tiles && plan->mode != PB_MODE_FAITHFUL) {
+            // the per-eye tile models of the nearest mode's plan: one wave per tile, then the failed tiles / fix pixels in float64
+            const unsigned gpf = plan->launch_groups;
+            const int windows = plan->mode != PB_MODE_FAST_DIRECT && ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
+            const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
+            const int per_launch = (int)(0x7FFFFFFFu / gpf);
+            for (int f0 = 0; f0 < n_frames; f0 += per_launch) {
+                const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;
+                const dim3 grid(gpf * (unsigned)nf), block(64 * PB_TILE_WAVES);
+                const uint8_t* sf = src_dev + (unsigned long long)f0 * src_frame_stride;
+                uint8_t* df = dst_dev + (unsigned long long)f0 * dst_frame_stride;
+#define PB_LAUNCH_BILINEAR_DOUBLE(WMODE)                                                                                                       \
+    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, pb_window_lds_bytes(P, 8), st, P, plan->table, plan->table_r, plan->ltable, rows, \
+                       plan->lat_tab, sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows)
+                if (rows) PB_LAUNCH_BILINEAR_DOUBLE(1);
+                else if (plan->n_lat_tiles) PB_LAUNCH_BILINEAR_DOUBLE(2);
+                else PB_LAUNCH_BILINEAR_DOUBLE(0);
+#undef PB_LAUNCH_BILINEAR_DOUBLE
+            }
+            const unsigned n_tiles64 = plan->n_fail_tiles + plan->n_bil_tiles;
+            const unsigned fix_blocks = 4u * n_tiles64 + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
+            if (fix_blocks)
+                hipLaunchKernelGGL(pb_bilinear_double_fix_kernel, dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, plan->fail_tiles, (int)plan->n_fail_tiles, plan->bil_tiles,
+                                   (int)n_tiles64, plan->fix_px, (int)plan->n_fix_px, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
+        } else {
+            hipLaunchKernelGGL(pb_bilinear_double_kernel, dim3(pb_blocks(npx)), dim3(PB_BLOCK), 0, st, P, src_dev, dst_dev, n_frames, src_frame_stride,
+                               dst_frame_stride);
+        }
         PB_HIP(hipGetLastError());
         return PB_OK;
     }
@@ -1382,6 +1436,10 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
     if (hipMalloc((void**)&pl->P_dev, sizeof(PbParams)) != hipSuccess || hipMemcpy(pl->P_dev, &pl->P, sizeof(PbParams), hipMemcpyHostToDevice) != hipSuccess) {
         pb_plan_destroy(pl);
         return pb_fail(PB_ERR_HIP, "plan upload failed: parameter block");
+    }
+    if (pl->dbl_ready && pb_build_bilinear_list(pl) != PB_OK) {
+        pb_plan_destroy(pl);
+        return PB_ERR_HIP;
     }
     rc = pb_build_launch_table(pl);  // derived state: rebuilt, not stored
     if (rc != PB_OK) {

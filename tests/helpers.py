@@ -82,8 +82,12 @@ def pb_chain(case: Case, image=None):
 def pb_plan(case: Case):
     from photonbend_amd.core.projection import _plan_for
 
+    from photonbend_amd import _native as nat
+
     src, cmap = pb_chain(case, image=np.zeros((case.src[1], case.src[2], 3), np.uint8))
-    return _plan_for(cmap.dst_proj, cmap.rotations, src._proj())
+    plan = _plan_for(cmap.dst_proj, cmap.rotations, src._proj())
+    plan.set_mode(nat.MODE_AUTO)  # the facade's cache entry is shared: an earlier test of the same geometry may have left its mode
+    return plan
 
 
 def pb_plan_private(case: Case, **kw):
