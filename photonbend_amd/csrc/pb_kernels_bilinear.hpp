@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(con
         }
         return;
     }
-    if (flags & (PB_TILE_LEAN | PB_TILE_DIRECT)) {
+    if ((flags & (PB_TILE_LEAN | PB_TILE_DIRECT)) && !(flags & PB_TILE_MASKED)) {  // (MASKED: invalid pixels inside - the guarded path below)
         // the four taps straight from the frame, unguarded (the tile's bounding box, margin texel included, lies inside
         // the frame with room for the last 4-byte read).  wide: an 8-byte load takes both taps of a row - allowed when
         // even the box's last tap has 8 bytes of frame behind it; one row group's loads are in flight together

@@ -285,6 +285,21 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
         const float num = along_x ? e->c[1][0] : e->c[5][0], den = along_x ? e->c[5][0] : e->c[1][0];
         const float slope = (den != 0.0f) ? -num / den : 0.0f;
         const int shift = (int)rintf(slope * ((float)p - 15.5f));
+        // MASKED tiles: bit n of `dead` = pixel n of this lane is an invalid destination pixel (exact integer test, as pb_model_row's)
+        unsigned dead = 0u;
+        if (flags & PB_TILE_MASKED) {
+            const int side = (P.dst.kind == PB_KIND_DOUBLE) && (X0 >= P.dst_half_w);
+            const int wc = (P.dst.kind == PB_KIND_DOUBLE) ? P.dst_half_w : P.dst.width;
+            const long long lo = P.inv_lo[side], hi = P.inv_hi[side];
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int q = (2 * n + hh + shift) & 31;
+                const int px = along_x ? p : q, py = along_x ? q : p;
+                const long long x2 = 2ll * (X0 + px - (side ? P.dst_half_w : 0)) - (wc - 1), y2 = (long long)(P.dst.height - 1) - 2ll * (Y0 + py);
+                const long long n4 = x2 * x2 + y2 * y2;
+                dead |= (unsigned)(n4 >= lo && n4 < hi) << n;
+            }
+        }
         unsigned go[16];
         if (along_x) {
             // column-first evaluation (one collapse per lane instead of one per pixel; certified by pb_certify_kernel
@@ -313,6 +328,12 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             if (PB_ABL_NO_LOAD) {
 #pragma unroll
                 for (int n = 0; n < 16; ++n) t[n] = go[n];
+            } else if (flags & PB_TILE_MASKED) {
+#pragma unroll
+                for (int n = 0; n < 16; ++n) {
+                    t[n] = 0u;
+                    if (!((dead >> n) & 1u)) __builtin_memcpy(&t[n], s + go[n], 4);
+                }
             } else {
 #pragma unroll
                 for (int n = 0; n < 16; ++n) __builtin_memcpy(&t[n], s + go[n], 4);
@@ -928,14 +949,15 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_window_kernel(const PbP
     pb_model_row(P, e, X0, Y0, y, xh, R);
     int rmin = 0x7fffffff, rmax = -0x7fffffff, cmin = 0x7fffffff, cmax = -0x7fffffff;   // raw (unwrapped)
     int wrmin = 0x7fffffff, wrmax = -1, wcmin = 0x7fffffff, wcmax = -1;               // as the generic path uses them
-    int not_plain = 0;  // pixels outside the image, invalid, black or wrapping
+    int not_plain = 0;  // pixels outside the image, black or wrapping
+    int n_invalid = 0;  // invalid destination pixels (inside the image)
     for (int k = 0; k < 16; ++k) {
         const int j = X0 + xh + k;
         if (i >= P.dst.height || j >= P.dst.width) { ++not_plain; continue; }
         int r, c;
         pb_f2 f;
         pb_model_px_raw(R, xh, k, r, c, f);
-        if (pb_row_px_invalid(R, k)) { ++not_plain; continue; }
+        if (pb_row_px_invalid(R, k)) { ++n_invalid; continue; }
         rmin = min(rmin, r); rmax = max(rmax, r);
         cmin = min(cmin, c); cmax = max(cmax, c);
         const int v = pb_model_px_rc<SRC_KIND>(P, R, xh, k);
@@ -948,6 +970,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_window_kernel(const PbP
     rmin = pb_wave_min(rmin); rmax = pb_wave_max(rmax); cmin = pb_wave_min(cmin); cmax = pb_wave_max(cmax);
     wrmin = pb_wave_min(wrmin); wrmax = pb_wave_max(wrmax); wcmin = pb_wave_min(wcmin); wcmax = pb_wave_max(wcmax);
     not_plain = pb_wave_sum(not_plain);
+    n_invalid = pb_wave_sum(n_invalid);
     if (lane != 0) return;
     if (wrmax < 0) {  // no pixel of the tile samples the source
         e->win_r0 = e->win_rows = e->win_c0 = e->win_cols = 0;
@@ -963,7 +986,21 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_window_kernel(const PbP
     const unsigned rowbytes = 3u * (unsigned)w;
     const unsigned safe_len = (rowbytes * (unsigned)h) & ~15u;
     if (not_plain != 0 || w >= 32768 || h >= 32768) return;
-    const int lr0 = rmin - 1, lc0 = cmin - 1, rows = rmax - rmin + 3, cols = cmax - cmin + 3;
+    // invalid destination pixels only (the rest plain): the MASKED class, single sources only (the two-eye paths do not know it)
+    const bool masked = n_invalid != 0;
+    if (masked && SRC_KIND != PB_KIND_PANO && SRC_KIND != PB_KIND_CAMERA) return;
+    int lr0 = rmin - 1, lc0 = cmin - 1, rows = rmax - rmin + 3, cols = cmax - cmin + 3;
+    if (masked) {
+        // a ring tile's valid pixels reach the LAST rows / columns of the source (a fisheye's rim is the panorama's pole row): the
+        // margin texel is clipped at the frame's edge.  Safe: certification checks for every sampled pixel, in both evaluation
+        // orders, that its window offsets lie inside [0, rows) x [0, cols) - no gather can leave the frame - and MASKED tiles never
+        // take the LDS-window or the unguarded bilinear paths, the margin's other customers
+        const int r1 = min(rmax + 1, h - 1), c1 = min(cmax + 1, w - 1);
+        lr0 = max(lr0, 0);
+        lc0 = max(lc0, 0);
+        rows = r1 - lr0 + 1;
+        cols = c1 - lc0 + 1;
+    }
     // (an eye's margin texel may lie in the other eye's half: inside the frame, never sampled)
     if (lr0 < 0 || lc0 < 0 || lr0 + rows > h || lc0 + cols > w) return;
     // the last sample's 4-byte read must stay inside the frame
@@ -984,7 +1021,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_window_kernel(const PbP
     e->win_cols = cols;
     e->win_n16 = (int)n16;
     e->win_a0 = (int)a0;
-    e->flags |= stageable ? PB_TILE_LEAN : PB_TILE_DIRECT;
+    e->flags |= masked ? (PB_TILE_DIRECT | PB_TILE_MASKED) : (stageable ? PB_TILE_LEAN : PB_TILE_DIRECT);
 }
 
 // One wave per tile: compares the hot path's index with the faithful one for every pixel of the
@@ -1018,7 +1055,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const Pb
                 const int fast = pb_model_px<SRC_KIND>(P, R, xh, k);
                 const int exact = pb_exact_index<SRC_KIND>(P, i, j);
                 diff |= (unsigned)(fast != exact) << k;
-                if (lean) {
+                if (lean && !pb_row_px_invalid(R, k)) {  // (a MASKED tile's invalid pixels are never sampled: the hot path masks them)
                     const pb_f2 f = pb_eval_row(R.a, pb_tile_coord(xh + k));
                     lean_ok = lean_ok && f.x >= 0.0f && f.y >= 0.0f && (int)f.x < e->win_rows && (int)f.y < e->win_cols;
                     // plain tiles may also be evaluated column-first by the hot kernel (a DIRECT tile whose gathers run

@@ -36,6 +36,12 @@
 #define PB_TILE_BLACK 8  // every pixel of the tile (inside the image) is black: the hot kernel only stores zeros
 #define PB_TILE_SKIP 32  // launch-order table only: an empty wave slot (beyond the image)
 #define PB_TILE_SOLO 512  // launch-order table of a double-fisheye plan only: the tile sees ONE eye, the entry is that eye's (flags: its LEAN / DIRECT / BLACK)
+// MASKED (with DIRECT; single sources): plain except that some of its pixels are INVALID destination pixels - the ring of tiles along
+// the edge of a fisheye destination's image circle.  The model runs over the whole tile (the coordinate field continues smoothly
+// past the validity boundary), the direct-gather path skips the loads of the invalid pixels (exact integer test) and paints them
+// black.  Without the class these tiles take the generic path, three times as slow, and a single launch ENDS on them (c2: 586 tiles,
+// 3.8 us of a 41.5 us launch - experiments/session_r3_k.sh).
+#define PB_TILE_MASKED 1024
 #define PB_TILE_EYE_R 2048  // launch-order table of a double-fisheye plan only: a SOLO entry that is the RIGHT eye's (the bilinear mode clamps taps to the eye)
 #define PB_TILE_W_UNIT_BIT 64  // == PB_TILE_W_UNIT (pb_kernels_double.hpp): blend factors exactly 1.0 for every pixel of the tile
 #define PB_LEAN_MAX_PASSES 24  // window rows / rows-per-load-instruction of a LEAN tile (register staging depth)
