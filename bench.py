@@ -390,6 +390,31 @@ def headline_extras(lib, nat, d, rots, s, cfg, device, stream, budget):
 
 
 
+def graph_replay_ms(lib, nat, plan, srcs, dsts, sbytes, dbytes, n_pool, device, launches=8, replays=25):
+    """`launches` single-frame launches of the headline config captured into ONE hipGraph and replayed -
+    ms per frame over `replays` replays (distinct frames of the pool inside a graph; the same graph replayed)."""
+    import torch
+
+    side = torch.cuda.Stream(device=device)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            st = int(torch.cuda.current_stream(device).cuda_stream)
+            for k in range(launches):
+                i = k % n_pool
+                nat.check(lib.pb_remap_u8(plan.handle, srcs.data_ptr() + i * sbytes, dsts.data_ptr() + i * dbytes, 1, sbytes, dbytes, st))
+        for _ in range(3):
+            g.replay()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(replays):
+            g.replay()
+        e1.record(side)
+        side.synchronize()
+    return e0.elapsed_time(e1) / (replays * launches)
+
+
 def copy_ceiling_gbs(lib, nat, device, stream) -> float:
     """A plain 16-byte-per-lane device copy of 512 MiB (beyond the 256 MiB Infinity Cache), read + write bytes per second."""
     import torch
@@ -637,6 +662,12 @@ def main():
         line["collective_backend"] = (dist.get_backend() if dist.is_initialized() else None)
         if world == 1 and not bilinear and not args.no_configs and args.config == "c2":
             # the other BASELINE configs, same process, same box, seconds: one driver-run line shows every kernel
+            try:
+                line["graph_replay_ms_per_frame"] = round(graph_replay_ms(lib, nat, plan, srcs, dsts, sbytes, dbytes, pool, device), 5)
+                line["graph_replay_note"] = "8 single-frame launches captured into one hipGraph, replayed 25 times (same kernels, same frames of the pool): launch boundaries inside a graph cost what eager launches cost"
+            except Exception as exc:  # a measurement extra: never fail the line over it
+                line["graph_replay_ms_per_frame"] = None
+                line["graph_replay_note"] = repr(exc)
             del srcs, dsts
             torch.cuda.empty_cache()
             single_ms, faithful_ms = headline_extras(lib, nat, d, rots, s, cfg, device, sts[0], budget)
