@@ -186,6 +186,30 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
  * (projection.py:439-457). */
 int pb_index_map_i32(const pb_plan* plan, int32_t* idx_dev, double* weights_dev, void* stream);
 
+/* ---- multi-GPU: one process per GPU (SURVEY 8 e; ABI 3) ------------------------------------------------------------------
+ * Frames are independent: a batch shards contiguously over the ranks and no pixel crosses a link.  The ONE data-path collective
+ * is the RCCL broadcast (ncclBroadcast over xGMI inside a node) of the parameter block - both projections with the host-side
+ * f_distance bits, the rotation matrices - from the root rank, so every device computes with identical bits; each rank then
+ * creates its own plan (pb_plan_create on its device).  The reference has no counterpart (single process, no collective);
+ * these entry points are what a non-Python host binds where the Python package uses torch.distributed
+ * (photonbend_amd/parallel.py: same block layout).  librccl.so.1 is loaded at first use; PB_ERR_UNSUPPORTED without it.
+ *   pb_comm_unique_id   rank 0 makes the 128-byte rendezvous id (ncclGetUniqueId); the launcher hands it to the other ranks
+ *   pb_comm_init        collective: every rank, on ITS current device (ncclCommInitRank)
+ *   pb_bcast_params     collective: root's dst / rot3x3[9 * n_rot] / n_rot / src overwrite everyone else's (rot3x3 must hold
+ *                       9 * PB_MAX_ROTATIONS doubles); synchronises `stream`
+ *   pb_shard_range      first = rank * q + min(rank, r), count = q + (rank < r)  (q, r = divmod(n_items, n_ranks))
+ *   pb_remap_batch_sharded  remaps THIS rank's share of a batch of n_frames_total frames: its count frames, resident in its own
+ *                       buffers from src_dev / dst_dev on (frame k of the share = batch frame first + k); one pb_remap_u8 */
+typedef struct pb_comm pb_comm;
+int pb_comm_unique_id(void* id128);
+int pb_comm_init(int n_ranks, int rank, const void* id128, pb_comm** out);
+int pb_comm_destroy(pb_comm* comm);
+int pb_comm_rank(const pb_comm* comm, int* n_ranks, int* rank);
+int pb_bcast_params(pb_comm* comm, pb_proj* dst, double* rot3x3, int* n_rot, pb_proj* src, int root, void* stream);
+int pb_shard_range(int n_items, int n_ranks, int rank, int* first, int* count);
+int pb_remap_batch_sharded(const pb_comm* comm, const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames_total,
+                           size_t src_frame_stride, size_t dst_frame_stride, int* first_out, int* count_out, void* stream);
+
 /* ---- materialised coordinate-map API (protocol compatibility) --------- */
 int pb_coordmap_f64(const pb_proj* dst, double* map_dev, void* stream);
 /* Zeroes lat/lon of invalid pixels IN map_in_dev (rotation.py:119-125), like the

@@ -100,6 +100,13 @@ SIGNATURES = {
     "pb_event_sync": (C.c_int, [_VP]),
     "pb_event_elapsed_ms": (C.c_int, [_VP, _VP, C.POINTER(C.c_float)]),
     "pb_stream_copy": (C.c_int, [_VP, _VP, C.c_size_t, _VP]),
+    "pb_comm_unique_id": (C.c_int, [_VP]),
+    "pb_comm_init": (C.c_int, [C.c_int, C.c_int, _VP, C.POINTER(_VP)]),
+    "pb_comm_destroy": (C.c_int, [_VP]),
+    "pb_comm_rank": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pb_bcast_params": (C.c_int, [_VP, C.POINTER(pb_proj), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(pb_proj), C.c_int, _VP]),
+    "pb_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pb_remap_batch_sharded": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]),
 }
 
 _lib = None

@@ -1483,6 +1483,167 @@ int pb_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* strea
     return PB_OK;
 }
 
+// ---- multi-GPU: one process per GPU, frames sharded, ONE collective (SURVEY 8 e) -----------------------------------------
+// RCCL (librccl.so.1; "nccl" on ROCm, over xGMI inside a node) is bound at first use with dlopen - the remap library itself has
+// no link-time dependency on it, and a host that brings its own communicator layer (torch.distributed in the Python package)
+// never touches these entry points.  The only data-path collective is the broadcast of the parameter block.
+}  // extern "C"
+#include <dlfcn.h>
+namespace {
+struct PbNcclId {
+    char internal[128];
+};
+typedef int (*pb_nccl_get_id_t)(PbNcclId*);
+typedef int (*pb_nccl_init_t)(void**, int, PbNcclId, int);
+typedef int (*pb_nccl_destroy_t)(void*);
+typedef int (*pb_nccl_bcast_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*pb_nccl_err_t)(int);
+struct PbRccl {
+    void* lib = nullptr;
+    pb_nccl_get_id_t get_id = nullptr;
+    pb_nccl_init_t init = nullptr;
+    pb_nccl_destroy_t destroy = nullptr;
+    pb_nccl_bcast_t bcast = nullptr;
+    pb_nccl_err_t err = nullptr;
+};
+PbRccl* pb_rccl() {
+    static PbRccl r = [] {
+        PbRccl q;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            q.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (q.lib) break;
+        }
+        if (q.lib) {
+            q.get_id = (pb_nccl_get_id_t)dlsym(q.lib, "ncclGetUniqueId");
+            q.init = (pb_nccl_init_t)dlsym(q.lib, "ncclCommInitRank");
+            q.destroy = (pb_nccl_destroy_t)dlsym(q.lib, "ncclCommDestroy");
+            q.bcast = (pb_nccl_bcast_t)dlsym(q.lib, "ncclBroadcast");
+            q.err = (pb_nccl_err_t)dlsym(q.lib, "ncclGetErrorString");
+        }
+        return q;
+    }();
+    return (r.lib && r.get_id && r.init && r.destroy && r.bcast) ? &r : nullptr;
+}
+int pb_nccl_fail(const PbRccl* r, const char* what, int code) {
+    return pb_fail(PB_ERR_HIP, std::string(what) + ": " + ((r && r->err) ? r->err(code) : "RCCL error"));
+}
+const int PB_BLOCK_DOUBLES = 2 + 2 * 7 + 9 * PB_MAX_ROTATIONS;  // the parameter block: photonbend_amd/parallel.py's layout
+}  // namespace
+
+struct pb_comm {
+    void* comm = nullptr;
+    int n_ranks = 1, rank = 0, device = -1;
+    double* block_dev = nullptr;
+};
+
+extern "C" {
+
+int pb_comm_unique_id(void* id128) {
+    if (!id128) return pb_fail(PB_ERR_INVALID, "null argument");
+    PbRccl* r = pb_rccl();
+    if (!r) return pb_fail(PB_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
+    const int rc = r->get_id(static_cast<PbNcclId*>(id128));
+    return rc == 0 ? PB_OK : pb_nccl_fail(r, "ncclGetUniqueId", rc);
+}
+
+int pb_comm_init(int n_ranks, int rank, const void* id128, pb_comm** out) {
+    if (!out || !id128) return pb_fail(PB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return pb_fail(PB_ERR_INVALID, "rank outside [0, n_ranks)");
+    PbRccl* r = pb_rccl();
+    if (!r) return pb_fail(PB_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
+    pb_comm* c = new (std::nothrow) pb_comm();
+    if (!c) return pb_fail(PB_ERR_INVALID, "out of host memory");
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    if (hipGetDevice(&c->device) != hipSuccess || hipMalloc((void**)&c->block_dev, PB_BLOCK_DOUBLES * sizeof(double)) != hipSuccess) {
+        delete c;
+        return pb_fail(PB_ERR_HIP, "pb_comm_init: no device memory for the parameter block");
+    }
+    PbNcclId id;
+    memcpy(&id, id128, sizeof(id));
+    const int rc = r->init(&c->comm, n_ranks, id, rank);  // one communicator per process, on the current device
+    if (rc != 0) {
+        (void)hipFree(c->block_dev);
+        delete c;
+        return pb_nccl_fail(r, "ncclCommInitRank", rc);
+    }
+    *out = c;
+    return PB_OK;
+}
+
+int pb_comm_destroy(pb_comm* comm) {
+    if (!comm) return PB_OK;
+    PbRccl* r = pb_rccl();
+    if (r && comm->comm) (void)r->destroy(comm->comm);
+    (void)hipFree(comm->block_dev);
+    delete comm;
+    return PB_OK;
+}
+
+int pb_comm_rank(const pb_comm* comm, int* n_ranks, int* rank) {
+    if (!comm) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (n_ranks) *n_ranks = comm->n_ranks;
+    if (rank) *rank = comm->rank;
+    return PB_OK;
+}
+
+int pb_bcast_params(pb_comm* comm, pb_proj* dst, double* rot3x3, int* n_rot, pb_proj* src, int root, void* stream) {
+    if (!comm || !dst || !src || !n_rot || !rot3x3) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (root < 0 || root >= comm->n_ranks) return pb_fail(PB_ERR_INVALID, "root outside [0, n_ranks)");
+    PbRccl* r = pb_rccl();
+    if (!r) return pb_fail(PB_ERR_UNSUPPORTED, "librccl.so.1 could not be loaded");
+    hipStream_t st = (hipStream_t)stream;
+    double block[PB_BLOCK_DOUBLES];
+    memset(block, 0, sizeof(block));
+    auto put = [](double* b, const pb_proj& p) { b[0] = p.kind; b[1] = p.lens; b[2] = p.height; b[3] = p.width; b[4] = p.fov; b[5] = p.magnitude; b[6] = p.f_distance; };
+    auto get = [](const double* b, pb_proj& p) { p.kind = (int32_t)b[0]; p.lens = (int32_t)b[1]; p.height = (int32_t)b[2]; p.width = (int32_t)b[3]; p.fov = b[4]; p.magnitude = b[5]; p.f_distance = b[6]; };
+    if (comm->rank == root) {
+        if (*n_rot < 0 || *n_rot > PB_MAX_ROTATIONS) return pb_fail(PB_ERR_INVALID, "n_rot outside [0, PB_MAX_ROTATIONS]");
+        block[0] = 1346522692.0;  // "PBND": the Python package's magic (photonbend_amd/parallel.py), same layout
+        block[1] = *n_rot;
+        put(block + 2, *dst);
+        put(block + 9, *src);
+        for (int k = 0; k < 9 * *n_rot; ++k) block[16 + k] = rot3x3[k];
+        PB_HIP(hipMemcpyAsync(comm->block_dev, block, sizeof(block), hipMemcpyHostToDevice, st));
+    }
+    const int rc = r->bcast(comm->block_dev, comm->block_dev, PB_BLOCK_DOUBLES, 8 /* ncclFloat64 */, root, comm->comm, st);
+    if (rc != 0) return pb_nccl_fail(r, "ncclBroadcast", rc);
+    PB_HIP(hipMemcpyAsync(block, comm->block_dev, sizeof(block), hipMemcpyDeviceToHost, st));
+    PB_HIP(hipStreamSynchronize(st));
+    if (block[0] != 1346522692.0 || !(block[1] >= 0 && block[1] <= PB_MAX_ROTATIONS)) return pb_fail(PB_ERR_INVALID, "corrupt parameter block");
+    *n_rot = (int)block[1];
+    get(block + 2, *dst);
+    get(block + 9, *src);
+    for (int k = 0; k < 9 * *n_rot; ++k) rot3x3[k] = block[16 + k];
+    return PB_OK;
+}
+
+int pb_shard_range(int n_items, int n_ranks, int rank, int* first, int* count) {
+    if (!first || !count) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || n_items < 0) return pb_fail(PB_ERR_INVALID, "bad shard request");
+    const int q = n_items / n_ranks, r = n_items % n_ranks;
+    *first = rank * q + (rank < r ? rank : r);
+    *count = q + (rank < r ? 1 : 0);
+    return PB_OK;
+}
+
+int pb_remap_batch_sharded(const pb_comm* comm, const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames_total,
+                           size_t src_frame_stride, size_t dst_frame_stride, int* first_out, int* count_out, void* stream) {
+    if (!comm || !plan || !src_dev || !dst_dev) return pb_fail(PB_ERR_INVALID, "null argument");
+    int first = 0, count = 0;
+    const int rc = pb_shard_range(n_frames_total, comm->n_ranks, comm->rank, &first, &count);
+    if (rc != PB_OK) return rc;
+    if (first_out) *first_out = first;
+    if (count_out) *count_out = count;
+    if (count == 0) return PB_OK;
+    const PbParams& P = plan->P;
+    if (!src_frame_stride) src_frame_stride = 3ull * P.src.height * P.src.width;
+    if (!dst_frame_stride) dst_frame_stride = 3ull * P.dst.height * P.dst.width;
+    // this rank's contiguous share of the batch, addressed in the caller's (rank-local) buffers from frame 0 on
+    return pb_remap_u8(plan, src_dev, dst_dev, count, src_frame_stride, dst_frame_stride, stream);
+}
+
 // ---- plumbing ----------------------------------------------------------------------
 int pb_malloc(void** dev_ptr, size_t bytes) {
     if (!dev_ptr) return pb_fail(PB_ERR_INVALID, "null argument");

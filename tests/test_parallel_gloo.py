@@ -180,3 +180,63 @@ def test_rccl_broadcast_of_the_parameter_block_on_one_gpu():
     p.join(timeout=120)
     assert p.exitcode == 0
     assert backend == "nccl" and world == 1 and bits_ok and red == 3.25 and same and fast
+
+
+# ---- the C ABI's own multi-GPU entry points (pb_comm_*, SURVEY 8 b) ---------------------------------------------------------
+@pytest.mark.parametrize("n,world", [(0, 1), (1, 8), (7, 8), (8, 8), (512, 8), (256, 8), (13, 5)])
+def test_c_shard_range_equals_the_python_one(n, world):
+    import ctypes
+
+    lib = nat.load()
+    first, count = ctypes.c_int(), ctypes.c_int()
+    for r in range(world):
+        assert lib.pb_shard_range(n, world, r, ctypes.byref(first), ctypes.byref(count)) == 0
+        assert list(range(first.value, first.value + count.value)) == list(parallel.shard_range(n, world, r))
+    assert lib.pb_shard_range(4, 2, 2, ctypes.byref(first), ctypes.byref(count)) == -1
+
+
+def _c_comm_worker(q):
+    import ctypes
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    lib = nat.load()
+    uid = ctypes.create_string_buffer(128)
+    nat.check(lib.pb_comm_unique_id(uid))
+    comm = ctypes.c_void_p()
+    nat.check(lib.pb_comm_init(1, 0, uid, ctypes.byref(comm)))
+    d, rots, s = _two_rank_projs()
+    d2, s2 = nat.pb_proj.from_buffer_copy(d), nat.pb_proj.from_buffer_copy(s)
+    rot = (ctypes.c_double * (9 * nat.PB_MAX_ROTATIONS))()
+    for k, v in enumerate(np.asarray(rots, dtype=np.float64).ravel()):
+        rot[k] = v
+    n_rot = ctypes.c_int(len(rots))
+    nat.check(lib.pb_bcast_params(comm, ctypes.byref(d2), rot, ctypes.byref(n_rot), ctypes.byref(s2), 0, None))
+    same = d2.key() == d.key() and s2.key() == s.key() and n_rot.value == len(rots) and np.array_equal(
+        np.frombuffer(rot, dtype=np.float64)[: 9 * len(rots)].view(np.uint64), np.asarray(rots, dtype=np.float64).ravel().view(np.uint64))
+    plan = nat.Plan(d2, [np.frombuffer(rot, dtype=np.float64)[9 * k : 9 * k + 9].reshape(3, 3).copy() for k in range(n_rot.value)], s2)
+    frames = torch.stack([nat.synth_frame(256, 512, frame=i, seed=0) for i in range(5)])
+    out = torch.zeros((5, d.height, d.width, 3), dtype=torch.uint8, device="cuda")
+    first, count = ctypes.c_int(-1), ctypes.c_int(-1)
+    nat.check(lib.pb_remap_batch_sharded(comm, plan.handle, frames.data_ptr(), out.data_ptr(), 5, 0, 0, ctypes.byref(first), ctypes.byref(count), nat.current_stream()))
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(out, plan.remap(frames)))
+    n, r = ctypes.c_int(), ctypes.c_int()
+    nat.check(lib.pb_comm_rank(comm, ctypes.byref(n), ctypes.byref(r)))
+    nat.check(lib.pb_comm_destroy(comm))
+    q.put((same, ok, first.value, count.value, n.value, r.value))
+
+
+@pytest.mark.gpu
+def test_c_abi_comm_broadcast_and_sharded_remap_on_one_gpu():
+    """pb_comm_unique_id / pb_comm_init / pb_bcast_params / pb_remap_batch_sharded through ctypes, a communicator of ONE rank:
+    librccl is bound with dlopen, the block travels through ncclBroadcast on the device and comes back bit for bit, the
+    rank's share (all 5 frames) equals a plain batch launch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_c_comm_worker, args=(q,))
+    p.start()
+    same, ok, first, count, n, r = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert same and ok and (first, count, n, r) == (0, 5, 1, 0)
