@@ -301,6 +301,12 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
             }
         }
         unsigned go[16];
+#ifdef PB_ABLATION  // VALU sensitivity of the direct-gather path (wrong pixels): PB_EXP bit 2 = no polynomial, addresses from the lane id
+        if (P.exp_flags & 2) {
+#pragma unroll
+            for (int n = 0; n < 16; ++n) go[n] = gbase + ((unsigned)((2 * n + hh) & 31) % (unsigned)e->win_rows) * rowbytes + 3u * ((unsigned)p % (unsigned)e->win_cols);  // inside the tile's own box
+        } else
+#endif
         if (along_x) {
             // column-first evaluation (one collapse per lane instead of one per pixel; certified by pb_certify_kernel
             // alongside the row-first order)
@@ -320,6 +326,18 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
                 go[n] = gbase + (unsigned)(int)fv.x * rowbytes + __umul24((unsigned)(int)fv.y, 3u);
             }
         }
+#ifdef PB_ABLATION  // VALU sensitivity, same addresses: PB_EXP bit 1 = the whole model arithmetic a second time (results kept alive, unused)
+        if (P.exp_flags & 1) {
+            pb_f2 a2[5];
+            pb_collapse_row(e, p ^ 1, a2);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const pb_f2 fv = pb_eval_row(a2, pb_tile_coord((2 * n + hh + shift + 1) & 31));
+                const unsigned g2 = gbase + (unsigned)(int)fv.x * rowbytes + __umul24((unsigned)(int)fv.y, 3u);
+                asm volatile("" ::"v"(g2));
+            }
+        }
+#endif
         PB_TR(2);
         for (int f = 0; f < n_frames; ++f) {
             const uint8_t* s = src + (unsigned long long)f * src_stride;
