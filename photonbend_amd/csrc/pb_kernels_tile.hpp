@@ -251,6 +251,15 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
 #define PB_ABL_NO_STORE(v) false
 #define PB_ABL_NO_LOAD false
 #endif
+    // where the lane's 12-byte groups go: 4 pixels at (st_x, st_y0 + st_dy * jr), jr = 0..3
+    int st_x = x, st_y0 = Y0 + yb, st_dy = 8;
+#ifdef PB_ABLATION  // PB_EXP bit 1024: the stores of a 64 x 16 tile shape (whole 192-byte row pieces per instruction; pixels land in the wrong places)
+    if (P.exp_flags & 1024) {
+        st_x = 64 * (tx >> 1) + 4 * (lane & 15);
+        st_y0 = Y0 + 16 * (tx & 1) + (lane >> 4);
+        st_dy = 4;
+    }
+#endif
     if (flags & PB_TILE_BLACK) {
         for (int f = 0; f < n_frames; ++f) {
             uint8_t* d = dst + (unsigned long long)f * dst_stride;
@@ -371,7 +380,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
 #pragma unroll
             for (int jr = 0; jr < 4; ++jr) {
                 const unsigned* r = win + (yb + 8 * jr) * 33 + 4 * xg;
-                const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
+                const unsigned long long off = 3ull * ((unsigned long long)(st_y0 + st_dy * jr) * W + st_x);
                 if (PB_ABL_NO_STORE(r[0])) continue;
                 if ((((uintptr_t)d + off) & 3u) == 0) {
                     pb_store3<NT>(pb_pack_px4(r[0], r[1], r[2], r[3]), d + off);
@@ -443,7 +452,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
                     a[k] = __builtin_amdgcn_alignbyte(win[(l >> 2) + 1], win[l >> 2], l);
                 }
                 // LEAN tiles lie fully inside the image; the 12-byte store is 4-byte aligned when the base is
-                const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
+                const unsigned long long off = 3ull * ((unsigned long long)(st_y0 + st_dy * jr) * W + st_x);
                 if (PB_ABL_NO_STORE(a[0])) continue;
                 if ((((uintptr_t)d + off) & 3u) == 0) {
                     pb_store3<NT>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);
