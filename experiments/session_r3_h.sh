@@ -11,7 +11,7 @@ for f in ('bench_default','bench_rccl'):
     try:
         j=json.loads(open(f'gpurun_out/r3h/{f}.json').read().strip().splitlines()[-1])
         print(f, j['value'], j['ms_per_step'], j['roofline']['frac'], j.get('ranks_seen'), j.get('collective_backend'), j.get('single_image_ms'), j.get('faithful_kernel_ms'))
-        for k,v in j.get('configs',{}).items(): print('  ',k, v['kernel_ms_per_frame'], v['frac'], v['attainable_frac'], v['tiles'])
+        for k,v in j.get("configs",{}).items(): print("  ",k, v["kernel_ms_per_frame"], v.get("frac"), v.get("plan_create_warm_ms"))
         if 'cpu_baseline' in j: print('  cpu', j['cpu_baseline']['value'])
     except Exception as e: print(f, 'ERR', e)
 PY

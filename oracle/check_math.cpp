@@ -1,7 +1,9 @@
 // check_math.cpp - TEST INFRASTRUCTURE (oracle/): the device math of photonbend_amd/csrc/pb_math.hpp compiled for the HOST and
 // compared, bit for bit, with this machine's glibc (what the reference reaches through NumPy: SURVEY 2) and with the
 // correctly rounded value (libquadmath, 113-bit).  Prints one line per function: arguments, mismatches against glibc,
-// mismatches against correct rounding, glibc's own mismatches against correct rounding.
+// mismatches against correct rounding, glibc's own mismatches against correct rounding - and, for the two-step (Ziv) evaluation,
+// how often the fast path left the rounding undecided and the largest relative error the fast path showed (its decision
+// threshold PB_FAST_REL must stay well above that).
 //   g++ -O2 -ffp-contract=off -mfma -o oracle/_ref/check_math oracle/check_math.cpp -lquadmath && oracle/_ref/check_math [n]
 #include <quadmath.h>
 
@@ -11,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#define PB_MATH_COUNT
 #include "../photonbend_amd/csrc/pb_math.hpp"
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
@@ -27,6 +30,7 @@ int main(int argc, char** argv) {
     const long n = argc > 1 ? atol(argv[1]) : 2000000;
     const double pi = 3.141592653589793;
     long bad_g = 0, bad_q = 0, g_q = 0;
+    double max_rel = 0.0;
     // ---- sine / cosine: longitudes in [-pi, pi], latitudes in [0, pi], lens arguments (halves, 0.713 x), small values
     for (long i = 0; i < n; ++i) {
         double x;
@@ -38,6 +42,17 @@ int main(int argc, char** argv) {
         }
         double s, c;
         pb_sincos_cr(x, &s, &c);
+        if (fabs(x) >= 0x1p-27) {  // the fast path's own error
+            double kd;
+            const pb_dd r = pb_reduce_pio2(x, kd);
+            pb_dd S, C, fs, fc;
+            pb_sincos_fast_reduced(r, S, C);
+            pb_quadrant((long long)kd, S, C, fs, fc);
+            const __float128 ts = sinq((__float128)x), tc = cosq((__float128)x);
+            const double es = (double)fabsq((((__float128)fs.h + fs.l) - ts) / ts), ec = (double)fabsq((((__float128)fc.h + fc.l) - tc) / tc);
+            if (es > max_rel) max_rel = es;
+            if (ec > max_rel) max_rel = ec;
+        }
         const double gs = sin(x), gc = cos(x);
         const double qs = (double)sinq((__float128)x), qc = (double)cosq((__float128)x);
         bad_g += !same(s, gs) + !same(c, gc);
@@ -45,6 +60,8 @@ int main(int argc, char** argv) {
         g_q += !same(gs, qs) + !same(gc, qc);
     }
     printf("sincos  n=%ld values=%ld  vs_glibc=%ld  vs_correctly_rounded=%ld  glibc_vs_correctly_rounded=%ld\n", n, 2 * n, bad_g, bad_q, g_q);
+    printf("  fast path: undecided on %ld of %ld calls, largest relative error 2^%.1f (threshold 2^%.0f)\n", pb_math_slow_sincos, n, log2(max_rel), log2(PB_FAST_REL));
+    max_rel = 0.0;
     // ---- atan2: pixel-centre offsets (half-integers) as a destination's mesh gives them, and unit-vector components as a
     // rotation gives them
     bad_g = bad_q = g_q = 0;
@@ -59,12 +76,23 @@ int main(int argc, char** argv) {
             y = sin(lon) * sin(lat);
             if (rnd() & 1) x *= uni();
         }
+        {
+            const double ax = fabs(x), ay = fabs(y), num = ay > ax ? ax : ay, den = ay > ax ? ay : ax;
+            if (den < 0x1p100 && den > 0x1p-100 && num > den * 0x1p-40) {
+                const pb_dd f = pb_atan_fast(num, den);
+                const __float128 t = atanq((__float128)num / (__float128)den);
+                const double e = (double)fabsq((((__float128)f.h + f.l) - t) / t);
+                if (e > max_rel) max_rel = e;
+            }
+        }
         const double r = pb_atan2_cr(y, x), g = atan2(y, x), q = (double)atan2q((__float128)y, (__float128)x);
         bad_g += !same(r, g);
         bad_q += !same(r, q);
         g_q += !same(g, q);
     }
     printf("atan2   n=%ld values=%ld  vs_glibc=%ld  vs_correctly_rounded=%ld  glibc_vs_correctly_rounded=%ld\n", n, n, bad_g, bad_q, g_q);
+    printf("  fast path: undecided on %ld of %ld calls, largest relative error 2^%.1f (threshold 2^%.0f)\n", pb_math_slow_atan2, n, log2(max_rel), log2(PB_FAST_REL));
+    const long atan2_slow = pb_math_slow_atan2;
     // ---- atan (lens inverses): radii in focal-length units
     bad_g = bad_q = g_q = 0;
     for (long i = 0; i < n; ++i) {
@@ -75,6 +103,7 @@ int main(int argc, char** argv) {
         g_q += !same(g, q);
     }
     printf("atan    n=%ld values=%ld  vs_glibc=%ld  vs_correctly_rounded=%ld  glibc_vs_correctly_rounded=%ld\n", n, n, bad_g, bad_q, g_q);
+    printf("  fast path: undecided on %ld of %ld calls\n", pb_math_slow_atan2 - atan2_slow, n);
     // ---- special values keep the platform's results
     const double sp[] = {0.0, -0.0, 1.0, -1.0, 0.5, INFINITY, -INFINITY, NAN, 1e300, -1e-300, 4e-320};
     long bad_s = 0;

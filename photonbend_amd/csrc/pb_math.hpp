@@ -8,8 +8,10 @@
 // measured 41 687 of 589 824 pixels one texel off on an identity remap, and tens to hundreds of ulp on rotated coordinate
 // maps.  glibc's own algorithm (IBM Accurate Mathematical Library: table lookups and double-double corrections; third-party,
 // sysdeps/ieee754/dbl-64/s_sin.c, e_atan2.c, not in /root/reference) is not restated here; instead these functions deliver
-// the CORRECTLY ROUNDED value - double-double evaluation to ~2^-100, far beyond the 2^-53 of the result - which is what
-// glibc returns wherever glibc is itself correctly rounded.  Measured against this container's glibc 2.35 on 2 x 10^7 random
+// the CORRECTLY ROUNDED value, which is what glibc returns wherever glibc is itself correctly rounded.  Two steps (Ziv's
+// strategy): a table-driven evaluation good to 2^-69 decides the rounding of all but ~1 result in 10^4 (pb_sincos_fast_reduced,
+// pb_atan_fast); only where the value sits within 2^-67 of a rounding boundary the double-double series (~2^-100) runs, as a
+// real call, so that it costs the callers neither registers nor code size.  The bits are the correctly rounded ones either way.  Measured against this container's glibc 2.35 on 2 x 10^7 random
 // arguments each (oracle/check_math.cpp, tests/test_oracle_golden.py::test_device_math_agrees_with_glibc): see DESIGN.md 2.
 //
 // The code is plain C++ (compiled for the host by the check program, for gfx950 by hipcc); every fused operation is an
@@ -19,9 +21,15 @@
 
 #if defined(__HIPCC__)
 #define PB_MATH_FN __device__ static inline
+#ifdef PB_MATH_INLINE_SLOW  // A/B builds only (experiments/session_r3_u.sh)
+#define PB_MATH_SLOW __device__ static inline
+#else
+#define PB_MATH_SLOW __device__ static __attribute__((noinline))  // the rarely taken double-double paths: real calls, out of the callers' register budgets
+#endif
 #define PB_MATH_CONST __device__ static const
 #else
 #define PB_MATH_FN static inline
+#define PB_MATH_SLOW static
 #define PB_MATH_CONST static const
 #endif
 
@@ -81,15 +89,23 @@ PB_MATH_FN pb_dd pb_dd_div(pb_dd a, pb_dd b) {
     return pb_dd_add_d(q, q3);
 }
 
-// sin and cos of x as double-doubles (relative error < 2^-95); x finite, |x| < 2^19 (far beyond the chain's angles)
-PB_MATH_FN void pb_sincos_dd(double x, pb_dd& s, pb_dd& c) {
-    const double kd = rint(x * PB_TWO_OVER_PI_DD[0]);
-    // r = x - kd * pi/2: the first two pieces of pi/2 have 33 bits, so their products with kd are exact
+// x = kd * pi/2 + r, |r| <= pi/4 (+ an ulp), r a double-double good to ~2^-120 of pi/2; x finite, |x| < 2^19
+PB_MATH_FN pb_dd pb_reduce_pio2(double x, double& kd) {
+    kd = rint(x * PB_TWO_OVER_PI_DD[0]);
+    // the first two pieces of pi/2 have 33 bits, so their products with kd are exact
     pb_dd r = pb_two_sum(x, -kd * PB_PIO2_1);
     r = pb_dd_add_d(r, -kd * PB_PIO2_2);
     pb_dd t = pb_two_prod(kd, PB_PIO2_3H);
     t.l = fma(kd, PB_PIO2_3L, t.l);
-    r = pb_dd_add(r, pb_dd_neg(t));
+    return pb_dd_add(r, pb_dd_neg(t));
+}
+
+// sin and cos of the reduced argument r as double-doubles (relative error < 2^-95): the SLOW path
+struct pb_dd_pair {
+    pb_dd s, c;
+};
+PB_MATH_SLOW pb_dd_pair pb_sincos_dd_reduced(pb_dd r) {
+    pb_dd S, C;
     const pb_dd z = pb_dd_mul(r, r);
     // sin r = r * S(z), S = sum (-1)^j z^j / (2j+1)!;  cos r = C(z), C = sum (-1)^j z^j / (2j)!   (|r| <= pi/4: z <= 0.617)
     // the terms from z^7 on contribute < 2^-40 of the sum: plain float64 there (their error: < 2^-93 of the sum)
@@ -99,14 +115,54 @@ PB_MATH_FN void pb_sincos_dd(double x, pb_dd& s, pb_dd& c) {
         sd = fma(sd, z.h, (j & 1) ? -PB_INV_FACT[2 * j + 1][0] : PB_INV_FACT[2 * j + 1][0]);
         cd = fma(cd, z.h, (j & 1) ? -PB_INV_FACT[2 * j][0] : PB_INV_FACT[2 * j][0]);
     }
-    pb_dd S = {sd, 0.0}, C = {cd, 0.0};
+    S = {sd, 0.0};
+    C = {cd, 0.0};
     for (int j = 6; j >= 0; --j) {
         const double sg = (j & 1) ? -1.0 : 1.0;
         S = pb_dd_add(pb_dd_mul(S, z), pb_dd{sg * PB_INV_FACT[2 * j + 1][0], sg * PB_INV_FACT[2 * j + 1][1]});
         C = pb_dd_add(pb_dd_mul(C, z), pb_dd{sg * PB_INV_FACT[2 * j][0], sg * PB_INV_FACT[2 * j][1]});
     }
     S = pb_dd_mul(S, r);
-    const long long k = (long long)kd;
+    return {S, C};
+}
+
+// The FAST path: sin r and cos r as NORMALISED head + tail pairs with a relative error below 2^-69 (PB_FAST_REL leaves a
+// factor of four).  |r| = j/256 + t, |t| <= 2^-9 (+ an ulp): sin(j/256), cos(j/256) from a double-double table, C * t and S * t
+// as double-double products, the rest - S (cos t - 1) + C (sin t - t), below 2^-19 of the result - in float64.
+#define PB_FAST_REL 0x1p-67
+PB_MATH_FN void pb_sincos_fast_reduced(pb_dd r, pb_dd& S, pb_dd& C) {
+    const double a = fabs(r.h), sg = r.h < 0.0 ? -1.0 : 1.0;
+    const int j = (int)rint(a * 256.0);  // 0 .. 202
+    // t = |r| - j/256: the subtraction of the heads is exact (a non-zero result is a multiple of ulp(r.h) > |r.l|)
+    const pb_dd t = pb_fast_two_sum(a - (double)j * 0.00390625, sg * r.l);
+    const double Sh = PB_SINCOS_TAB[j][0], Sl = PB_SINCOS_TAB[j][1], Ch = PB_SINCOS_TAB[j][2], Cl = PB_SINCOS_TAB[j][3];
+    const double z = t.h * t.h;
+    const double sc = t.h * (z * fma(z, fma(z, -0x1.a01a01a01a01ap-13, 0x1.1111111111111p-7), -0x1.5555555555555p-3));  // sin t - t
+    const double cc = z * fma(z, fma(z, -0x1.6c16c16c16c17p-10, 0x1.5555555555555p-5), -0.5);                            // cos t - 1
+    pb_dd p = pb_two_prod(Ch, t.h);  // C * t
+    p.l += fma(Ch, t.l, Cl * t.h);
+    pb_dd q = pb_two_prod(Sh, t.h);  // S * t
+    q.l += fma(Sh, t.l, Sl * t.h);
+    // sin |r| = S + C t + (S cc + C sc);  |S| >= |C t| for j >= 1, S = 0 for j = 0
+    pb_dd s = pb_fast_two_sum(Sh, p.h);
+    s.l += (Sl + p.l) + fma(Sh, cc, Ch * sc);
+    s = pb_fast_two_sum(s.h, s.l);
+    // cos |r| = C - S t + (C cc - S sc)
+    pb_dd c = pb_fast_two_sum(Ch, -q.h);
+    c.l += (Cl - q.l) + fma(Ch, cc, -(Sh * sc));
+    C = pb_fast_two_sum(c.h, c.l);
+    S = {sg * s.h, sg * s.l};
+}
+
+// is RN(h + l) the same for every value within rel * |h| of h + l?  (h, l normalised: h == RN(h + l))
+PB_MATH_FN bool pb_rounding_decided(pb_dd v, double* out) {
+    const double e = fabs(v.h) * PB_FAST_REL;
+    const double lo = v.h + (v.l - e), hi = v.h + (v.l + e);
+    *out = lo;
+    return lo == hi;
+}
+
+PB_MATH_FN void pb_quadrant(long long k, pb_dd S, pb_dd C, pb_dd& s, pb_dd& c) {
     switch ((int)(k & 3)) {
         case 0: s = S; c = C; break;
         case 1: s = C; c = pb_dd_neg(S); break;
@@ -115,7 +171,24 @@ PB_MATH_FN void pb_sincos_dd(double x, pb_dd& s, pb_dd& c) {
     }
 }
 
+// sin and cos of x as double-doubles (relative error < 2^-95); x finite, |x| < 2^19 (far beyond the chain's angles)
+PB_MATH_FN void pb_sincos_dd(double x, pb_dd& s, pb_dd& c) {
+    double kd;
+    const pb_dd r = pb_reduce_pio2(x, kd);
+    const pb_dd_pair v = pb_sincos_dd_reduced(r);
+    pb_quadrant((long long)kd, v.s, v.c, s, c);
+}
+
+#ifdef PB_MATH_COUNT  // oracle/check_math.cpp: how often the fast paths leave the rounding undecided
+static long pb_math_slow_sincos = 0, pb_math_slow_atan2 = 0;
+#define PB_MATH_COUNT_SLOW(c) (++(c))
+#else
+#define PB_MATH_COUNT_SLOW(c) ((void)0)
+#endif
+
 // Correctly rounded (to nearest) sin / cos.  Non-finite and huge arguments keep the platform libm's behaviour.
+// Two steps (Ziv): the fast evaluation decides the rounding of all but a few results in 10^4; the double-double series runs only
+// for those - the bits are the correctly rounded ones either way.
 PB_MATH_FN void pb_sincos_cr(double x, double* sn, double* cs) {
     if (!(fabs(x) < 524288.0)) {
         *sn = sin(x);
@@ -127,8 +200,16 @@ PB_MATH_FN void pb_sincos_cr(double x, double* sn, double* cs) {
         *cs = 1.0;
         return;
     }
-    pb_dd s, c;
-    pb_sincos_dd(x, s, c);
+    double kd;
+    const pb_dd r = pb_reduce_pio2(x, kd);
+    pb_dd S, C, s, c;
+    pb_sincos_fast_reduced(r, S, C);
+    pb_quadrant((long long)kd, S, C, s, c);
+    const bool ok_s = pb_rounding_decided(s, sn), ok_c = pb_rounding_decided(c, cs);
+    if (ok_s && ok_c) return;
+    PB_MATH_COUNT_SLOW(pb_math_slow_sincos);
+    const pb_dd_pair v = pb_sincos_dd_reduced(r);
+    pb_quadrant((long long)kd, v.s, v.c, s, c);
     *sn = s.h + s.l;
     *cs = c.h + c.l;
 }
@@ -171,20 +252,64 @@ PB_MATH_FN pb_dd pb_atan_dd01(pb_dd t) {
     return r;
 }
 
+// The FAST path of atan(num / den), 0 < num <= den: a NORMALISED head + tail pair, relative error below 2^-69.
+// atan(num / den) = atan(c) + atan(u), c = i / 256 the table point next to the quotient, u = (num - c den) / (den + c num) formed
+// from the ARGUMENTS (one reciprocal in all), |u| <= 2^-9 (+): atan u = u + u^3 (-1/3 + u^2 / 5 - u^4 / 7) with the bracket in float64.
+PB_MATH_FN pb_dd pb_atan_fast(double num, double den) {
+    const int i = (int)rintf(256.0f * ((float)num / (float)den));  // 0 .. 256; a neighbour of the best index serves as well
+    const double c = (double)i * 0.00390625;
+    const pb_dd p = pb_two_prod(c, den), q = pb_two_prod(c, num);
+    pb_dd N = pb_two_sum(num, -p.h);
+    N = pb_fast_two_sum(N.h, N.l - p.l);
+    pb_dd D = pb_fast_two_sum(den, q.h);  // den >= c num
+    D = pb_fast_two_sum(D.h, D.l + q.l);
+    const double inv = 1.0 / D.h;
+    const double u1 = N.h * inv;
+    double rem = fma(-u1, D.h, N.h);  // exact: u1 is within two ulps of N.h / D.h
+    rem = fma(-u1, D.l, rem) + N.l;
+    const double u2 = rem * inv;
+    const double w = u1 * u1;
+    const double corr = u1 * (w * fma(w, fma(w, -0x1.2492492492492p-3, 0x1.999999999999ap-3), -0x1.5555555555555p-2));
+    pb_dd r = pb_fast_two_sum(PB_ATAN_TAB256[i][0], u1);  // atan(c) >= |u| for i >= 1, 0 for i = 0
+    r.l += (PB_ATAN_TAB256[i][1] + u2) + corr;
+    return pb_fast_two_sum(r.h, r.l);
+}
+
+// the double-double evaluation of atan2 (num, den = the smaller and the larger of |y|, |x|)
+PB_MATH_SLOW double pb_atan2_slow(double y, double x, double num, double den, bool swap) {
+    const pb_dd pio2 = {PB_PIO2_DD[0], PB_PIO2_DD[1]}, pi = {PB_PI_DD[0], PB_PI_DD[1]};
+    const pb_dd t = pb_dd_div(pb_dd{num, 0.0}, pb_dd{den, 0.0});
+    if (!swap && x > 0.0 && t.h < 0x1p-60) return y < 0.0 ? -(t.h + t.l) : (t.h + t.l);  // atan t = t to far below half an ulp
+    pb_dd r = pb_atan_dd01(t);
+    if (swap) r = pb_dd_add_d(pb_dd_add(pio2, pb_dd_neg(r)), PB_PIO2_DD[2]);
+    if (x < 0.0) r = pb_dd_add_d(pb_dd_add(pi, pb_dd_neg(r)), PB_PI_DD[2]);
+    const double v = r.h + r.l;
+    return y < 0.0 ? -v : v;
+}
+
 // Correctly rounded atan2(y, x) for finite non-zero arguments; zeros, infinities and NaNs take the platform libm (whose
-// results there are exact constants or signed zeros).
+// results there are exact constants or signed zeros).  Two steps like pb_sincos_cr.
 PB_MATH_FN double pb_atan2_cr(double y, double x) {
     const double ax = fabs(x), ay = fabs(y);
     if (!(ax < HUGE_VAL) || !(ay < HUGE_VAL) || ax == 0.0 || ay == 0.0) return atan2(y, x);
     // keep the quotient away from overflow / underflow (never near them in the remap chain, but be total)
     if (ax > 0x1p1000 || ay > 0x1p1000 || ax < 0x1p-900 || ay < 0x1p-900) return atan2(y, x);
     const bool swap = ay > ax;
-    const pb_dd t = swap ? pb_dd_div(pb_dd{ax, 0.0}, pb_dd{ay, 0.0}) : pb_dd_div(pb_dd{ay, 0.0}, pb_dd{ax, 0.0});
-    if (!swap && x > 0.0 && t.h < 0x1p-60) return y < 0.0 ? -(t.h + t.l) : (t.h + t.l);  // atan t = t to far below half an ulp
-    pb_dd r = pb_atan_dd01(t);
+    const double num = swap ? ax : ay, den = swap ? ay : ax;
     const pb_dd pio2 = {PB_PIO2_DD[0], PB_PIO2_DD[1]}, pi = {PB_PI_DD[0], PB_PI_DD[1]};
-    if (swap) r = pb_dd_add_d(pb_dd_add(pio2, pb_dd_neg(r)), PB_PIO2_DD[2]);
-    if (x < 0.0) r = pb_dd_add_d(pb_dd_add(pi, pb_dd_neg(r)), PB_PI_DD[2]);
-    const double v = r.h + r.l;
-    return y < 0.0 ? -v : v;
+    if (den < 0x1p100 && den > 0x1p-100 && num > den * 0x1p-40) {
+        pb_dd r = pb_atan_fast(num, den);
+        if (swap) {  // pi/2 - r
+            pb_dd s = pb_two_sum(pio2.h, -r.h);
+            r = pb_fast_two_sum(s.h, s.l + (pio2.l - r.l));
+        }
+        if (x < 0.0) {  // pi - r
+            pb_dd s = pb_two_sum(pi.h, -r.h);
+            r = pb_fast_two_sum(s.h, s.l + (pi.l - r.l));
+        }
+        double v;
+        if (pb_rounding_decided(r, &v)) return y < 0.0 ? -v : v;
+        PB_MATH_COUNT_SLOW(pb_math_slow_atan2);
+    }
+    return pb_atan2_slow(y, x, num, den, swap);
 }

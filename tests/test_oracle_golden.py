@@ -135,7 +135,8 @@ def test_c1_real_image_pin():
 def test_device_math_agrees_with_glibc(tmp_path):
     """photonbend_amd/csrc/pb_math.hpp (the sin / cos / atan2 / atan of the faithful device chain) compiled for the HOST: every
     result is the correctly rounded one (113-bit libquadmath reference) and therefore equals this machine's glibc - what the
-    reference reaches through NumPy - wherever glibc is itself correctly rounded (all but ~1 argument in 1000)."""
+    reference reaches through NumPy - wherever glibc is itself correctly rounded (all but ~1 argument in 1000).  Both steps of
+    the evaluation are exercised: the table-driven fast path and, where it leaves the rounding undecided, the double-double series."""
     import re
     import shutil
     import subprocess
@@ -157,3 +158,11 @@ def test_device_math_agrees_with_glibc(tmp_path):
         assert int(vs_cr) == 0, f"{name}: {vs_cr} of {n} results are not correctly rounded"
         assert int(vs_glibc) == int(glibc_cr) and int(vs_glibc) <= int(n) * 3 // 1000, f"{name}: {vs_glibc} of {n} differ from glibc"
     assert "special values: 0 mismatches" in out, out
+    # the two-step evaluation: the fast path decides all but a few results in 10^4, and its own error stays a factor of
+    # four (2 bits) below the threshold its decision assumes
+    fast = re.findall(r"fast path: undecided on (\d+) of (\d+) calls(?:, largest relative error 2\^(-[\d.]+) \(threshold 2\^(-\d+)\))?", out)
+    assert len(fast) == 3, out
+    for undecided, calls, err, thr in fast:
+        assert int(undecided) <= int(calls) // 2000, out
+        if err:
+            assert float(err) <= float(thr) - 2.0, out
