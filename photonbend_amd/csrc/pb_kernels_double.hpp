@@ -233,6 +233,10 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     // A batch is cut into chunks of frames_per_wave frames; chunks are a grid dimension (chunk-major, a tile group keeps
     // its XCD residue): the launch ramp and drain are paid once per batch, and inside a chunk the wave reuses its two
     // entries, blend weights and per-pixel addresses across the frames (ONE: chunks of one frame, no frame loop).
+    // the five numbers a one-eye tile needs besides its entry, fetched with the table pointer in the wave's FIRST scalar round
+    // trip (the compiler would otherwise fetch them after the entry has arrived: one more dependent trip per wave)
+    const PbHot Hd = pb_hot_of(P);
+    asm volatile("" ::"s"(ltable), "s"(Hd.dst_w), "s"(Hd.dst_h), "s"(Hd.src_w), "s"(Hd.src_h), "s"(Hd.win_budget), "s"(groups_per_frame));
     unsigned group = blockIdx.x;
     int frames = ONE ? 1 : frames_per_wave;
     if (group >= groups_per_frame) {
@@ -271,8 +275,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
 #endif
         if (entry.flags & PB_TILE_SOLO) {
             PB_TR(1);
-            pb_win_tile<PB_KIND_CAMERA, false>(P, &entry, entry.flags & (PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK), tx, ty, lane,
-                                               pb_wave_window(P, wave, 8), src, dst, frames, src_stride, dst_stride);
+            pb_win_tile<PB_KIND_CAMERA, false>(P, Hd, &entry, entry.flags & (PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK), tx, ty, lane,
+                                               pb_dyn_lds + (size_t)wave * ((Hd.win_budget >> 2) + 8), src, dst, frames, src_stride, dst_stride);
 #ifdef PB_TRACE
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PB_TR(6);

@@ -182,6 +182,14 @@ extern __shared__ __attribute__((aligned(16))) unsigned pb_dyn_lds[];
 __device__ __forceinline__ unsigned* pb_wave_window(const PbParams& P, int wave, int pad_dwords = 4) {
     return pb_dyn_lds + (size_t)wave * ((P.win_budget >> 2) + pad_dwords);
 }
+// The five numbers a plain tile (LEAN / DIRECT / BLACK) needs besides its entry.  The single-source hot kernel receives them as
+// kernel ARGUMENTS - they arrive with the table pointer in the wave's first scalar round trip - while everything else of the
+// parameter block stays behind the plan-resident pointer and is fetched only by the tiles that need it (masked, generic, failed).
+struct PbHot {
+    int32_t dst_w, dst_h, src_w, src_h, win_budget;
+};
+__device__ __forceinline__ PbHot pb_hot_of(const PbParams& P) { return {P.dst.width, P.dst.height, P.src.width, P.src.height, P.win_budget}; }
+static inline PbHot pb_hot_of_host(const PbParams& P) { return {P.dst.width, P.dst.height, P.src.width, P.src.height, P.win_budget}; }
 static inline size_t pb_window_lds_bytes(const PbParams& P, int pad_dwords = 4) {
     return (size_t)PB_TILE_WAVES * ((size_t)P.win_budget + 4u * pad_dwords);
 }
@@ -228,16 +236,16 @@ __device__ __forceinline__ void pb_issue_window_loads(const uint8_t* __restrict_
 
 // One tile of the windowed hot kernel (the four tile classes); returns when the tile's pixels are stored.
 template <int SRC_KIND, bool NT = (SRC_KIND == PB_KIND_CAMERA)>
-__device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry* __restrict__ e, const int flags, const int tx,
+__device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbHot& Hd, const PbTileEntry* __restrict__ e, const int flags, const int tx,
                                             const int ty, const int lane, unsigned* win, const uint8_t* __restrict__ src,
                                             uint8_t* __restrict__ dst, const int n_frames, const unsigned long long src_stride,
                                             const unsigned long long dst_stride) {
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
-    const unsigned rowbytes = 3u * (unsigned)P.src.width;
-    const unsigned frame_bytes = rowbytes * (unsigned)P.src.height;   // < 2^31 (host check)
+    const unsigned rowbytes = 3u * (unsigned)Hd.src_w;
+    const unsigned frame_bytes = rowbytes * (unsigned)Hd.src_h;       // < 2^31 (host check)
     const unsigned safe_len = frame_bytes & ~15u;                     // every 16-byte chunk below this is loadable
     const int xg = lane & 7, yb = lane >> 3;
-    const int W = P.dst.width, H = P.dst.height;
+    const int W = Hd.dst_w, H = Hd.dst_h;
     const int x = X0 + 4 * xg;
 
 #ifdef PB_ABLATION  // timing experiments only (experiments/): skipped work = wrong pixels; never compiled into the product
@@ -482,7 +490,7 @@ __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbTileEntry
     if (nrows > 0) {
         n16 = (3 * e->win_cols + 15 + 1 + 15) >> 4;  // + worst-case alignment slack + 1 byte for the dword reads
         if (n16 > 64) n16 = 64;
-        const int cap = P.win_budget / (16 * n16);
+        const int cap = Hd.win_budget / (16 * n16);
         if (nrows > cap) nrows = cap;
     }
     const unsigned pitch = 16u * (unsigned)n16;
@@ -575,13 +583,13 @@ __device__ __forceinline__ void pb_load_entry(const PbTileEntry* __restrict__ e,
 // With them the hot launch is the only launch of a frame: a failed tile is gathered by its own wave through its
 // index slot, a tile's fix pixels are re-copied by its wave after its stores; no float64 in the kernel.
 template <bool ONE>
-__device__ __forceinline__ void pb_failed_tile(const PbParams& P, const PbTileEntry* __restrict__ e, const int tx, const int ty,
+__device__ __forceinline__ void pb_failed_tile(const PbHot& Hd, const PbTileEntry* __restrict__ e, const int tx, const int ty,
                                                const int lane, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                const int n_frames, const unsigned long long src_stride,
                                                const unsigned long long dst_stride, const int32_t* __restrict__ idx_tab) {
     // failed tile: gather through the plan's exact indices (lane = 4 consecutive pixels x 4 rows)
     const int xg = lane & 7, yb = lane >> 3;
-    const int W = P.dst.width, H = P.dst.height;
+    const int W = Hd.dst_w, H = Hd.dst_h;
     const int x = tx * PB_TILE + 4 * xg;
     const int32_t* __restrict__ slot = idx_tab + (size_t)e->aux_off * (PB_TILE * PB_TILE);
     int id[4][4];
@@ -590,7 +598,7 @@ __device__ __forceinline__ void pb_failed_tile(const PbParams& P, const PbTileEn
         const int4 v = *reinterpret_cast<const int4*>(slot + (yb + 8 * jr) * PB_TILE + 4 * xg);
         id[jr][0] = v.x; id[jr][1] = v.y; id[jr][2] = v.z; id[jr][3] = v.w;
     }
-    const unsigned last_px = (unsigned)P.src.height * (unsigned)P.src.width - 1u;
+    const unsigned last_px = (unsigned)Hd.src_h * (unsigned)Hd.src_w - 1u;
     for (int f = 0; f < n_frames; ++f) {
         const uint8_t* s = src + (unsigned long long)f * src_stride;
         uint8_t* d = dst + (unsigned long long)f * dst_stride;
@@ -644,7 +652,7 @@ __device__ __forceinline__ void pb_failed_tile(const PbParams& P, const PbTileEn
 // c1 13.9-14.7 -> 13.7-13.9, c3 +-0, the all-tiles-skipped launch of 4096 workgroups 5.9-7.1 -> 5.9-6.7.  The double-fisheye kernel
 // keeps the block by value: by pointer measured 1.4 % SLOWER there (58.4-58.9 -> 59.5-59.8 us).
 template <int SRC_KIND>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams* __restrict__ Pp, const PbTileEntry* __restrict__ table,
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams* __restrict__ Pp, const PbHot Hd, const PbTileEntry* __restrict__ table,
                                                                          const uint8_t* __restrict__ src,
                                                                          uint8_t* __restrict__ dst, const unsigned groups_per_frame,
                                                                          unsigned long long src_stride,
@@ -655,13 +663,17 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
     const PbParams& P = *Pp;
     // every kernel argument the tile prologue needs, in one scalar round trip (the compiler would otherwise fetch
     // the table pointer only after the tile index is known: a second dependent trip per wave)
-    asm volatile("" ::"s"(table), "s"(P.dst.width), "s"(P.dst.height), "s"(P.src.width), "s"(P.src.height), "s"(P.win_budget), "s"(groups_per_frame));
+    asm volatile("" ::"s"(table), "s"(Hd.dst_w), "s"(Hd.dst_h), "s"(Hd.src_w), "s"(Hd.src_h), "s"(Hd.win_budget), "s"(groups_per_frame));
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // A workgroup is `wpw` waves (1, 2 or 4; blockDim.x / 64).  LDS is released per WORKGROUP: with four waves the
     // window of a wave that has finished idles until the slowest of the four is done.  Tile groups (2x2 tiles) keep
     // their XCD: workgroup id -> (XCD residue, slot); the slot's waves continue the XCD's list of tile groups.
+#ifdef PB_ABLATION
     const unsigned wpw = blockDim.x >> 6;
+#else
+    constexpr unsigned wpw = PB_TILE_WAVES;  // (blockDim.x is a hidden kernel argument of its own cache line: a round trip and a division saved)
+#endif
     unsigned wg = blockIdx.x;
     const unsigned wgs_per_frame = groups_per_frame * (4u / wpw);
     if (wg >= wgs_per_frame) {  // a batch: which frame
@@ -690,7 +702,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
     const int flags = e->flags;
     PB_TR(1);
     if (flags & PB_TILE_FAILED) {
-        pb_failed_tile<true>(P, e, tx, ty, lane, src, dst, 1, src_stride, dst_stride, idx_tab);
+        pb_failed_tile<true>(Hd, e, tx, ty, lane, src, dst, 1, src_stride, dst_stride, idx_tab);
 #ifdef PB_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PB_TR(6);
@@ -698,7 +710,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
 #endif
         return;
     }
-    pb_win_tile<SRC_KIND>(P, e, flags, tx, ty, lane, pb_wave_window(P, wave_in_wg), src, dst, 1, src_stride, dst_stride);
+    pb_win_tile<SRC_KIND>(P, Hd, e, flags, tx, ty, lane, pb_dyn_lds + (size_t)wave_in_wg * ((Hd.win_budget >> 2) + 4), src, dst, 1, src_stride, dst_stride);
 #ifdef PB_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PB_TR(6);

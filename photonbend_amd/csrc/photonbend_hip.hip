@@ -370,7 +370,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
             const uint8_t* sf = src + (unsigned long long)f0 * ss;
             uint8_t* df = dst + (unsigned long long)f0 * ds;
 #define PB_LAUNCH_WIN(KIND)                                                                                                   \
-    hipLaunchKernelGGL((pb_hot_win_kernel<KIND>), bgrid, wblock, lds, st, (const PbParams*)pl->P_dev, pl->ltable, sf, df, gpf, ss, ds, pl->idx_tab, \
+    hipLaunchKernelGGL((pb_hot_win_kernel<KIND>), bgrid, wblock, lds, st, (const PbParams*)pl->P_dev, pb_hot_of_host(P), pl->ltable, sf, df, gpf, ss, ds, pl->idx_tab, \
                        pl->fix_px, pl->fix_idx)
             if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_WIN(PB_KIND_PANO);
             else PB_LAUNCH_WIN(PB_KIND_CAMERA);
