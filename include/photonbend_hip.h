@@ -174,7 +174,8 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
  * k + 0.5; taps clamped to the image, panorama columns wrap; round half to even).  Pixels the nearest mode
  * paints black stay black.  A double-fisheye source is the reference's blend (projection.py:439-460) of the two eyes'
  * bilinear samples (each eye sampled like a camera source on its half, rounded to uint8, then blended and cast as the
- * nearest mode does); that combination runs the float64 chain per pixel. */
+ * nearest mode does); it runs through the per-eye tile models like the nearest mode (ABI 3; pixels the models cannot serve
+ * are recomputed by the float64 chain in the same call). */
 int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames,
                          size_t src_frame_stride, size_t dst_frame_stride, void* stream);
 

@@ -160,6 +160,7 @@ static inline unsigned pb_num_tiles(const PbParams& P) {
     return ((P.dst.width + PB_TILE - 1) / PB_TILE) * ((P.dst.height + PB_TILE - 1) / PB_TILE);
 }
 
+static_assert(16384 / PB_TILE < 65536, "PbTileEntry::tile_xy packs tile coordinates in 16 bits each");
 static bool pb_fast_possible_dims(const PbParams& P) {
     // the tile models need 32-bit squares of the doubled pixel offsets and u24 index arithmetic
     return P.dst.width <= 16384 && P.dst.height <= 16384 && P.src.width < 32768 && P.src.height < 32768;
