@@ -154,6 +154,12 @@ int pb_plan_src_shape(const pb_plan* plan, int* height, int* width);
 /* bytes of LDS window per wave the plan's hot launches use (it decides which path a tile takes, never its
  * pixels); 0 without device state */
 int pb_plan_window_budget(const pb_plan* plan);
+/* How many 32x32 tiles of a prepared plan the opt-in bilinear mode (pb_remap_bilinear_u8) recomputes with the float64 chain per
+ * pixel instead of the tile models: failed tiles, tiles whose model is further than 1/1024 px from the faithful coordinate
+ * somewhere (fine for the reference's truncating sampler, whose exceptions are tabulated; too coarse to interpolate at), and
+ * - double-fisheye sources - tiles that are not plain for an eye that sees them.  0 for a deferred plan. */
+int pb_plan_bilinear_float64_tiles(const pb_plan* plan);
+
 /* 1 when `plan` was made for exactly this request (same projections, same rotation bits), 0 when not, negative on bad
  * arguments (ABI 3).  What a cache of serialized plans checks after pb_plan_deserialize: the blob's checksum says it is
  * intact, not that it belongs to the geometry the caller has in mind. */

@@ -74,6 +74,7 @@ SIGNATURES = {
     "pb_plan_dst_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_plan_src_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_plan_window_budget": (C.c_int, [_VP]),
+    "pb_plan_bilinear_float64_tiles": (C.c_int, [_VP]),
     "pb_plan_matches": (C.c_int, [_VP, C.POINTER(pb_proj), C.POINTER(C.c_double), C.c_int, C.POINTER(pb_proj)]),
     "pb_remap_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
     "pb_remap_bilinear_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
@@ -239,6 +240,7 @@ class Plan:
             "direct_tiles": int(st[6]),
             "thresholds": [int(t) for t in thr],
             "window_budget": int(load().pb_plan_window_budget(self._h)),
+            "bilinear_float64_tiles": int(load().pb_plan_bilinear_float64_tiles(self._h)),
         }
 
     def __del__(self):

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(con
     pb_load_entry(table + vslot, entry);
     const PbTileEntry* __restrict__ e = &entry;
     const int flags = e->flags;
-    if (flags & (PB_TILE_SKIP | PB_TILE_FAILED)) return;  // failed tiles: pb_bilinear_fix_kernel
+    if (flags & (PB_TILE_SKIP | PB_TILE_FAILED | PB_TILE_COARSE)) return;  // failed tiles, tiles whose model is too coarse to interpolate at: pb_bilinear_fix_kernel
     const int tx = e->tile_xy & 0xFFFF, ty = (int)((unsigned)e->tile_xy >> 16);
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
     const int xg = lane & 7, yb = lane >> 3;
@@ -270,7 +270,8 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_fix_kernel(const PbParam
                                                                    uint8_t* __restrict__ dst, int n_frames,
                                                                    unsigned long long src_stride, unsigned long long dst_stride,
                                                                    int n_fail_tiles = 0, const int32_t* __restrict__ fix_px = nullptr,
-                                                                   int n_fix_px = 0) {
+                                                                   int n_fix_px = 0, const int32_t* __restrict__ more_tiles = nullptr,
+                                                                   int n_fail_only = 0) {
     int i, j;
     if (all_pixels) {
         const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
@@ -284,7 +285,9 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_fix_kernel(const PbParam
         i = p / (unsigned)P.dst.width;
         j = p - (unsigned)i * (unsigned)P.dst.width;
     } else {
-        const int t = fail_tiles[blockIdx.x >> 2];
+        // n_fail_tiles: the plan's failed tiles (the first n_fail_only, from fail_tiles) and its COARSE tiles (more_tiles) together
+        const int k = blockIdx.x >> 2;
+        const int t = (more_tiles && k >= n_fail_only) ? more_tiles[k - n_fail_only] : fail_tiles[k];
         const int ty = t / pb_tiles_x(P), tx = t - ty * pb_tiles_x(P);
         const int local = (blockIdx.x & 3) * 256 + threadIdx.x;
         i = ty * PB_TILE + (local >> 5);
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_double_hot_ker
     unsigned* win = pb_wave_window(P, wave, 8);
     unsigned a[16];
     if (entry.flags & PB_TILE_SOLO) {
+        if (entry.flags & PB_TILE_COARSE) return;  // (on the plan's float64 list)
         if (entry.flags & PB_TILE_EYE_R)
             pb_bilinear_eye_vals<PB_KIND_EYE_R>(P, &entry, entry.flags, X0, Y0, lane, win, windows, src, a);
         else
@@ -528,11 +532,11 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_double_hot_ker
         pb_load_entry(table_l + tile, entry);
         const int fl0 = entry.flags, lat_slot = entry.aux_off;
         const int served = PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK;
-        if ((fl0 & PB_TILE_FAILED) || !(fl0 & served)) return;  // failed, or not plain for the left eye: the float64 pass's (pb_bilinear_tile_list_kernel)
+        if ((fl0 & (PB_TILE_FAILED | PB_TILE_COARSE)) || !(fl0 & served)) return;  // failed, coarse, or not plain for the left eye: the float64 pass's (pb_bilinear_tile_list_kernel)
         unsigned al[16];
         pb_bilinear_eye_vals<PB_KIND_EYE_L>(P, &entry, fl0, X0, Y0, lane, win, windows, src, al);
         pb_load_entry(table_r + tile, entry);
-        if (!(entry.flags & served)) return;
+        if (!(entry.flags & served) || (entry.flags & PB_TILE_COARSE)) return;
         pb_bilinear_eye_vals<PB_KIND_EYE_R>(P, &entry, entry.flags, X0, Y0, lane, win, windows, src, a);
         const bool by_row = WMODE == 1 && (fl0 & PB_TILE_W_ROW) != 0;
         const bool by_lat = WMODE == 2 && (fl0 & PB_TILE_W_LAT) != 0;
@@ -581,10 +585,13 @@ __global__ void pb_bilinear_tile_list_kernel(const PbTileEntry* __restrict__ tab
                                              int32_t* __restrict__ list, unsigned* __restrict__ count) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
-    const int fl = table_l[t].flags, fr = table_r[t].flags;
+    // (single-source plans: table_r == nullptr, and only COARSE tiles are listed - the single-source bilinear kernel serves
+    // generic tiles itself)
+    const int fl = table_l[t].flags, fr = table_r ? table_r[t].flags : 0;
     const int served = PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK;
     if ((fl | fr) & PB_TILE_FAILED) return;  // on the fail list already
-    if (!(fl & served) || !(fr & served)) list[atomicAdd(count, 1u)] = (int32_t)t;
+    const bool coarse = ((fl | fr) & PB_TILE_COARSE) != 0;
+    if (coarse || (table_r && (!(fl & served) || !(fr & served)))) list[atomicAdd(count, 1u)] = (int32_t)t;
 }
 
 // behind pb_bilinear_double_hot_kernel: the plan's failed tiles and the tiles of the list above (4 blocks each), then the fix

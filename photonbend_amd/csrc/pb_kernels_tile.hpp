@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, 
         const bool solo_r = solo_ok && !solo_l && (fl & PB_TILE_BLACK) && (fr & plain);
         if (solo_l || solo_r) {
             if (solo_r) w = wr;
-            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK)) | PB_TILE_SOLO | (solo_r ? PB_TILE_EYE_R : 0);
+            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK | PB_TILE_COARSE)) | PB_TILE_SOLO | (solo_r ? PB_TILE_EYE_R : 0);
         } else {
             w = 0;
         }
@@ -1088,12 +1088,29 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const Pb
         PbRowModel R;
         pb_model_row(P, e, X0, Y0, y, xh, R);
         bool lean_ok = true;
+        double coarse = 0.0;  // largest |model - faithful| pre-truncation coordinate over this lane's sampled pixels, px
         for (int k = 0; k < 16; ++k) {
             const int j = X0 + xh + k;
             if (i < P.dst.height && j < P.dst.width) {
                 const int fast = pb_model_px<SRC_KIND>(P, R, xh, k);
-                const int exact = pb_exact_index<SRC_KIND>(P, i, j);
+                PbCoord cc = pb_dst_coord(P, i, j);
+                for (int r = 0; r < P.n_rot; ++r) cc = pb_rotate(P.R[r], cc);
+                const int exact = pb_exact_index_of<SRC_KIND>(P, cc);
                 diff |= (unsigned)(fast != exact) << k;
+                if (exact >= 0) {  // (what the bilinear mode needs to know: PB_TILE_COARSE)
+                    double f0, f1;
+                    pb_src_pretrunc<SRC_KIND>(P, cc, f0, f1);
+                    int mr, mc;
+                    pb_f2 mf;
+                    pb_model_px_raw(R, xh, k, mr, mc, mf);
+                    double d0 = fabs(((double)R.anchor_r + (double)mf.x) - f0), d1 = fabs(((double)R.anchor_c + (double)mf.y) - f1);
+                    if (SRC_KIND == PB_KIND_PANO) {  // the model runs on across the seam (columns) and the pole row
+                        d0 = fmin(d0, fabs(d0 - (double)P.src.height));
+                        d1 = fmin(d1, fabs(d1 - (double)P.src.width));
+                    }
+                    const double dm = fmax(d0, d1);
+                    coarse = (dm == dm) ? fmax(coarse, dm) : 1.0;
+                }
                 if (lean && !pb_row_px_invalid(R, k)) {  // (a MASKED tile's invalid pixels are never sampled: the hot path masks them)
                     const pb_f2 f = pb_eval_row(R.a, pb_tile_coord(xh + k));
                     lean_ok = lean_ok && f.x >= 0.0f && f.y >= 0.0f && (int)f.x < e->win_rows && (int)f.y < e->win_cols;
@@ -1115,6 +1132,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const Pb
             atomicAdd(&counters[(e->flags & PB_TILE_LEAN) ? 4 : 6], 1u);
         }
         if (lane == 0 && (e->flags & PB_TILE_BLACK)) atomicAdd(&counters[5], 1u);
+        if (__builtin_amdgcn_ballot_w64(coarse > PB_COARSE_PX) != 0 && lane == 0) e->flags |= PB_TILE_COARSE;
         unsigned total = (unsigned)pb_wave_sum((int)__popc(diff));
         if (lane == 0) {
             atomicAdd(&counters[2], total);

@@ -43,6 +43,12 @@
 // 3.8 us of a 41.5 us launch - experiments/session_r3_k.sh).
 #define PB_TILE_MASKED 1024
 #define PB_TILE_EYE_R 2048  // launch-order table of a double-fisheye plan only: a SOLO entry that is the RIGHT eye's (the bilinear mode clamps taps to the eye)
+// COARSE: somewhere on a sampled pixel the model's coordinate is more than PB_COARSE_PX from the faithful pre-truncation
+// coordinate (a 32-px tile of a SMALL image spans tens of degrees; the edge of a lens's domain).  Harmless for the reference's
+// nearest sampling - the fix list holds every pixel whose truncation differs - but the opt-in bilinear mode interpolates AT the
+// coordinate: it leaves such tiles to its float64 pass (pb_certify_kernel measures, the bilinear kernels obey).
+#define PB_TILE_COARSE 4096
+#define PB_COARSE_PX 0x1p-10  // 1/1024 px: at most half an LSB of a channel on the steepest possible content
 #define PB_TILE_W_UNIT_BIT 64  // == PB_TILE_W_UNIT (pb_kernels_double.hpp): blend factors exactly 1.0 for every pixel of the tile
 #define PB_LEAN_MAX_PASSES 24  // window rows / rows-per-load-instruction of a LEAN tile (register staging depth)
 
@@ -93,12 +99,16 @@ __device__ __forceinline__ void pb_chain_real(const PbParams& P, double fi, doub
 
 // faithful chain at an integer pixel -> source index (-1 = black); THE reference path
 template <int SRC_KIND>
-__device__ __forceinline__ int pb_exact_index(const PbParams& P, int i, int j) {
-    PbCoord c = pb_dst_coord(P, i, j);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+__device__ __forceinline__ int pb_exact_index_of(const PbParams& P, const PbCoord& c) {
     if (SRC_KIND == PB_KIND_EYE_L) return pb_src_double_taps(P, c).il;
     if (SRC_KIND == PB_KIND_EYE_R) return pb_src_double_taps(P, c).ir;
     return (SRC_KIND == PB_KIND_PANO) ? pb_src_pano_index(P, c) : pb_src_camera_index(P, c);
+}
+template <int SRC_KIND>
+__device__ __forceinline__ int pb_exact_index(const PbParams& P, int i, int j) {
+    PbCoord c = pb_dst_coord(P, i, j);
+    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    return pb_exact_index_of<SRC_KIND>(P, c);
 }
 
 // ---- the hot-path model evaluation (float32, bit-reproducible) ----------------------

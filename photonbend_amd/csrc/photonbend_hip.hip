@@ -61,7 +61,7 @@ struct pb_plan {
     int32_t* saved_r = nullptr;
     // the hot kernel's launch-order copy of `table` (rebuilt with every budget change; derived, never serialized)
     PbTileEntry* ltable = nullptr;
-    int32_t* bil_tiles = nullptr;  // double-fisheye plans: tiles the bilinear tile kernel leaves to the float64 pass (an eye sees them, not plain for it)
+    int32_t* bil_tiles = nullptr;  // tiles the bilinear tile kernels leave to the float64 pass: PB_TILE_COARSE models; double-fisheye plans also tiles an eye sees but that are not plain for it
     unsigned n_bil_tiles = 0;
     PbParams* P_dev = nullptr;   // device copy of P as the hot launches see it (refreshed with every budget change)
     unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
@@ -170,7 +170,7 @@ static bool pb_fast_possible(const PbParams& P) {
            P.src.height < (1 << 24);
 }
 
-// double-fisheye plans: the bilinear mode's float64 tile list (pb_bilinear_tile_list_kernel); derived state, not serialized
+// the bilinear mode's float64 tile list (pb_bilinear_tile_list_kernel); derived state, not serialized
 static int pb_build_bilinear_list(pb_plan* pl) {
     unsigned* cnt = nullptr;
     (void)hipFree(pl->bil_tiles);
@@ -325,6 +325,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                 if (hipDeviceSynchronize() != hipSuccess) { rc = PB_ERR_HIP; break; }
             }
         }
+        if (pb_build_bilinear_list(pl) != PB_OK) { rc = PB_ERR_HIP; break; }
         pl->fast_ready = 1;
     } while (0);
     if (rc != PB_OK) {
@@ -888,6 +889,10 @@ int pb_plan_dst_shape(const pb_plan* plan, int* height, int* width) {
     *width = plan->P.dst.width;
     return PB_OK;
 }
+int pb_plan_bilinear_float64_tiles(const pb_plan* plan) {
+    if (!plan || !(plan->fast_ready || plan->dbl_ready)) return 0;
+    return (int)(plan->n_fail_tiles + (plan->bil_tiles ? plan->n_bil_tiles : 0u));
+}
 int pb_plan_window_budget(const pb_plan* plan) {
     return (plan && (plan->fast_ready || plan->dbl_ready)) ? plan->P.win_budget : 0;
 }
@@ -1015,7 +1020,7 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         PB_HIP(hipGetLastError());
         return PB_OK;
     }
-    if (pb_use_fast(plan) && plan->ltable && plan->launch_groups > 0) {
+    if (pb_use_fast(plan) && plan->ltable && plan->launch_groups > 0 && plan->bil_tiles) {
         // launched like the nearest hot kernel: the plan's launch-order table, frames of a batch as a grid dimension;
         // LEAN tiles take their taps from LDS windows, except for frames LDS-DMA cannot address (not 16-byte aligned)
         const unsigned gpf = plan->launch_groups;
@@ -1031,10 +1036,12 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
                                src_dev + (unsigned long long)f0 * src_frame_stride, dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, \
                                (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows);                 \
         }                                                                                                                            \
-        if (plan->n_fail_tiles || plan->n_fix_px)                                                                                    \
-            hipLaunchKernelGGL(pb_bilinear_fix_kernel<KIND>, dim3(4u * plan->n_fail_tiles + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK),  \
+        const unsigned n64 = plan->n_fail_tiles + (plan->bil_tiles ? plan->n_bil_tiles : 0u); /* failed + coarse tiles */          \
+        if (n64 || plan->n_fix_px)                                                                                                   \
+            hipLaunchKernelGGL(pb_bilinear_fix_kernel<KIND>, dim3(4u * n64 + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK),            \
                                dim3(PB_BLOCK), 0, st, P, plan->fail_tiles, 0, src_dev, dst_dev, n_frames, src_frame_stride,          \
-                               dst_frame_stride, (int)plan->n_fail_tiles, plan->fix_px, (int)plan->n_fix_px);                        \
+                               dst_frame_stride, (int)n64, plan->fix_px, (int)plan->n_fix_px, plan->bil_tiles,                       \
+                               (int)plan->n_fail_tiles);                                                                             \
     } while (0)
         if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_BILINEAR(PB_KIND_PANO);
         else PB_LAUNCH_BILINEAR(PB_KIND_CAMERA);
@@ -1294,7 +1301,7 @@ struct PbBlobHeader {
     uint64_t checksum;  // of everything after the header
 };
 const uint32_t PB_BLOB_MAGIC = 0x4C504250u;  // "PBPL"
-const uint32_t PB_BLOB_VERSION = 3;
+const uint32_t PB_BLOB_VERSION = 4;  // 4: tile flags carry PB_TILE_COARSE
 
 struct PbSection {
     void** ptr;
@@ -1438,7 +1445,7 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
         pb_plan_destroy(pl);
         return pb_fail(PB_ERR_HIP, "plan upload failed: parameter block");
     }
-    if (pl->dbl_ready && pb_build_bilinear_list(pl) != PB_OK) {
+    if ((pl->dbl_ready || pl->fast_ready) && pb_build_bilinear_list(pl) != PB_OK) {
         pb_plan_destroy(pl);
         return PB_ERR_HIP;
     }
