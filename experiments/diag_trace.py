@@ -85,4 +85,9 @@ if True:
         print('XCD %d: %5d tiles (%5d black) first start %.1f last start %.1f last end %.1f us; busy wave-us %.0f' % (
             x, int(m.sum()), int((m & classes['BLACK']).sum()), us(starts[m].min() - t0), us(starts[m].max() - t0), us(ends[m].max() - t0), us((ends[m] - starts[m]).sum())))
 if os.environ.get('PB_TRACE_SAVE'):
-    np.savez_compressed(os.environ['PB_TRACE_SAVE'], T=T, table=np.frombuffer(tab, dtype=np.int32).reshape(nt, 64))
+    extra = {}
+    if case.src[0] == 'double':
+        tab_r = (ctypes.c_int32 * (nt * 64))()
+        if lib.pb_debug_copy_table_r(plan.handle, tab_r, nt * 256) == 0:
+            extra['table_r'] = np.frombuffer(tab_r, dtype=np.int32).reshape(nt, 64)
+    np.savez_compressed(os.environ['PB_TRACE_SAVE'], T=T, table=np.frombuffer(tab, dtype=np.int32).reshape(nt, 64), **extra)

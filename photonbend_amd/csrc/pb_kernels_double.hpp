@@ -65,16 +65,29 @@ __device__ __forceinline__ PbDesc pb_desc_of_lanes(unsigned v) {
     return d;
 }
 
-// pb_collapse_row on a lane-held entry: the same packed FMAs on the same values, hence the same bits
-__device__ __forceinline__ void pb_collapse_row_lanes(unsigned v, int y, pb_f2 a[5]) {
-    const float t = pb_tile_coord(y);
+// The 25 coefficient pairs of a lane-held entry as scalars: ONE v_readlane each.  (Reading them inside pb_collapse_row_lanes, once
+// per row group, left 200 v_readlane per eye in the ISA - 70 % of the collapse's instructions; the two-eye tiles of c5 spent
+// 5 us of their 13.5 us life in the model math: experiments/session_r3_ab.sh.)
+struct PbCoefs {
+    float c[50];
+};
+__device__ __forceinline__ PbCoefs pb_coefs_of_lanes(unsigned v) {
+    PbCoefs K;
     const int c0 = PB_E_DWORD(c);
 #pragma unroll
+    for (int n = 0; n < 50; ++n) K.c[n] = pb_lane_f(v, c0 + n);
+    return K;
+}
+
+// pb_collapse_row on a lane-held entry: the same packed FMAs on the same values, hence the same bits
+__device__ __forceinline__ void pb_collapse_row_lanes(const PbCoefs& K, int y, pb_f2 a[5]) {
+    const float t = pb_tile_coord(y);
+#pragma unroll
     for (int n = 0; n < 5; ++n) {
-        pb_f2 s = {pb_lane_f(v, c0 + 2 * (20 + n)), pb_lane_f(v, c0 + 2 * (20 + n) + 1)};
+        pb_f2 s = {K.c[2 * (20 + n)], K.c[2 * (20 + n) + 1]};
 #pragma unroll
         for (int m = 3; m >= 0; --m) {
-            const pb_f2 cm = {pb_lane_f(v, c0 + 2 * (m * 5 + n)), pb_lane_f(v, c0 + 2 * (m * 5 + n) + 1)};
+            const pb_f2 cm = {K.c[2 * (m * 5 + n)], K.c[2 * (m * 5 + n) + 1]};
             s = pb_fma2(s, t, cm);
         }
         a[n] = s;
@@ -132,10 +145,11 @@ __device__ __forceinline__ void pb_d_math(const PbParams& P, const PbDesc& D, co
         const bool lean = (D.flags & PB_TILE_LEAN) != 0;
         const unsigned pitch = lean ? 16u * (unsigned)D.win_n16 : C.rowbytes;
         const unsigned off = lean ? (unsigned)D.win_a0 : (unsigned)D.anchor_r * C.rowbytes + 3u * (unsigned)D.anchor_c;
+        const PbCoefs K = pb_coefs_of_lanes(ve);
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) {
             pb_f2 a[5];
-            pb_collapse_row_lanes(ve, C.yb + 8 * jr, a);
+            pb_collapse_row_lanes(K, C.yb + 8 * jr, a);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const pb_f2 fv = pb_eval_row(a, C.u[k]);

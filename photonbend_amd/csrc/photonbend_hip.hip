@@ -1091,6 +1091,11 @@ __attribute__((visibility("default"))) int pb_debug_trace_frame(const pb_plan* p
     if (hipMemcpyToSymbol(HIP_SYMBOL(pb_trace_wpf), &wpf, sizeof(wpf)) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(pb_trace_frame), &f, sizeof(f)) == hipSuccess ? 0 : -1;
 }
+__attribute__((visibility("default"))) int pb_debug_copy_table_r(const pb_plan* plan, void* host, size_t bytes) {  // the right eye's table of a double-fisheye plan
+    if (!plan || !plan->table_r) return -1;
+    const size_t have = (size_t)plan->n_tiles * sizeof(PbTileEntry);
+    return hipMemcpy(host, plan->table_r, bytes < have ? bytes : have, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
 __attribute__((visibility("default"))) int pb_debug_copy_table(const pb_plan* plan, void* host, size_t bytes) {
     if (!plan || !plan->table) return -1;
     const size_t have = (size_t)plan->n_tiles * sizeof(PbTileEntry);
