@@ -57,6 +57,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# The frames a rank rotates through must be COLD: 1.25 GiB, five times the 256 MB Infinity Cache.  With 1.4 x (round 1-3's 320 MB
+# rule in the `configs` block) the cache still served part of every frame: c1 12.3 us instead of 16.2, c3 29.5 instead of 33
+# (experiments/session_r3_ai.sh; c2 and c5 were not affected).
+POOL_BYTES_MIN = 1280 << 20
 
 # name -> geometry (degrees; magnitude as the CLI computes it), pool = frames resident per GPU,
 # pin = the entry of tests/golden/full.json that holds the reference's algorithmic bytes for the geometry
@@ -255,7 +259,7 @@ def byte_accounting(plan, src_hw, device):
     return out_bytes + 3 * int(valid.numel()), out_bytes + LINE * int(touched.sum().item())
 
 
-def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0, pool_bytes=320 << 20, bilinear=False):
+def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0, pool_bytes=0, bilinear=False):
     """One config measured like the headline, inside this process: its plan at the pinned budget, a pool of distinct frames
     larger than the 256 MiB Infinity Cache, `steps` launches in groups of 4 between HIP event pairs on the launch stream.
     Returns the entry of the line's ``configs`` block."""
@@ -272,7 +276,7 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
     plan_ms = (time.perf_counter() - t0) * 1e3
     sh, sw, dh, dw = s.height, s.width, d.height, d.width
     sbytes, dbytes = 3 * sh * sw, 3 * dh * dw
-    pool = max(2 * batch, pool_bytes // (sbytes + dbytes) + 1)
+    pool = max(2 * batch, (pool_bytes or POOL_BYTES_MIN) // (sbytes + dbytes) + 1)
     pool = (pool + batch - 1) // batch * batch
     srcs = torch.empty((pool, sh, sw, 3), dtype=torch.uint8, device=device)
     for f in range(pool):
@@ -325,6 +329,10 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
         raise SystemExit(f"bench.py: {name}: algorithmic bytes from the plan's index map ({alg}) differ from the reference's ({ref_alg})")
     per_frame_ms = float(np.mean(durs))
     info = plan.info()
+    wall = {}
+    if batch == 1:
+        for n in (1, 2, 3):
+            wall[str(n)] = round(multi_stream_ms(fn, h, sp0, dp0, sbytes, dbytes, pool, batch, device, n), 5)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", f"traffic_{name}_{info['window_budget']}.json")
     if os.path.exists(tpath):
@@ -353,6 +361,8 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
         "window_budget": info["window_budget"],
         "launches_timed": n_groups * every,
     }
+    if wall:
+        out["wall_ms_per_frame_by_streams"] = wall
     del srcs, dsts, plan
     torch.cuda.empty_cache()
     return out
@@ -388,6 +398,31 @@ def headline_extras(lib, nat, d, rots, s, cfg, device, stream, budget):
     lib.pb_event_destroy(e1)
     return round(single_ms, 3), round(ms.value / 8, 5)
 
+
+
+def multi_stream_ms(fn, handle, sp0, dp0, sbytes, dbytes, n_pool, batch, device, n_streams, launches=120):
+    """Wall-clock ms per frame of `launches` independent launches dealt round-robin to n_streams HIP streams (device drained
+    before and after): the next launch's ramp runs in the previous one's drain.  A per-kernel duration is not defined there -
+    the kernels overlap - so this is reported NEXT to the single-stream figures the roofline block is computed from."""
+    import torch
+
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+    sts = [int(x.cuda_stream) for x in streams]
+    groups = n_pool // batch
+
+    def go(n):
+        for k in range(n):
+            i = (k % groups) * batch
+            rc = fn(handle, sp0 + i * sbytes, dp0 + i * dbytes, batch, sbytes, dbytes, sts[k % n_streams])
+            if rc:
+                raise RuntimeError(f"launch failed: {rc}")
+
+    go(2 * n_streams + 8)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    go(launches)
+    torch.cuda.synchronize(device)
+    return (time.perf_counter() - t0) * 1e3 / (launches * batch)
 
 
 def graph_replay_ms(lib, nat, plan, srcs, dsts, sbytes, dbytes, n_pool, device, launches=8, replays=25):
@@ -463,7 +498,7 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     cfg = CONFIGS[args.config]
     batch = args.batch or cfg["batch"]
-    pool = args.pool or cfg["pool"]
+    pool = args.pool or max(cfg["pool"], POOL_BYTES_MIN // (3 * (cfg["src"][1] * cfg["src"][2] + cfg["dst"][1] * cfg["dst"][2])) + 1)
     pool = max(batch, (pool // batch) * batch)  # launches take `batch` consecutive frames of the pool
     budget = args.budget or BENCH_BUDGET[args.config]
 
@@ -668,6 +703,14 @@ def main():
             except Exception as exc:  # a measurement extra: never fail the line over it
                 line["graph_replay_ms_per_frame"] = None
                 line["graph_replay_note"] = repr(exc)
+            try:
+                line["wall_ms_per_frame_by_streams"] = {str(n): round(multi_stream_ms(remap_fn, h, sp0, dp0, sbytes, dbytes, pool, batch, device, n), 5) for n in (1, 2, 3, 4)}
+                line["wall_ms_per_frame_by_streams_note"] = ("120 independent single-frame launches dealt round-robin to N HIP streams, wall clock between two device syncs: "
+                                                             "with N >= 2 the next launch's ramp runs in the previous one's drain (the C ABI takes the stream per call; "
+                                                             "`value` and `roofline` above are the single-stream figures, where a per-kernel duration is defined)")
+            except Exception as exc:
+                line["wall_ms_per_frame_by_streams"] = None
+                line["wall_ms_per_frame_by_streams_note"] = repr(exc)
             del srcs, dsts
             torch.cuda.empty_cache()
             single_ms, faithful_ms = headline_extras(lib, nat, d, rots, s, cfg, device, sts[0], budget)

@@ -20,7 +20,7 @@ for spec in sys.argv[2:]:
     d, rots, s = bench.build_projs(cfg)
     plan = nat.Plan(d, rots, s, budget=budget)
     sb, db = 3 * s.height * s.width, 3 * d.height * d.width
-    pool = max(2 * batch, int((320 << 20) // (sb + db)) + 1)
+    pool = max(2 * batch, int((int(os.environ.get('PB_POOL_MB', '1280')) << 20) // (sb + db)) + 1)  # PB_POOL_MB: bytes of frames rotated (default 1280 MB = 5 x the 256 MB Infinity Cache; 320 MB left c1 / c3 partly cached)
     pool = (pool + batch - 1) // batch * batch
     srcs = torch.empty((pool, s.height, s.width, 3), dtype=torch.uint8, device=dev)
     for f in range(pool): nat.synth_frame(s.height, s.width, frame=f, seed=0, circle_mask=cfg['mask'], out=srcs[f])
@@ -40,7 +40,7 @@ for spec in sys.argv[2:]:
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3 / 40 / batch)
     i = plan.info()
-    print('%-22s %-8s batch %2d budget %5d : median %7.2f us/frame  (min %7.2f max %7.2f)  lean %5d direct %5d packed %5d black %5d fail %4d' % (
-        os.path.basename(lib), spec, batch, i['window_budget'], float(np.median(ts)), min(ts), max(ts), i['lean_tiles'], i['direct_tiles'], i.get('packed_tiles', 0), i['black_tiles'], i['fix_tiles']), flush=True)
+    print('%-22s %-8s pool %3d batch %2d budget %5d : median %7.2f us/frame  (min %7.2f max %7.2f)  lean %5d direct %5d packed %5d black %5d fail %4d' % (
+        os.path.basename(lib), spec, pool, batch, i['window_budget'], float(np.median(ts)), min(ts), max(ts), i['lean_tiles'], i['direct_tiles'], i.get('packed_tiles', 0), i['black_tiles'], i['fix_tiles']), flush=True)
     del srcs, dsts, plan
     torch.cuda.empty_cache()

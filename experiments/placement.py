@@ -15,7 +15,7 @@ batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 cfg = bench.CONFIGS[name]
 d, rots, s = bench.build_projs(cfg)
 sb, db = 3 * s.height * s.width, 3 * d.height * d.width
-pool = max(2 * batch, int((320 << 20) // (sb + db)) + 1)
+pool = max(2 * batch, int((1280 << 20) // (sb + db)) + 1)
 pool = (pool + batch - 1) // batch * batch
 st = nat.current_stream()
 

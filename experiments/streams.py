@@ -8,7 +8,7 @@ L = nat.load()
 cfg = bench.CONFIGS[sys.argv[1]]
 d, rots, s = bench.build_projs(cfg)
 sb, db = 3 * s.height * s.width, 3 * d.height * d.width
-pool = int((320 << 20) // (sb + db)) + 1
+pool = int((1280 << 20) // (sb + db)) + 1
 plan = nat.Plan(d, rots, s)
 srcs = torch.empty((pool, s.height, s.width, 3), dtype=torch.uint8, device='cuda')
 for f in range(pool): nat.synth_frame(s.height, s.width, frame=f, seed=0, circle_mask=cfg['mask'], out=srcs[f])

@@ -235,7 +235,12 @@ __device__ __forceinline__ void pb_issue_window_loads(const uint8_t* __restrict_
 }
 
 // One tile of the windowed hot kernel (the four tile classes); returns when the tile's pixels are stored.
-template <int SRC_KIND, bool NT = (SRC_KIND == PB_KIND_CAMERA)>
+#ifdef PB_PLAIN_STORES  // A/B builds only (experiments/session_r3_aj.sh): plain stores for every source kind
+#define PB_NT_DEFAULT(kind) false
+#else
+#define PB_NT_DEFAULT(kind) ((kind) == PB_KIND_CAMERA)
+#endif
+template <int SRC_KIND, bool NT = PB_NT_DEFAULT(SRC_KIND)>
 __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbHot& Hd, const PbTileEntry* __restrict__ e, const int flags, const int tx,
                                             const int ty, const int lane, unsigned* win, const uint8_t* __restrict__ src,
                                             uint8_t* __restrict__ dst, const int n_frames, const unsigned long long src_stride,
@@ -659,7 +664,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
                                                                          unsigned long long dst_stride,
                                                                          const int32_t* __restrict__ idx_tab,
                                                                          const int32_t* __restrict__ fix_px,
-                                                                         const int32_t* __restrict__ fix_idx) {
+                                                                         const int32_t* __restrict__ fix_idx, const unsigned n_frames,
+                                                                         const unsigned ilv) {
     const PbParams& P = *Pp;
     // every kernel argument the tile prologue needs, in one scalar round trip (the compiler would otherwise fetch
     // the table pointer only after the tile index is known: a second dependent trip per wave)
@@ -676,6 +682,14 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
 #endif
     unsigned wg = blockIdx.x;
     const unsigned wgs_per_frame = groups_per_frame * (4u / wpw);
+#ifdef PB_ABLATION  // PB_ILV=G: the frames of a batch progress TOGETHER - G workgroups of frame 0, the same G of frame 1, ... (G a multiple of 8 dividing a frame's share)
+    if (ilv && n_frames > 1 && wgs_per_frame % ilv == 0) {
+        const unsigned span = ilv * n_frames, chunk = wg / span, rem = wg - chunk * span, f = rem / ilv;
+        wg = chunk * ilv + (rem - f * ilv);
+        src += (unsigned long long)f * src_stride;
+        dst += (unsigned long long)f * dst_stride;
+    } else
+#endif
     if (wg >= wgs_per_frame) {  // a batch: which frame
         const unsigned f = wg / wgs_per_frame;
         wg -= f * wgs_per_frame;

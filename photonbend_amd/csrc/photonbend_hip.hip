@@ -366,6 +366,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
         const size_t lds = pb_window_lds_bytes(P) / PB_TILE_WAVES * wpw + (size_t)pb_knob("PB_LDS_PAD", 0);  // (the pad: occupancy experiments, -DPB_ABLATION only)
         const unsigned wpf = gpf * (4u / wpw);
         const int per_launch = (int)(0x7FFFFFFFu / wpf);  // grid limit: absurdly long batches go in several launches
+        static const unsigned ilv = (unsigned)pb_knob("PB_ILV", 0);  // experiments: frames of a batch interleaved every `ilv` workgroups (0: frame-major)
         for (int f0 = 0; f0 < n_frames; f0 += per_launch) {
             const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;
             const dim3 bgrid(wpf * (unsigned)nf);
@@ -373,7 +374,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
             uint8_t* df = dst + (unsigned long long)f0 * ds;
 #define PB_LAUNCH_WIN(KIND)                                                                                                   \
     hipLaunchKernelGGL((pb_hot_win_kernel<KIND>), bgrid, wblock, lds, st, (const PbParams*)pl->P_dev, pb_hot_of_host(P), pl->ltable, sf, df, gpf, ss, ds, pl->idx_tab, \
-                       pl->fix_px, pl->fix_idx)
+                       pl->fix_px, pl->fix_idx, (unsigned)nf, ilv)
             if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_WIN(PB_KIND_PANO);
             else PB_LAUNCH_WIN(PB_KIND_CAMERA);
         }

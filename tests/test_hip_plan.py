@@ -105,6 +105,34 @@ def test_streaming_batch_overlaps_and_matches():
     assert list(batch.remap_frames(plan, iter([]))) == []
 
 
+CONCURRENT_CASES = [
+    Case("k_c2like", cam(1024, 1024, "equidistant", 360, inscribed(1024)), pano(1024, 2048)),
+    Case("k_rim", cam(768, 768, "equisolid", 360, inscribed(768)), cam(768, 768, "equidistant", 360, inscribed(768)), [(30, 45, 10)]),
+    Case("k_double", pano(768, 1536), dbl(960, 1920, "equidistant", 195), [(3, 90, -7)]),
+]
+
+
+@pytest.mark.parametrize("case", CONCURRENT_CASES, ids=[c.name for c in CONCURRENT_CASES])
+def test_one_plan_on_several_streams_at_once(case):
+    """Independent frames dealt round-robin to three HIP streams (bench.py: wall_ms_per_frame_by_streams - the next launch's ramp
+    runs in the previous one's drain): launches of ONE plan overlap on the device and every output equals the serial one."""
+    plan = H.pb_plan(case)
+    lib = nat.load()
+    _, h, w, *_ = case.src
+    n = 12
+    frames = torch.stack([nat.synth_frame(h, w, frame=f, circle_mask=case.mask) for f in range(n)])
+    want = torch.stack([plan.remap(frames[f]) for f in range(n)])
+    got = torch.zeros_like(want)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    sb, db = frames[0].numel(), want[0].numel()
+    for rep in range(3):
+        for f in range(n):
+            nat.check(lib.pb_remap_u8(plan.handle, frames.data_ptr() + f * sb, got.data_ptr() + f * db, 1, 0, 0, int(streams[f % 3].cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
 GRAPH_CASES = [
     Case("g_pano", cam(256, 256, "equidistant", 360, inscribed(256)), pano(256, 512), [(5, 10, 15)]),
     # a rim of failed tiles (360-degree equisolid destination): served from the plan's exact-index tables
