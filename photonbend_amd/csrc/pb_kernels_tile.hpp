@@ -771,17 +771,18 @@ __global__ void pb_budget_kernel(PbTileEntry* __restrict__ table, const int32_t*
 __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
                                                               PbTileEntry* __restrict__ ltable, const int* __restrict__ unit_of,
                                                               int units_per_xcd, unsigned n_slots, int unit_side,
-                                                              const PbTileEntry* __restrict__ table_r = nullptr) {
+                                                              const PbTileEntry* __restrict__ table_r = nullptr, int unit_side_y = 0) {
     const unsigned v = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (v >= n_slots) return;
     const unsigned B = v >> 2, wave = v & 3u;
     const int gx = (pb_tiles_x(P) + 1) / 2, gy = (pb_tiles_y(P) + 1) / 2;
     long long group = B;
     if (unit_of) {
-        const unsigned U = (unsigned)unit_side, xcd = B & 7u, slot = B >> 3, k = slot / (U * U), inner = slot - k * U * U;
+        // a unit is U x UY workgroups (UY = U unless the caller says otherwise), walked row by row
+        const unsigned U = (unsigned)unit_side, UY = unit_side_y ? (unsigned)unit_side_y : U, xcd = B & 7u, slot = B >> 3, k = slot / (U * UY), inner = slot - k * U * UY;
         const int S = (int)k < units_per_xcd ? unit_of[xcd * units_per_xcd + k] : -1;
         const int sgx = gx / (int)U;
-        group = S < 0 ? -1 : (long long)((S / sgx) * (int)U + (int)(inner / U)) * gx + (S % sgx) * (int)U + (int)(inner % U);
+        group = S < 0 ? -1 : (long long)((S / sgx) * (int)UY + (int)(inner / U)) * gx + (S % sgx) * (int)U + (int)(inner % U);
     }
     int tx = -1, ty = -1;
     if (group >= 0 && group < (long long)gx * gy) {
@@ -829,13 +830,14 @@ __device__ __forceinline__ float pb_tile_cost(const PbTileEntry& e) {
 // A wave's measured life (experiments/diag_trace.py): 3 us on a black tile, 4.2 + 0.4 per KiB of window on a window tile,
 // 9.5 + 0.03 per source column on a direct-gather tile - here relative to a direct-gather tile of ordinary width.
 __global__ void pb_unit_cost_kernel(const PbTileEntry* __restrict__ table, unsigned n_tiles, unsigned tiles_x, unsigned unit_tiles,
-                                    unsigned units_x, unsigned* __restrict__ unit_cost, const PbTileEntry* __restrict__ table_r = nullptr) {
+                                    unsigned units_x, unsigned* __restrict__ unit_cost, const PbTileEntry* __restrict__ table_r = nullptr,
+                                    unsigned unit_tiles_y = 0) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     float c = pb_tile_cost(table[t]);
     if (table_r) c += pb_tile_cost(table_r[t]) - 0.3f;  // double-fisheye source: both eyes' work (a one-eye tile costs its live eye's)
     const unsigned ty = t / tiles_x, tx = t - ty * tiles_x;
-    atomicAdd(&unit_cost[(ty / unit_tiles) * units_x + tx / unit_tiles], (unsigned)(c * 1024.0f + 0.5f));
+    atomicAdd(&unit_cost[(ty / (unit_tiles_y ? unit_tiles_y : unit_tiles)) * units_x + tx / unit_tiles], (unsigned)(c * 1024.0f + 0.5f));
 }
 __global__ void pb_save_flags_kernel(const PbTileEntry* __restrict__ table, int32_t* __restrict__ saved, unsigned n_tiles) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;

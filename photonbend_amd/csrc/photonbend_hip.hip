@@ -436,15 +436,17 @@ static int pb_build_launch_table(pb_plan* pl) {
     const unsigned tiles_x = (P.dst.width + PB_TILE - 1) / PB_TILE, tiles_y = (P.dst.height + PB_TILE - 1) / PB_TILE;
     const unsigned gx = (tiles_x + 1) / 2, gy = (tiles_y + 1) / 2;
     static const unsigned U = [] { const int v = pb_knob("PB_UNIT", 4); return (v == 2 || v == 8 || v == 16) ? (unsigned)v : 4u; }();  // workgroups per unit side
-    const bool units = gx % U == 0 && gy % U == 0 && (gx / U) * (gy / U) >= 16u;
+    static const unsigned UYk = [] { const int v = pb_knob("PB_UNIT_Y", 0); return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? (unsigned)v : 0u; }();  // experiments: unit height in workgroups (0: square)
+    const unsigned UY = UYk ? UYk : U;
+    const bool units = gx % U == 0 && gy % UY == 0 && (gx / U) * (gy / UY) >= 16u;
     static const int order_mode = pb_knob("PB_ORDER", 0);
     std::vector<int> unit_of;
     int units_per_xcd = 0;
     unsigned n_groups = (gx * gy + 7u) & ~7u;
     if (units) {
-        const unsigned sgx = gx / U, sgy = gy / U, ns = sgx * sgy;
+        const unsigned sgx = gx / U, sgy = gy / UY, ns = sgx * sgy;
         units_per_xcd = (int)((ns + 7u) / 8u);
-        n_groups = 8u * (unsigned)units_per_xcd * U * U;
+        n_groups = 8u * (unsigned)units_per_xcd * U * UY;
         // the walk: rows of super-tiles top to bottom, XCD = position in the walk mod 8 (plain), unless the plan's tiles say
         // that work is unevenly spread - then the launch starts on its heaviest part and ENDS on its cheapest, which drains fast:
         //   rows differ (max / min > 1.45; a fisheye output's black-cornered edges against its dense centre, a panorama's
@@ -470,7 +472,7 @@ static int pb_build_launch_table(pb_plan* pl) {
             }
             (void)hipMemsetAsync(cost_dev, 0, ns * sizeof(unsigned), 0);
             hipLaunchKernelGGL(pb_unit_cost_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->n_tiles, tiles_x, 2u * U, sgx, cost_dev,
-                               pl->dbl_ready ? pl->table_r : nullptr);
+                               pl->dbl_ready ? pl->table_r : nullptr, 2u * UY);
             const hipError_t ce = hipMemcpy(fixed.data(), cost_dev, ns * sizeof(unsigned), hipMemcpyDeviceToHost);
             (void)hipFree(cost_dev);
             if (ce != hipSuccess) {
@@ -578,7 +580,7 @@ static int pb_build_launch_table(pb_plan* pl) {
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, fresh, unit_dev, units_per_xcd, n_slots, (int)U,
-                           pl->dbl_ready ? pl->table_r : nullptr);
+                           pl->dbl_ready ? pl->table_r : nullptr, (int)UY);
         e = hipDeviceSynchronize();
     }
     (void)hipFree(unit_dev);
