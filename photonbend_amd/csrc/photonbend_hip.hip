@@ -460,7 +460,7 @@ static int pb_build_launch_table(pb_plan* pl) {
         for (unsigned S = 0; S < ns; ++S) seq[S] = S;
         std::vector<float> unit_cost;
         bool row_walk = true;  // seq is a sequence of whole rows
-        const int walk = order_mode == 1 ? 1 : pl->walk;  // (PB_ORDER=1 forces the plain walk)
+        const int walk = (order_mode >= 1 && order_mode <= 3) ? order_mode : pl->walk;  // (PB_ORDER=1 / 2 / 3, diagnostic build: force the plain walk / rows outwards / heaviest first)
         if (walk != 1 && sgy >= 4 && (ns >= 128u || walk != 0)) {  // (fewer than 16 super-tiles per XCD: too coarse to reorder - a 3072x2048 output measured 3-4 % slower)
             std::vector<unsigned> fixed(ns, 0u);
             unsigned* cost_dev = nullptr;
