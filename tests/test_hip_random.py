@@ -92,6 +92,32 @@ def test_random_geometry_matches_oracle(case):
     assert int(bad.sum()) <= max(4, bad.size // 2000), f"{int(bad.sum())} fragile-set differences"
 
 
+@pytest.mark.parametrize("case", CASES[::3], ids=lambda c: f"{c.name}:{c.dst[0]}<-{c.src[0]}:r{len(c.rotations)}")
+def test_random_geometry_through_materialised_maps(case):
+    """The same geometries through the protocol's materialised float64 maps (pb_coordmap_f64 -> pb_rotate_f64 ... ->
+    pb_sample_map_u8, the path of users who look at or edit a map between the stages): the map handed over as an ndarray.
+    Same bar as above - the oracle's bytes outside the fragile set."""
+    od, os_ = H.orc_proj(case.dst), H.orc_proj(case.src)
+    rots = H.orc_rots(case)
+    frame = synth_frame(case.src[1], case.src[2], frame=7)
+    with np.errstate(all="ignore"):
+        want = orc.remap(od, os_, frame, rots)
+        fragile = orc.fragile_mask(orc.pretrunc(od, os_, rots))
+    src, cmap = H.pb_chain(case, frame)
+    arr = np.array(np.asarray(cmap))  # materialised on the GPU, downloaded
+    assert arr.dtype == np.float64 and arr.shape[:2] == want.shape[:2]
+    got = src.process_coordinate_map(arr)
+    if case.src[0] == "double":
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        d = np.minimum(d, 256 - d)
+        assert int(((d > 1).any(axis=2) & ~fragile).sum()) == 0, "a channel differs by more than 1 LSB outside the fragile set"
+        assert int((d > 0).any(axis=2).sum()) <= max(4, d.shape[0] * d.shape[1] // 500)
+        return
+    bad = (got != want).any(axis=2)
+    assert int((bad & ~fragile).sum()) == 0, f"{int((bad & ~fragile).sum())} pixels differ from the oracle outside the fragile set"
+    assert int(bad.sum()) <= max(4, bad.size // 500), f"{int(bad.sum())} fragile-set differences"
+
+
 # ---- the same random geometries at 8 x the size: hundreds of LEAN / DIRECT / failed tiles each, every launch path --------
 def scaled_case(k: int, scale: int = 8) -> Case:
     """random_case(5000 + k) with every image dimension (and magnitude) multiplied; half of the sources get a width that is
