@@ -170,56 +170,74 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(con
         return;
     }
     if ((flags & (PB_TILE_LEAN | PB_TILE_DIRECT)) && !(flags & PB_TILE_MASKED)) {  // (MASKED: invalid pixels inside - the guarded path below)
-        // the four taps straight from the frame, unguarded (the tile's bounding box, margin texel included, lies inside
-        // the frame with room for the last 4-byte read).  wide: an 8-byte load takes both taps of a row - allowed when
-        // even the box's last tap has 8 bytes of frame behind it; one row group's loads are in flight together
+        // The four taps straight from the frame, unguarded (the tile's bounding box, margin texel included, lies inside the
+        // frame with room for the last 4-byte read).  wide: an 8-byte load takes both taps of a row - allowed when even the
+        // box's last tap has 8 bytes of frame behind it.  The gathers run like the nearest mode's (pb_win_tile, DIRECT): lane =
+        // pixel column (or row), 16 pixels down the other direction, sheared along the line of constant source row, so that one
+        // load instruction touches few lines whatever the tile's orientation in the source; the blended pixels are regrouped
+        // for the 12-byte stores through the wave's LDS window.  Either evaluation order of the model is certified.
+        // (round 3: c2 118 -> see experiments/README.md; the row-group order it replaces issued 4 dependent rounds of loads
+        // whose 64 lanes touched up to 64 lines each.)
         const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
         const bool wide = gbase + (unsigned)(e->win_rows - 1) * rowbytes + 3u * (unsigned)(e->win_cols - 1) + 8u <= frame_bytes;
+        const bool along_x = fabsf(e->c[1][0]) <= fabsf(e->c[5][0]);  // |d row / du| <= |d row / dv|
+        const int p = lane & 31, hh = lane >> 5;
+        const float num = along_x ? e->c[1][0] : e->c[5][0], den = along_x ? e->c[5][0] : e->c[1][0];
+        const float slope = (den != 0.0f) ? -num / den : 0.0f;
+        const int shift = (int)rintf(slope * ((float)p - 15.5f));
+        pb_f2 cf[5];
+        if (along_x) pb_collapse_col(e, p, cf);
+        else pb_collapse_row(e, p, cf);
 #pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            pb_f2 c[5];
-            pb_collapse_row(e, yb + 8 * jr, c);
-            unsigned long long t8[4][2];
-            unsigned t[4][4];
-            float wy[4], wx[4];
+        for (int half = 0; half < 2; ++half) {  // 8 pixels' loads in flight together (16 x 8 bytes per lane)
+            unsigned long long t8[8][2];
+            unsigned t[8][4];
+            float wy[8], wx[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const pb_f2 fv = pb_eval_row(c, pb_tile_coord(4 * xg + k));
+            for (int m = 0; m < 8; ++m) {
+                const int n = 8 * half + m, q = (2 * n + hh + shift) & 31;
+                const pb_f2 fv = pb_eval_row(cf, pb_tile_coord(q));
                 const float sy = fv.x - 0.5f, sx = fv.y - 0.5f;
                 const float fy0 = floorf(sy), fx0 = floorf(sx);
-                wy[k] = sy - fy0;
-                wx[k] = sx - fx0;
+                wy[m] = sy - fy0;
+                wx[m] = sx - fx0;
                 const unsigned g = gbase + (unsigned)(int)fy0 * rowbytes + __umul24((unsigned)(int)fx0, 3u);
                 if (wide) {
-                    __builtin_memcpy(&t8[k][0], s + g, 8);
-                    __builtin_memcpy(&t8[k][1], s + g + rowbytes, 8);
+                    __builtin_memcpy(&t8[m][0], s + g, 8);
+                    __builtin_memcpy(&t8[m][1], s + g + rowbytes, 8);
                 } else {
-                    __builtin_memcpy(&t[k][0], s + g, 4);
-                    __builtin_memcpy(&t[k][1], s + g + 3u, 4);
-                    __builtin_memcpy(&t[k][2], s + g + rowbytes, 4);
-                    __builtin_memcpy(&t[k][3], s + g + rowbytes + 3u, 4);
+                    __builtin_memcpy(&t[m][0], s + g, 4);
+                    __builtin_memcpy(&t[m][1], s + g + 3u, 4);
+                    __builtin_memcpy(&t[m][2], s + g + rowbytes, 4);
+                    __builtin_memcpy(&t[m][3], s + g + rowbytes + 3u, 4);
                 }
             }
-            unsigned a[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int m = 0; m < 8; ++m) {
+                const int n = 8 * half + m, q = (2 * n + hh + shift) & 31;
                 if (wide) {
-                    t[k][0] = (unsigned)t8[k][0];
-                    t[k][1] = (unsigned)(t8[k][0] >> 24);
-                    t[k][2] = (unsigned)t8[k][1];
-                    t[k][3] = (unsigned)(t8[k][1] >> 24);
+                    t[m][0] = (unsigned)t8[m][0];
+                    t[m][1] = (unsigned)(t8[m][0] >> 24);
+                    t[m][2] = (unsigned)t8[m][1];
+                    t[m][3] = (unsigned)(t8[m][1] >> 24);
                 }
-                a[k] = pb_bilinear_mix(t[k][0], t[k][1], t[k][2], t[k][3], wx[k], wy[k]);
+                // park as [y][x] with a 33-dword pitch (the lane's pixel is (p, q) or (q, p))
+                win[along_x ? q * 33 + p : p * 33 + q] = pb_bilinear_mix(t[m][0], t[m][1], t[m][2], t[m][3], wx[m], wy[m]);
             }
+        }
+        pb_wave_sync();
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            const unsigned* r = win + (yb + 8 * jr) * 33 + 4 * xg;
             const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
             if ((((uintptr_t)d + off) & 3u) == 0) {
-                pb_store3<SRC_KIND == PB_KIND_CAMERA>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);
+                pb_store3<SRC_KIND == PB_KIND_CAMERA>(pb_pack_px4(r[0], r[1], r[2], r[3]), d + off);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
-                    d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
-                    d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
+                    d[off + 3 * k + 0] = (uint8_t)(r[k] & 0xFF);
+                    d[off + 3 * k + 1] = (uint8_t)((r[k] >> 8) & 0xFF);
+                    d[off + 3 * k + 2] = (uint8_t)((r[k] >> 16) & 0xFF);
                 }
             }
         }
