@@ -137,13 +137,25 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(con
     if ((flags & PB_TILE_LEAN) && windows) {  // (windows == 0: frames LDS-DMA cannot address)
         const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
         const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+        // the model is evaluated in the order the direct-gather path below uses for this tile (column-first when the source row
+        // changes least along x): the LDS budget moves a tile between the two paths and must not move a bit of its coordinates
         pb_f2 fv[4][4];
+        if (fabsf(e->c[1][0]) <= fabsf(e->c[5][0])) {
 #pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            pb_f2 a[5];
-            pb_collapse_row(e, yb + 8 * jr, a);
+            for (int k = 0; k < 4; ++k) {
+                pb_f2 b[5];
+                pb_collapse_col(e, 4 * xg + k, b);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) fv[jr][k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
+                for (int jr = 0; jr < 4; ++jr) fv[jr][k] = pb_eval_row(b, pb_tile_coord(yb + 8 * jr));
+            }
+        } else {
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                pb_f2 a[5];
+                pb_collapse_row(e, yb + 8 * jr, a);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fv[jr][k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
+            }
         }
         asm volatile("" ::: "memory");
         pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
@@ -433,13 +445,25 @@ __device__ __forceinline__ void pb_bilinear_eye_vals(const PbParams& P, const Pb
     if (inside && (flags & PB_TILE_LEAN) && windows) {
         const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
         const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+        // the model is evaluated in the order the direct-gather path below uses for this tile (column-first when the source row
+        // changes least along x): the LDS budget moves a tile between the two paths and must not move a bit of its coordinates
         pb_f2 fv[4][4];
+        if (fabsf(e->c[1][0]) <= fabsf(e->c[5][0])) {
 #pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            pb_f2 a[5];
-            pb_collapse_row(e, yb + 8 * jr, a);
+            for (int k = 0; k < 4; ++k) {
+                pb_f2 b[5];
+                pb_collapse_col(e, 4 * xg + k, b);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) fv[jr][k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
+                for (int jr = 0; jr < 4; ++jr) fv[jr][k] = pb_eval_row(b, pb_tile_coord(yb + 8 * jr));
+            }
+        } else {
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                pb_f2 a[5];
+                pb_collapse_row(e, yb + 8 * jr, a);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fv[jr][k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
+            }
         }
         asm volatile("" ::: "memory");
         pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
