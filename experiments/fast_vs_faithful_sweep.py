@@ -26,9 +26,15 @@ for k in range(n):
         w16 = max(32, (w // 16) * 16)
         case = Case(case.name, case.dst, (kind, h if kind != 'pano' else w16 // 2, w16, lens, fov, mag if kind != 'camera' or mag is None else min(mag, 0.75 * min(h, w16))), case.rotations, case.mask)
     try:
-        plan = H.pb_plan(case)
+        plan = H.pb_plan_private(case)
+        # a random window budget, and every other plan through a serialize -> deserialize round trip
+        plan.set_window_budget(int(rng.choice([4224, 5632, 7168, 9216, 12288])))
+        if k % 2:
+            blob = plan.serialize()
+            src_o, cmap_o = H.pb_chain(case, image=np.zeros((case.src[1], case.src[2], 3), np.uint8))
+            plan = nat.Plan.deserialize(blob, cmap_o.dst_proj, cmap_o.rotations, src_o._proj())
     except Exception as e:
-        print('plan failed', case, e); continue
+        print('plan failed', case, e); bad += 1; continue
     _, h, w, *_ = case.src
     frames = torch.stack([nat.synth_frame(h, w, frame=f) for f in range(2)])
     plan.set_mode(nat.MODE_FAITHFUL)
