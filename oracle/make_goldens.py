@@ -390,19 +390,72 @@ def gen_full():
     print("full.json written")
 
 
+def bilinear_crops(case: Case):
+    """Two 128 x 128 windows of a full-size output kept whole next to the seeded samples: the image centre (a pole / the fisheye
+    centre / the stitch's seam column) and a place on the rim of what the geometry paints - localized errors that 65 536 random
+    samples of 16-33 M pixels would miss."""
+    H, W = case.dst[1], case.dst[2]
+    centre = (H // 2 - 64, W // 2 - 64)
+    if case.dst[0] == "pano":
+        rim = (H // 2 - 64, W // 4 - 64) if case.src[0] == "double" else (H - 128, W // 3)  # an eye's rim (the blend band) / the pole rows
+    else:
+        rim = (H // 2 - 64, 0)  # where the image circle touches the frame's left edge
+    return {"centre": centre, "rim": rim}
+
+
+def gen_full_bilinear():
+    """f-4 at the sizes it is benchmarked at: for the five BASELINE geometries on the synthetic (noise) frame,
+    65 536 seeded sample values of oracle.remap_bilinear - OUR definition of the opt-in mode; the reference has no bilinear
+    behaviour, so these pin the HIP kernels to the written definition, not to the reference ("parity unpinned") - plus counts and
+    two 128 x 128 crops.  Samples and crops go to full_bilinear.npz, counts and positions to full.json under "bilinear"."""
+    path = os.path.join(GOLD, "full.json")
+    with open(path) as f:
+        pins = json.load(f)
+    arrays = {}
+    for case in full_cases():
+        od, os_ = orc_proj(case.dst), orc_proj(case.src)
+        rots = [tuple(map(to_radians, r)) for r in case.rotations]
+        kind, h, w, *_ = case.src
+        frame = synth_frame(h, w, frame=0, seed=0, circle_mask=case.mask)
+        assert sha(frame) == pins[case.name]["frame_sha256"]
+        out = orc.remap_bilinear(od, os_, frame, rots)
+        H, W = out.shape[:2]
+        pos = np.random.default_rng(pins[case.name]["sample_seed"]).integers(0, H * W, size=65536)
+        flat = out.reshape(-1, 3)
+        arrays[f"{case.name}/samples"] = flat[pos].copy()
+        crops = bilinear_crops(case)
+        for tag, (r0, c0) in crops.items():
+            arrays[f"{case.name}/crop_{tag}"] = out[r0:r0 + 128, c0:c0 + 128].copy()
+        black = (out == 0).all(axis=2)
+        pins[case.name]["bilinear"] = {
+            "definition": "oracle/reference_path.py:remap_bilinear (no reference behaviour: parity unpinned)",
+            "samples_sha256": sha(arrays[f"{case.name}/samples"]),
+            "black_pixels": int(black.sum()),
+            "byte_sum": int(out.astype(np.uint64).sum()),
+            "crops": {k: list(v) for k, v in crops.items()},
+        }
+        print(f"  {case.name} bilinear: {pins[case.name]['bilinear']['black_pixels']} black pixels, byte sum {pins[case.name]['bilinear']['byte_sum']}")
+        del out, frame, flat, black
+    np.savez_compressed(os.path.join(GOLD, "full_bilinear.npz"), **arrays)
+    with open(path, "w") as f:
+        json.dump(pins, f, indent=1)
+    print("full_bilinear.npz written; full.json updated (bilinear counts)")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--lens", action="store_true")
     ap.add_argument("--small", action="store_true")
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--full-raw", action="store_true", help="only add the unmasked-frame pins of the double-fisheye configs to full.json")
+    ap.add_argument("--full-bilinear", action="store_true", help="only add the full-size pins of the opt-in bilinear mode (our definition) to full.json / full_bilinear.npz")
     ap.add_argument("--mapproj", action="store_true")
     ap.add_argument("--cli", action="store_true")
     ap.add_argument("--real", action="store_true")
     ap.add_argument("--mid", action="store_true")
     ap.add_argument("--generic", action="store_true")
     a = ap.parse_args()
-    everything = not (a.full_raw or a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic)
+    everything = not (a.full_bilinear or a.full_raw or a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic)
     os.makedirs(GOLD, exist_ok=True)
     if a.lens or everything:
         gen_lens()
@@ -416,6 +469,8 @@ if __name__ == "__main__":
         gen_full()
     if a.full or a.full_raw or everything:
         gen_full_raw()
+    if a.full or a.full_bilinear or everything:
+        gen_full_bilinear()
     if a.mapproj or everything:
         gen_mapproj()
     if a.cli or everything:

@@ -4,6 +4,8 @@ from float32 tile models (~1e-5 px) and blends in float32, so a channel may land
 definition when the blended value sits near x.5; pixels on a validity / image boundary may flip between
 black and sampled."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,7 +14,7 @@ from oracle import reference_path as orc
 from oracle.synth import synth_frame
 from photonbend_amd import _native as nat
 from tests import helpers as H
-from tests.cases import Case, cam, case_by_name, inscribed, pano
+from tests.cases import Case, cam, case_by_name, full_cases, inscribed, pano
 
 pytestmark = pytest.mark.gpu
 
@@ -108,6 +110,61 @@ def test_bilinear_rejects_chains_beyond_one_fused_plan():
     assert src.process_coordinate_map(cmap).shape == (48, 48, 3)
 
 
+def _rim_of(black):
+    """one pixel either side of a black / sampled edge of the definition's output (8-neighbourhood)"""
+    rim = np.zeros_like(black)
+    for dy, dx in ((0, 1), (1, 0), (0, -1), (-1, 0), (1, 1), (1, -1), (-1, 1), (-1, -1)):
+        rim |= black != np.roll(np.roll(black, dy, axis=0), dx, axis=1)
+    return rim
+
+
+@pytest.mark.parametrize("case", full_cases(), ids=lambda c: c.name)
+def test_bilinear_full_size_against_definition(case):
+    """the bilinear mode at the sizes it is benchmarked at (c1, c2, c3, c5 at 180 and 195 degrees), on the
+    synthetic NOISE frame (255 LSB per pixel of coordinate error), against oracle.remap_bilinear's values captured at full size
+    (tests/golden/full_bilinear.npz, oracle/make_goldens.py --full-bilinear): 65 536 seeded samples, two whole 128 x 128 crops
+    (centre; rim / seam), the number of black pixels and the sum of all bytes.  +-1 LSB (+-2 for the double blend) everywhere but
+    on the one-pixel rim of the black regions."""
+    pin = H.load_full()[case.name]
+    gold = np.load(os.path.join(H.GOLD, "full_bilinear.npz"))
+    plan = H.pb_plan_private(case)
+    info = plan.info()
+    assert info["fast_path"]
+    _, h, w, *_ = case.src
+    frame = nat.synth_frame(h, w, frame=0, seed=0, circle_mask=case.mask)
+    out = plan.remap(frame, interpolation="bilinear")
+    Hd, Wd = case.dst[1], case.dst[2]
+    limit = 2 if case.src[0] == "double" else 1
+
+    def diff(got, want):
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        if case.src[0] == "double":
+            d = np.minimum(d, 256 - d)  # the blend's cast wraps mod 256 like the reference's
+        return d.max(axis=-1)
+
+    pos = np.random.default_rng(pin["sample_seed"]).integers(0, Hd * Wd, size=65536)
+    got = out.reshape(-1, 3)[torch.from_numpy(pos).cuda()].cpu().numpy()
+    want = gold[f"{case.name}/samples"]
+    d = diff(got, want)
+    flips = ((got == 0).all(axis=1) != (want == 0).all(axis=1))  # black <-> sampled: a validity / image boundary within float32 reach
+    off = int(((d > limit) & ~flips).sum())
+    assert off == 0, f"{off} of 65536 sampled pixels beyond {limit} LSB (max {int(d[~flips].max())})"
+    assert int(flips.sum()) <= 8, f"{int(flips.sum())} sampled pixels flipped between black and sampled"
+    assert int((d > 0).sum()) <= 65536 // 20, f"{int((d > 0).sum())} of 65536 samples differ at all"
+    for tag, (r0, c0) in pin["bilinear"]["crops"].items():
+        wantc = gold[f"{case.name}/crop_{tag}"]
+        gotc = out[r0:r0 + 128, c0:c0 + 128].cpu().numpy()
+        dc = diff(gotc, wantc)
+        rim = _rim_of((wantc == 0).all(axis=2))
+        assert int((dc[~rim] > limit).sum()) == 0, f"crop {tag}: {int((dc[~rim] > limit).sum())} pixels off the black rims beyond {limit} LSB (max {int(dc[~rim].max())})"
+        assert int((dc[rim] > limit).sum()) <= max(4, int(rim.sum()) // 50), f"crop {tag}: {int((dc[rim] > limit).sum())} of {int(rim.sum())} rim pixels differ"
+    black = int((out == 0).all(dim=2).sum())
+    assert abs(black - pin["bilinear"]["black_pixels"]) <= 64, (black, pin["bilinear"]["black_pixels"])
+    total = int(out.to(torch.int64).sum())
+    assert abs(total - pin["bilinear"]["byte_sum"]) <= 3 * Hd * Wd // 200, (total, pin["bilinear"]["byte_sum"])  # (mean error per byte below 1/200 LSB)
+    assert info["bilinear_float64_tiles"] * 100 <= info["tiles"], f"{info['bilinear_float64_tiles']} of {info['tiles']} tiles still take the float64 pass"
+
+
 @pytest.mark.parametrize("fov", [180, 195])
 def test_bilinear_double_tiles_against_float64_at_full_size(fov):
     """c5's geometry (7776x3888 double fisheye -> 8192x4096): the tile-model kernel (round 3) against the per-pixel float64
@@ -115,17 +172,24 @@ def test_bilinear_double_tiles_against_float64_at_full_size(fov):
     from tests.cases import dbl
 
     case = Case("c5", pano(4096, 8192), dbl(3888, 7776, "equidistant", fov), mask=2)
-    plan = H.pb_plan(case)
+    plan = H.pb_plan_private(case)  # (a plan of its own - the facade's shared cache entry must never be left in another mode)
     assert plan.info()["fast_path"]
     frame = nat.synth_frame(3888, 7776, frame=1, circle_mask=2)
     got = plan.remap(frame, interpolation="bilinear").to(torch.int16)
     plan.set_mode(nat.MODE_FAITHFUL)
     want = plan.remap(frame, interpolation="bilinear").to(torch.int16)
-    plan.set_mode(nat.MODE_AUTO)
     d = (got - want).abs()
     d = torch.minimum(d, 256 - d).amax(dim=2)
-    n_off = int((d > 1).sum())
-    assert n_off <= d.numel() // 2000, f"{n_off} of {d.numel()} pixels differ by more than 1 LSB"
+    # beyond 2 LSB only where the float64 kernel's output has a black / sampled edge (one pixel either side): a coordinate within
+    # float32 reach of an eye's rim or of the seam may flip a pixel between black and sampled
+    black = (want == 0).all(dim=2)
+    rim = torch.zeros_like(black)
+    for dy, dx in ((0, 1), (1, 0), (0, -1), (-1, 0), (1, 1), (1, -1), (-1, 1), (-1, -1)):
+        rim |= black != torch.roll(black, (dy, dx), (0, 1))
+    n_off = int(((d > 2) & ~rim).sum())
+    assert n_off == 0, f"{n_off} pixels off the black rims differ by more than 2 LSB (max {int(d[~rim].max())})"
+    assert int(((d > 2) & rim).sum()) <= d.numel() // 20000, int(((d > 2) & rim).sum())
+    assert int((d > 1).sum()) <= d.numel() // 2000, f"{int((d > 1).sum())} of {d.numel()} pixels differ by more than 1 LSB"
     assert int((d > 0).sum()) <= d.numel() // 20, int((d > 0).sum())
 
 
