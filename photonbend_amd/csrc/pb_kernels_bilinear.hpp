@@ -9,16 +9,34 @@
 // outside [0, h) x [0, w)) stay black.  A double-fisheye source is the reference's own blend (projection.py:439-460) of
 // the two eyes' BILINEAR samples: each eye is sampled like a camera source on its half of the frame (the right eye on
 // the mirrored half, taps clamped to the eye), rounded to uint8, then (l * fl + r * fr).astype(uint8) with the
-// reference's factors - pb_bilinear_double_hot_kernel from the per-eye tile models of the nearest mode's plan (round 3),
-// pb_bilinear_double_kernel (float64 coordinates per pixel) for plans without tile tables.
+// reference's factors.
 //
-//   pb_bilinear_hot_kernel   modelled tiles: float32 tile models give f (error ~1e-5 px, no fix list needed: there
-//                            is no truncation to protect), exact integer validity thresholds; LEAN tiles read their
-//                            four taps from the LDS window of the nearest mode, other tiles gather them directly
-//   pb_bilinear_fix_kernel   failed tiles (seam, pole, centre, no model): float64 faithful chain per pixel
+// Round 4: ONE launch per call, no float64 in it.  A tile is served either by its float32 tile model (certified to
+// 1/1024 px against the faithful coordinate, pb_certify_kernel) or - failed tiles, coarse models, tiles with invalid
+// pixels, an image edge or an eye's rim inside - by the plan's EXACT COORDINATE TABLE: the faithful tap coordinate of each of
+// its pixels in 1/4096 px, 8 KiB per tile, built once per plan from the float64 chain (like the nearest mode's exact-index
+// tables: what the models cannot reproduce is looked up, not recomputed).  Round 3 recomputed those tiles per frame in
+// float64 (c3: 1 506 of 16 384 tiles, 61 us of a 115 us frame; c5: 63 us).
+//
+//   pb_bilinear_hot_kernel          pano / camera sources: one wave per tile over the plan's launch-order table
+//   pb_bilinear_double_hot_kernel   double-fisheye sources: one-eye (SOLO) tiles through the same tile code, two-eye tiles
+//                                   sample both eyes and blend with the tile's weight class
+//   pb_bilinear_fix_kernel, pb_bilinear_double_kernel, pb_bilinear_double_fix_kernel
+//                                   the float64 chain per pixel: the mode's definition on the device (PB_MODE_FAITHFUL, plans
+//                                   without tile tables) and the fallback for plans whose coordinate table would not fit
 #pragma once
 #include "pb_kernels_tile.hpp"
 
+#ifndef PB_BIL_ABL  // timing experiments only (experiments/r4/): bits skip parts of the bilinear tile code (wrong pixels); 0 in the product
+#define PB_BIL_ABL 0
+#endif
+#ifdef PB_MARKS  // ISA reading aid (experiments/r4/isa_count.py): comment markers around the paths of the tile code; never in the product build
+#define PB_MARK(name) asm volatile("; PBMARK " name ::: "memory")
+#else
+#define PB_MARK(name)
+#endif
+
+// ---- float64 passes: tap arithmetic ------------------------------------------------------------------------------------------
 template <int SRC_KIND>
 __device__ __forceinline__ unsigned pb_bilinear_taps(const PbParams& P, const uint8_t* __restrict__ s, float sy, float sx, int by,
                                                      int bx) {
@@ -54,59 +72,467 @@ __device__ __forceinline__ unsigned pb_bilinear_taps(const PbParams& P, const ui
     return out;
 }
 
-// one bilinear pixel from the wave's LDS window: the four taps around (sy, sx) = f - 0.5 in WINDOW coordinates
-// (LEAN tiles carry one texel of margin on every side - exactly the taps' reach - and lie strictly inside the
-// image, so nothing is clamped or wrapped)
-__device__ __forceinline__ unsigned pb_bilinear_lds(const unsigned* win, float sy, float sx, unsigned pitch, unsigned a0) {
-    const float fy0 = floorf(sy), fx0 = floorf(sx);
-    const float ty = sy - fy0, tx = sx - fx0;
-    const unsigned l00 = __umul24((unsigned)(int)fy0, pitch) + __umul24((unsigned)(int)fx0, 3u) + a0;
-    const unsigned l10 = l00 + pitch;
-    // two horizontally adjacent taps = 6 consecutive bytes: three aligned dwords cover them
-    const unsigned w0 = win[l00 >> 2], w1 = win[(l00 >> 2) + 1], w2 = win[(l00 >> 2) + 2];
-    const unsigned v0 = win[l10 >> 2], v1 = win[(l10 >> 2) + 1], v2 = win[(l10 >> 2) + 2];
-    // the right-hand tap starts 3 bytes on: in the same dword pair only when the left tap is dword-aligned
-    const bool c0 = (l00 & 3u) != 0, c1 = (l10 & 3u) != 0;
-    const unsigned p00 = __builtin_amdgcn_alignbyte(w1, w0, l00);
-    const unsigned p01 = __builtin_amdgcn_alignbyte(c0 ? w2 : w1, c0 ? w1 : w0, l00 + 3u);
-    const unsigned p10 = __builtin_amdgcn_alignbyte(v1, v0, l10);
-    const unsigned p11 = __builtin_amdgcn_alignbyte(c1 ? v2 : v1, c1 ? v1 : v0, l10 + 3u);
-    unsigned out = 0;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float a = (float)((p00 >> (8 * ch)) & 0xFF), b = (float)((p01 >> (8 * ch)) & 0xFF);
-        const float c = (float)((p10 >> (8 * ch)) & 0xFF), d = (float)((p11 >> (8 * ch)) & 0xFF);
-        const float top = fmaf(tx, b - a, a), bot = fmaf(tx, d - c, c);
-        const float v = fmaf(ty, bot - top, top);
-        out |= ((unsigned)(int)rintf(fminf(fmaxf(v, 0.0f), 255.0f))) << (8 * ch);
-    }
-    return out;
-}
+// ---- exact coordinate tables ------------------------------------------------------------------------------------------------
+// The faithful tap coordinate s = f - 0.5 of one pixel for one source (or eye), in 1/4096 px, in FRAME space: the right eye's
+// column runs over the mirrored half (w - 1 - s_eye: bilinear interpolation commutes with the mirror, the taps are the frame's
+// texels floor(s), floor(s) + 1 of either eye, clamped to the eye's own columns).  y == PB_BIL_DEAD: the pixel is black for this
+// source (invalid destination pixel, position outside the image / the eye, not finite).  2^-13 px of quantisation = 0.06 LSB on
+// the steepest possible content.
+struct PbBilCoord {
+    int32_t y, x;
+};
+#define PB_BIL_SHIFT 12
+#define PB_BIL_DEAD ((int32_t)0x80000000)
+#define PB_BIL_MAX_DIM (1 << 18)  // source sides the fixed point holds (the plan keeps the float64 pass beyond)
 
-// The four channels' arithmetic of one pixel: taps p00 p01 / p10 p11 (low 3 bytes), weights (tx, ty) -> packed RGB
-__device__ __forceinline__ unsigned pb_bilinear_mix(unsigned p00, unsigned p01, unsigned p10, unsigned p11, float tx, float ty) {
-    unsigned out = 0;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float a = (float)((p00 >> (8 * ch)) & 0xFF), b = (float)((p01 >> (8 * ch)) & 0xFF);
-        const float c = (float)((p10 >> (8 * ch)) & 0xFF), d = (float)((p11 >> (8 * ch)) & 0xFF);
-        const float top = fmaf(tx, b - a, a), bot = fmaf(tx, d - c, c);
-        const float v = fmaf(ty, bot - top, top);
-        out |= ((unsigned)(int)rintf(fminf(fmaxf(v, 0.0f), 255.0f))) << (8 * ch);
-    }
-    return out;
-}
-
-// One wave per tile, launched like pb_hot_win_kernel: `table` is the plan's LAUNCH-ORDER table (the entry says which
-// tile it is), frames of a batch are a grid dimension.  LEAN tiles take their taps from the LDS window the nearest mode
-// stages (same plan, same LDS-DMA loads); DIRECT tiles gather them from the frame, two horizontally adjacent taps (6
-// consecutive bytes) per 8-byte load; other tiles tap by tap.
 template <int SRC_KIND>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
-                                                                              const uint8_t* __restrict__ src,
-                                                                              uint8_t* __restrict__ dst, const unsigned groups_per_frame,
-                                                                              unsigned long long src_stride,
-                                                                              unsigned long long dst_stride, int windows) {
+__device__ __forceinline__ PbBilCoord pb_bil_coord_of(const PbParams& P, const PbCoord& c) {
+    PbBilCoord q = {PB_BIL_DEAD, 0};
+    if (c.inv) return q;
+    double f0, f1;
+    bool live;
+    if (SRC_KIND == PB_KIND_PANO) {
+        pb_src_pretrunc<PB_KIND_PANO>(P, c, f0, f1);
+        live = f0 == f0 && f1 == f1 && fabs(f0) < 1.0e9 && fabs(f1) < 1.0e9;
+    } else {
+        // one fisheye (or one eye, sampled like a camera source on its half: projection.py:429-434) in ITS pixel space
+        const double lat = (SRC_KIND == PB_KIND_EYE_R) ? (c.lat * -1.0) + PB_PI : c.lat;  // projection.py:426-427
+        const int we = (SRC_KIND == PB_KIND_EYE_L) ? P.src_eye_w : (SRC_KIND == PB_KIND_EYE_R) ? P.src_eye_w_right : P.src.width;
+        const double cx = (SRC_KIND == PB_KIND_EYE_R) ? P.src_cx_r : P.src_cx;
+        const double dist = pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
+        double sl, cl;
+        pb_sincos_cr(c.lon, &sl, &cl);  // np.exp(lon * 1j)
+        f0 = ((sl * dist) * -1.0) + P.src_cy;
+        f1 = (cl * dist) + cx;
+        live = f0 == f0 && f1 == f1 && fabs(f0) < 1.0e9 && fabs(f1) < 1.0e9 && f0 >= 0.0 && f0 < (double)P.src.height && f1 >= 0.0 && f1 < (double)we;
+        if (SRC_KIND == PB_KIND_EYE_R) f1 = (double)P.src.width - f1;  // the mirrored half of the frame (projection.py:430-431)
+    }
+    if (!live) return q;
+    q.y = (int32_t)rint((f0 - 0.5) * (double)(1 << PB_BIL_SHIFT));
+    q.x = (int32_t)rint((f1 - 0.5) * (double)(1 << PB_BIL_SHIFT));
+    return q;
+}
+
+// ---- the arithmetic of one pixel -------------------------------------------------------------------------------------------
+// Two horizontally adjacent taps are 6 consecutive bytes; (lo, hi) = the 8 bytes from the left tap's first byte on.  The four weights
+// (1-tx)(1-ty), tx(1-ty), (1-tx)ty, tx ty are formed once; channels 0 and 1 run as one float2 (v_pk_mul / v_pk_fma_f32), every byte is
+// converted straight from its place (v_cvt_f32_ubyteN), and the result is rounded half-to-even, clamped and packed by
+// v_cvt_pk_u8_f32 (checked on MI355X: experiments/r4/exp_isa.hip).  (The definition nests three lerps in float64; the weighted sum
+// in float32 differs from it by ~1e-5 LSB, i.e. only where the exact value sits that close to x.5.)
+__device__ __forceinline__ unsigned pb_bil_mix64(unsigned lo0, unsigned hi0, unsigned lo1, unsigned hi1, float tx, float ty) {
+    const pb_f2 a = {(float)(lo0 & 0xFFu), (float)((lo0 >> 8) & 0xFFu)}, b = {(float)(lo0 >> 24), (float)(hi0 & 0xFFu)};
+    const pb_f2 c = {(float)(lo1 & 0xFFu), (float)((lo1 >> 8) & 0xFFu)}, d = {(float)(lo1 >> 24), (float)(hi1 & 0xFFu)};
+    const float a2 = (float)((lo0 >> 16) & 0xFFu), b2 = (float)((hi0 >> 8) & 0xFFu);
+    const float c2 = (float)((lo1 >> 16) & 0xFFu), d2 = (float)((hi1 >> 8) & 0xFFu);
+    const float ux = 1.0f - tx, uy = 1.0f - ty;
+    const float w00 = ux * uy, w01 = tx * uy, w10 = ux * ty, w11 = tx * ty;
+    const pb_f2 ww = {w00, w00};
+    pb_f2 v = a * ww;
+    v = pb_fma2(b, w01, v);
+    v = pb_fma2(c, w10, v);
+    v = pb_fma2(d, w11, v);
+    const float v2 = fmaf(d2, w11, fmaf(c2, w10, fmaf(b2, w01, a2 * w00)));
+    unsigned out = __builtin_amdgcn_cvt_pk_u8_f32(v.x, 0u, 0u);
+    out = __builtin_amdgcn_cvt_pk_u8_f32(v.y, 1u, out);
+    return __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, out);
+}
+// Two pixels at once: the weights of both are formed packed, channels 0 / 1 of each pixel run as one float2 against that pixel's
+// weights (broadcast from the pair), and the two pixels' third channels share a float2: 18 packed instructions per pair where two
+// single calls take 26.
+__device__ __forceinline__ void pb_bil_mix64x2(const unsigned lo0[2], const unsigned hi0[2], const unsigned lo1[2], const unsigned hi1[2], const pb_f2 tx,
+                                               const pb_f2 ty, unsigned out[2]) {
+    const pb_f2 one = {1.0f, 1.0f};
+    const pb_f2 ux = one - tx, uy = one - ty;
+    const pb_f2 w00 = ux * uy, w01 = tx * uy, w10 = ux * ty, w11 = tx * ty;
+    pb_f2 v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const pb_f2 a = {(float)(lo0[i] & 0xFFu), (float)((lo0[i] >> 8) & 0xFFu)}, b = {(float)(lo0[i] >> 24), (float)(hi0[i] & 0xFFu)};
+        const pb_f2 c = {(float)(lo1[i] & 0xFFu), (float)((lo1[i] >> 8) & 0xFFu)}, d = {(float)(lo1[i] >> 24), (float)(hi1[i] & 0xFFu)};
+        const pb_f2 q00 = {w00[i], w00[i]}, q01 = {w01[i], w01[i]}, q10 = {w10[i], w10[i]}, q11 = {w11[i], w11[i]};
+        v[i] = __builtin_elementwise_fma(d, q11, __builtin_elementwise_fma(c, q10, __builtin_elementwise_fma(b, q01, a * q00)));
+    }
+    const pb_f2 a2 = {(float)((lo0[0] >> 16) & 0xFFu), (float)((lo0[1] >> 16) & 0xFFu)}, b2 = {(float)((hi0[0] >> 8) & 0xFFu), (float)((hi0[1] >> 8) & 0xFFu)};
+    const pb_f2 c2 = {(float)((lo1[0] >> 16) & 0xFFu), (float)((lo1[1] >> 16) & 0xFFu)}, d2 = {(float)((hi1[0] >> 8) & 0xFFu), (float)((hi1[1] >> 8) & 0xFFu)};
+    const pb_f2 v2 = __builtin_elementwise_fma(d2, w11, __builtin_elementwise_fma(c2, w10, __builtin_elementwise_fma(b2, w01, a2 * w00)));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        unsigned o = __builtin_amdgcn_cvt_pk_u8_f32(v[i].x, 0u, 0u);
+        o = __builtin_amdgcn_cvt_pk_u8_f32(v[i].y, 1u, o);
+        out[i] = __builtin_amdgcn_cvt_pk_u8_f32(v2[i], 2u, o);
+    }
+}
+// the same from four separate taps (low 3 bytes of each)
+__device__ __forceinline__ unsigned pb_bil_mix4(unsigned p00, unsigned p01, unsigned p10, unsigned p11, float tx, float ty) {
+    return pb_bil_mix64((p00 & 0xFFFFFFu) | (p01 << 24), p01 >> 8, (p10 & 0xFFFFFFu) | (p11 << 24), p11 >> 8, tx, ty);
+}
+
+// a * b + c on 24-bit operands in ONE instruction (the compiler forms v_mul_u32_u24 + v_add3_u32 from __umul24(a, b) + c)
+__device__ __forceinline__ unsigned pb_umad24(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// Four pixels from the wave's LDS window: the four taps around s = f - 0.5 (WINDOW coordinates; LEAN tiles carry one texel of margin
+// on every side - exactly the taps' reach - and lie strictly inside the image, so nothing is clamped or wrapped, and s >= 0.5:
+// truncation is floor).  Three aligned dwords per row (ds_read2_b32 + ds_read_b32) and two v_alignbyte give the 8 bytes from the left
+// tap on (an unaligned ds_read_b64 is legal here but measured three times slower: experiments/r4/exp_isa.hip).  Four pixels per call:
+// their 24 LDS reads are in flight together and their arithmetic interleaves - one pixel at a time left a wave waiting for LDS sixteen
+// times per tile, with a wait state after every dependent v_pk_fma of the coordinate polynomial (c5: a wave lived 19 us).
+__device__ __forceinline__ void pb_bil_lds4(const unsigned* win, const pb_f2 sv[4], unsigned pitch, unsigned a0, unsigned out[4]) {
+    unsigned l0[4], w[4][6];
+    float tx[4], ty[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ty[k] = __builtin_amdgcn_fractf(sv[k].x);
+        tx[k] = __builtin_amdgcn_fractf(sv[k].y);
+        l0[k] = pb_umad24((unsigned)(int)sv[k].x, pitch, pb_umad24((unsigned)(int)sv[k].y, 3u, a0));
+        if (PB_BIL_ABL & 2) l0[k] = (l0[k] & 3u) + 64u;  // every lane reads the same dwords: no bank conflicts
+        const unsigned i0 = l0[k] >> 2, i1 = (l0[k] + pitch) >> 2;  // (the pitch is a multiple of 16: both rows share the byte phase)
+        w[k][0] = win[i0];
+        w[k][1] = win[i0 + 1];
+        w[k][2] = win[i0 + 2];
+        w[k][3] = win[i1];
+        w[k][4] = win[i1 + 1];
+        w[k][5] = win[i1 + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        unsigned lo0[2], hi0[2], lo1[2], hi1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            lo0[i] = __builtin_amdgcn_alignbyte(w[k + i][1], w[k + i][0], l0[k + i]);
+            hi0[i] = __builtin_amdgcn_alignbyte(w[k + i][2], w[k + i][1], l0[k + i]);
+            lo1[i] = __builtin_amdgcn_alignbyte(w[k + i][4], w[k + i][3], l0[k + i]);
+            hi1[i] = __builtin_amdgcn_alignbyte(w[k + i][5], w[k + i][4], l0[k + i]);
+        }
+        const pb_f2 tx2 = {tx[k], tx[k + 1]}, ty2 = {ty[k], ty[k + 1]};
+        if (PB_BIL_ABL & 8) {
+            out[k] = lo0[0] ^ hi0[0] ^ lo1[0] ^ hi1[0] ^ __float_as_uint(tx[k] + ty[k]);
+            out[k + 1] = lo0[1] ^ hi0[1] ^ lo1[1] ^ hi1[1] ^ __float_as_uint(tx[k + 1] + ty[k + 1]);
+        } else {
+            pb_bil_mix64x2(lo0, hi0, lo1, hi1, tx2, ty2, &out[k]);
+        }
+    }
+}
+
+// the three bytes of a pixel at byte offset o of the frame as the low bytes of a dword; the frame's very last pixel is read one byte
+// early and shifted (a dword at its address would touch one byte past the buffer).  Needs frame_bytes >= 4 (host check).
+__device__ __forceinline__ unsigned pb_bil_load_px(const uint8_t* __restrict__ s, unsigned o, unsigned frame_bytes) {
+    const unsigned oo = min(o, frame_bytes - 4u);
+    unsigned t;
+    __builtin_memcpy(&t, s + oo, 4);
+    return t >> (8u * (o - oo));
+}
+
+// one pixel from its exact tap coordinate (fix pixels): taps clamped to the frame's rows and to the columns [cmin, cmax) of the
+// source (an eye's half), a panorama's columns wrap
+template <bool WRAP>
+__device__ __forceinline__ unsigned pb_bil_table_px(const uint8_t* __restrict__ s, int qy, int qx, int h, int w, int cmin, int cmax,
+                                                    unsigned frame_bytes) {
+    const bool dead = qy == PB_BIL_DEAD;
+    if (dead) qy = 0;
+    const float ty = (float)(qy & ((1 << PB_BIL_SHIFT) - 1)) * (1.0f / (float)(1 << PB_BIL_SHIFT));
+    const float tx = (float)(qx & ((1 << PB_BIL_SHIFT) - 1)) * (1.0f / (float)(1 << PB_BIL_SHIFT));
+    int r0 = qy >> PB_BIL_SHIFT, c0 = qx >> PB_BIL_SHIFT;  // arithmetic shifts: floor
+    int r1 = r0 + 1, c1 = c0 + 1;
+    r0 = min(max(r0, 0), h - 1);
+    r1 = min(max(r1, 0), h - 1);
+    if (WRAP) {
+        c0 = c0 < 0 ? c0 + w : (c0 >= w ? c0 - w : c0);
+        c1 = c1 < 0 ? c1 + w : (c1 >= w ? c1 - w : c1);
+    }
+    c0 = min(max(c0, cmin), cmax - 1);
+    c1 = min(max(c1, cmin), cmax - 1);
+    const unsigned b0 = (unsigned)r0 * (unsigned)w, b1 = (unsigned)r1 * (unsigned)w;
+    const unsigned p00 = pb_bil_load_px(s, 3u * (b0 + (unsigned)c0), frame_bytes), p01 = pb_bil_load_px(s, 3u * (b0 + (unsigned)c1), frame_bytes);
+    const unsigned p10 = pb_bil_load_px(s, 3u * (b1 + (unsigned)c0), frame_bytes), p11 = pb_bil_load_px(s, 3u * (b1 + (unsigned)c1), frame_bytes);
+    const unsigned out = pb_bil_mix4(p00, p01, p10, p11, tx, ty);
+    return dead ? 0u : out;
+}
+
+// The table path of a tile: the lane's 16 pixels from their exact tap coordinates, eight at a time.  A pixel's two taps of a row
+// are 6 consecutive bytes wherever the right tap is the left one's neighbour: ONE 8-byte load per row (moved back and shifted where
+// it would run past the frame's end).  A right tap clamped onto the left one (an image / eye edge) is that same tap again; a
+// panorama's wrapped right tap (column 0 after column w - 1) is loaded by itself, the only divergent case.  Needs frame_bytes >= 8.
+struct PbBilTap {
+    unsigned o0, o1;  // byte offsets of the left taps of the two rows
+    unsigned c1off;   // WRAP only: byte offset of the right tap's column relative to the left one's row start, or ~0u: neighbour / same
+    float tx, ty;
+    int kind;         // 0: neighbours, 1: the right tap is the left tap, 2: wrapped, -1: black
+};
+template <bool WRAP>
+__device__ __forceinline__ PbBilTap pb_bil_table_tap(int qy, int qx, int h, int w, int cmin, int cmax) {
+    PbBilTap t;
+    const bool dead = qy == PB_BIL_DEAD;
+    if (dead) qy = 0;
+    t.ty = (float)(qy & ((1 << PB_BIL_SHIFT) - 1)) * (1.0f / (float)(1 << PB_BIL_SHIFT));
+    t.tx = (float)(qx & ((1 << PB_BIL_SHIFT) - 1)) * (1.0f / (float)(1 << PB_BIL_SHIFT));
+    int r0 = qy >> PB_BIL_SHIFT, c0 = qx >> PB_BIL_SHIFT;
+    int r1 = r0 + 1, c1 = c0 + 1;
+    r0 = min(max(r0, 0), h - 1);
+    r1 = min(max(r1, 0), h - 1);
+    if (WRAP) {
+        c0 = c0 < 0 ? c0 + w : (c0 >= w ? c0 - w : c0);
+        c1 = c1 < 0 ? c1 + w : (c1 >= w ? c1 - w : c1);
+    }
+    c0 = min(max(c0, cmin), cmax - 1);
+    c1 = min(max(c1, cmin), cmax - 1);
+    t.o0 = 3u * ((unsigned)r0 * (unsigned)w + (unsigned)c0);
+    t.o1 = 3u * ((unsigned)r1 * (unsigned)w + (unsigned)c0);
+    t.kind = dead ? -1 : (c1 == c0 + 1 ? 0 : (c1 == c0 ? 1 : 2));
+    t.c1off = 3u * (unsigned)(c1 - c0);  // (kind 2: negative, as an unsigned wrap-around - added to o0 / o1)
+    return t;
+}
+// 8 bytes at byte offset o of the frame (moved back and shifted at the frame's end)
+__device__ __forceinline__ unsigned long long pb_bil_load8(const uint8_t* __restrict__ s, unsigned o, unsigned frame_bytes) {
+    const unsigned oo = min(o, frame_bytes - 8u);
+    unsigned long long t;
+    __builtin_memcpy(&t, s + oo, 8);
+    return t >> (8u * (o - oo));
+}
+template <bool WRAP>
+__device__ __forceinline__ void pb_bil_table8(const uint8_t* __restrict__ s, const int4 q[4], int h, int w, int cmin, int cmax, unsigned frame_bytes,
+                                              unsigned out[8]) {
+    PbBilTap t[8];
+    unsigned long long r0[8], r1[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int4 qq = q[n >> 1];
+        t[n] = pb_bil_table_tap<WRAP>((n & 1) ? qq.z : qq.x, (n & 1) ? qq.w : qq.y, h, w, cmin, cmax);
+        r0[n] = pb_bil_load8(s, t[n].o0, frame_bytes);
+        r1[n] = pb_bil_load8(s, t[n].o1, frame_bytes);
+    }
+#pragma unroll
+    for (int n = 0; n < 8; n += 2) {
+        unsigned lo0[2], hi0[2], lo1[2], hi1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const PbBilTap& tt = t[n + i];
+            lo0[i] = (unsigned)r0[n + i];
+            hi0[i] = (unsigned)(r0[n + i] >> 32);
+            lo1[i] = (unsigned)r1[n + i];
+            hi1[i] = (unsigned)(r1[n + i] >> 32);
+            if (tt.kind == 1) {  // the right tap is the left tap again: bytes 0-2 repeated as bytes 3-5
+                hi0[i] = lo0[i] >> 8;
+                lo0[i] = (lo0[i] & 0xFFFFFFu) | (lo0[i] << 24);
+                hi1[i] = lo1[i] >> 8;
+                lo1[i] = (lo1[i] & 0xFFFFFFu) | (lo1[i] << 24);
+            }
+            if (WRAP && tt.kind == 2) {  // the panorama's seam: the right tap by itself
+                const unsigned p01 = pb_bil_load_px(s, tt.o0 + tt.c1off, frame_bytes), p11 = pb_bil_load_px(s, tt.o1 + tt.c1off, frame_bytes);
+                lo0[i] = (lo0[i] & 0xFFFFFFu) | (p01 << 24);
+                hi0[i] = p01 >> 8;
+                lo1[i] = (lo1[i] & 0xFFFFFFu) | (p11 << 24);
+                hi1[i] = p11 >> 8;
+            }
+        }
+        const pb_f2 tx2 = {t[n].tx, t[n + 1].tx}, ty2 = {t[n].ty, t[n + 1].ty};
+        pb_bil_mix64x2(lo0, hi0, lo1, hi1, tx2, ty2, &out[n]);
+        if (t[n].kind < 0) out[n] = 0u;
+        if (t[n + 1].kind < 0) out[n + 1] = 0u;
+    }
+}
+
+// The direct-gather path's loads and arithmetic for one lane: its 16 pixels q(n) = (2 n + q0) & 31 along the collapsed polynomial
+// cf, eight pixels' loads in flight together (WIDE: two 8-byte loads per pixel, else four dwords), each blended pixel parked in the
+// wave's LDS at park_p + q * park_q.
+template <bool WIDE>
+__device__ __forceinline__ void pb_bil_direct_gather(const uint8_t* __restrict__ s, unsigned* win, const pb_f2 cf[5], const unsigned gbase,
+                                                     const unsigned rowbytes, const int q0, const int park_p, const int park_q) {
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+        unsigned lo[8][2], hi[8][2];
+        float wy[8], wx[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int q = (2 * (8 * grp + m) + q0) & 31;
+            const pb_f2 sv = pb_eval_row(cf, pb_tile_coord(q));
+            wy[m] = __builtin_amdgcn_fractf(sv.x);
+            wx[m] = __builtin_amdgcn_fractf(sv.y);
+            const unsigned g = gbase + (unsigned)(int)sv.x * rowbytes + __umul24((unsigned)(int)sv.y, 3u);  // (s >= 0.5: truncation is floor)
+            if (WIDE) {
+                unsigned long long t0, t1;
+                __builtin_memcpy(&t0, s + g, 8);
+                __builtin_memcpy(&t1, s + g + rowbytes, 8);
+                lo[m][0] = (unsigned)t0;
+                hi[m][0] = (unsigned)(t0 >> 32);
+                lo[m][1] = (unsigned)t1;
+                hi[m][1] = (unsigned)(t1 >> 32);
+            } else {
+                unsigned t00, t01, t10, t11;
+                __builtin_memcpy(&t00, s + g, 4);
+                __builtin_memcpy(&t01, s + g + 3u, 4);
+                __builtin_memcpy(&t10, s + g + rowbytes, 4);
+                __builtin_memcpy(&t11, s + g + rowbytes + 3u, 4);
+                lo[m][0] = (t00 & 0xFFFFFFu) | (t01 << 24);
+                hi[m][0] = t01 >> 8;
+                lo[m][1] = (t10 & 0xFFFFFFu) | (t11 << 24);
+                hi[m][1] = t11 >> 8;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) {
+            const unsigned l0[2] = {lo[m][0], lo[m + 1][0]}, h0[2] = {hi[m][0], hi[m + 1][0]}, l1[2] = {lo[m][1], lo[m + 1][1]}, h1[2] = {hi[m][1], hi[m + 1][1]};
+            const pb_f2 tx2 = {wx[m], wx[m + 1]}, ty2 = {wy[m], wy[m + 1]};
+            unsigned o[2];
+            pb_bil_mix64x2(l0, h0, l1, h1, tx2, ty2, o);
+            win[park_p + ((2 * (8 * grp + m) + q0) & 31) * park_q] = o[0];
+            win[park_p + ((2 * (8 * grp + m + 1) + q0) & 31) * park_q] = o[1];
+        }
+    }
+}
+
+// ---- one source's (or eye's) values for a tile -----------------------------------------------------------------------------
+// v[jr * 4 + k] = the bilinear sample of pixel (4 xg + k, yb + 8 jr) of the tile (xg = lane & 7, yb = lane >> 3: the lane's four
+// 12-byte stores), packed RGB.  Which path:
+//   table   the entry names a slot of the exact coordinate table (bil_off >= 0): failed tiles, coarse models, tiles with invalid
+//           pixels, an image edge or an eye's rim inside - every pixel from its stored coordinate, taps clamped;
+//   black   nothing of the tile samples this source;
+//   window  LEAN tile: the nearest mode's LDS window (same plan, same LDS-DMA loads), taps from LDS;
+//   direct  plain tile whose window exceeds the LDS budget: both taps of a row in one 8-byte load straight from the frame,
+//           unguarded (the tile's box, margin texel included, lies inside the frame and - an eye - inside its half).  The gathers
+//           run like the nearest mode's (pb_win_tile, DIRECT): lane = pixel column (or row), sheared along the line of constant
+//           source row, regrouped for the stores through the wave's LDS.
+// The model is evaluated column-first when the source row changes least along x, row-first otherwise, in the window path and in
+// the direct path alike: the LDS budget moves a tile between the two and must not move a bit of its coordinates.
+// Registers: the paths compute four pixels at a time and keep only the packed results (round 3 held all coordinates and all taps:
+// 136 / 202 VGPRs, 3 / 2 waves per SIMD).
+template <bool WRAP>
+__device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* __restrict__ e, const int flags, const int lane, unsigned* win,
+                                            const int windows, const uint8_t* __restrict__ s, const PbBilCoord* __restrict__ bil_xy, const int cmin,
+                                            const int cmax, unsigned v[16]) {
+    const int xg = lane & 7, yb = lane >> 3;
+    const int h = Hd.src_h, w = Hd.src_w;
+    const unsigned rowbytes = 3u * (unsigned)w, frame_bytes = rowbytes * (unsigned)h, safe_len = frame_bytes & ~15u;
+    if ((PB_BIL_ABL & 32) && e->bil_off >= 0) return;                                                 // skip table tiles
+    if ((PB_BIL_ABL & 64) && e->bil_off < 0 && (flags & PB_TILE_LEAN) && windows) return;            // skip window tiles
+    if ((PB_BIL_ABL & 16) && e->bil_off < 0 && (flags & PB_TILE_DIRECT)) return;                     // skip direct-gather tiles
+    if (e->bil_off >= 0) {
+        PB_MARK("table");
+        const PbBilCoord* __restrict__ t = bil_xy + (size_t)e->bil_off * (PB_TILE * PB_TILE);
+        int4 q[8];  // all sixteen coordinates first: one round trip
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) {
+            q[2 * jr] = *reinterpret_cast<const int4*>(t + (yb + 8 * jr) * PB_TILE + 4 * xg);
+            q[2 * jr + 1] = *reinterpret_cast<const int4*>(t + (yb + 8 * jr) * PB_TILE + 4 * xg + 2);
+        }
+        pb_bil_table8<WRAP>(s, &q[0], h, w, cmin, cmax, frame_bytes, &v[0]);
+        pb_bil_table8<WRAP>(s, &q[4], h, w, cmin, cmax, frame_bytes, &v[8]);
+        PB_MARK("end");
+        return;
+    }
+    if (!(flags & (PB_TILE_LEAN | PB_TILE_DIRECT))) {  // BLACK (every other class has a table slot)
+#pragma unroll
+        for (int n = 0; n < 16; ++n) v[n] = 0u;
+        return;
+    }
+    const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+    const bool along_x = fabsf(e->c[1][0]) <= fabsf(e->c[5][0]);  // |d row / du| <= |d row / dv|
+    if ((flags & PB_TILE_LEAN) && windows) {
+        const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
+        if (!(PB_BIL_ABL & 4)) pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pb_wave_sync();
+        const pb_f2 half = {0.5f, 0.5f};
+        if (along_x) {
+            PB_MARK("window_colfirst");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pb_f2 b[5], sv[4];
+                unsigned o[4];
+                pb_collapse_col(e, 4 * xg + k, b);
+                b[0] = b[0] - half;  // s = f - 0.5, folded into the constant term (window path and direct path alike)
+#pragma unroll
+                for (int jr = 0; jr < 4; ++jr) sv[jr] = pb_eval_row(b, pb_tile_coord(yb + 8 * jr));
+                pb_bil_lds4(win, sv, pitch, a0, o);
+#pragma unroll
+                for (int jr = 0; jr < 4; ++jr) v[jr * 4 + k] = o[jr];
+            }
+        } else {
+            PB_MARK("window_rowfirst");
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                pb_f2 a[5], sv[4];
+                pb_collapse_row(e, yb + 8 * jr, a);
+                a[0] = a[0] - half;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
+                pb_bil_lds4(win, sv, pitch, a0, &v[jr * 4]);
+            }
+        }
+        PB_MARK("end");
+        pb_wave_sync();  // every lane has read its taps: the window may be refilled (the other eye, the next path)
+        return;
+    }
+    // direct gathers.  wide: an 8-byte load takes both taps of a row - allowed when even the box's last tap has 8 bytes of frame
+    // behind it.
+    const bool wide = gbase + (unsigned)(e->win_rows - 1) * rowbytes + 3u * (unsigned)(e->win_cols - 1) + 8u <= frame_bytes;
+    const int p = lane & 31, hh = lane >> 5;
+    PB_MARK("direct");
+    const float num = along_x ? e->c[1][0] : e->c[5][0], den = along_x ? e->c[5][0] : e->c[1][0];
+    const float slope = (den != 0.0f) ? -num / den : 0.0f;
+    const int shift = (int)rintf(slope * ((float)p - 15.5f));
+    pb_f2 cf[5];
+    if (along_x) pb_collapse_col(e, p, cf);
+    else pb_collapse_row(e, p, cf);
+    {
+        const pb_f2 half = {0.5f, 0.5f};
+        cf[0] = cf[0] - half;  // s = f - 0.5 (as in the window path)
+    }
+    const int park_p = along_x ? p : p * 33, park_q = along_x ? 33 : 1;  // the lane's pixel (p, q) or (q, p) parks at [y][x], 33-dword pitch
+    if (wide) pb_bil_direct_gather<true>(s, win, cf, gbase, rowbytes, hh + shift, park_p, park_q);
+    else pb_bil_direct_gather<false>(s, win, cf, gbase, rowbytes, hh + shift, park_p, park_q);
+    pb_wave_sync();
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[jr * 4 + k] = win[(yb + 8 * jr) * 33 + 4 * xg + k];
+    PB_MARK("end");
+    pb_wave_sync();
+}
+
+// the lane's four 12-byte stores (4 consecutive pixels x 4 rows); tiles on the image's edge are clipped
+template <bool NT>
+__device__ __forceinline__ void pb_bil_store(const unsigned v[16], uint8_t* __restrict__ d, const int X0, const int Y0, const int lane, const int W,
+                                             const int H) {
+    const int xg = lane & 7, yb = lane >> 3, x = X0 + 4 * xg;
+    const bool inside = X0 + PB_TILE <= W && Y0 + PB_TILE <= H;
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+        const int y = Y0 + yb + 8 * jr;
+        if (!inside && y >= H) continue;
+        const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
+        if ((PB_BIL_ABL & 1) && v[jr * 4] != 0x12345678u) continue;  // no stores
+        if ((inside || x + 3 < W) && (((uintptr_t)d + off) & 3u) == 0) {
+            pb_store3<NT>(pb_pack_px4(v[jr * 4], v[jr * 4 + 1], v[jr * 4 + 2], v[jr * 4 + 3]), d + off);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (inside || x + k < W) {
+                    d[off + 3 * k + 0] = (uint8_t)(v[jr * 4 + k] & 0xFF);
+                    d[off + 3 * k + 1] = (uint8_t)((v[jr * 4 + k] >> 8) & 0xFF);
+                    d[off + 3 * k + 2] = (uint8_t)((v[jr * 4 + k] >> 16) & 0xFF);
+                }
+        }
+    }
+}
+
+// One wave per tile, launched like pb_hot_win_kernel: `table` is the plan's LAUNCH-ORDER table (the entry says which tile it is),
+// frames of a batch are a grid dimension.  The tile's fix pixels - the model's truncation differs from the faithful one: mostly a
+// coordinate a hair from an integer, harmless here, but also the genuine discontinuities a polynomial cannot follow inside an
+// otherwise modelled tile (the edge of a lens inverse's domain, a validity or image boundary) - are redone from their exact
+// coordinates by the tile's wave after its stores, like the nearest mode's.  bil_xy == nullptr: the plan has no coordinate table
+// (it would not fit); tiles that need one, and the fix pixels, are then left to pb_bilinear_fix_kernel.
+template <int SRC_KIND>
+__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(const PbHot Hd, const PbTileEntry* __restrict__ table,
+                                                                              const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                              const unsigned groups_per_frame, unsigned long long src_stride,
+                                                                              unsigned long long dst_stride, int windows,
+                                                                              const PbBilCoord* __restrict__ bil_xy, const int32_t* __restrict__ fix_px,
+                                                                              const PbBilCoord* __restrict__ fix_xy) {
+    asm volatile("" ::"s"(table), "s"(Hd.dst_w), "s"(Hd.dst_h), "s"(Hd.src_w), "s"(Hd.src_h), "s"(Hd.win_budget), "s"(groups_per_frame));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned wg = blockIdx.x;
@@ -121,170 +547,23 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(con
     pb_load_entry(table + vslot, entry);
     const PbTileEntry* __restrict__ e = &entry;
     const int flags = e->flags;
-    if (flags & (PB_TILE_SKIP | PB_TILE_FAILED | PB_TILE_COARSE)) return;  // failed tiles, tiles whose model is too coarse to interpolate at: pb_bilinear_fix_kernel
+    if (flags & PB_TILE_SKIP) return;
+    if (e->bil_off >= 0 && !bil_xy) return;  // (no coordinate table: the float64 pass owns the tile)
     const int tx = e->tile_xy & 0xFFFF, ty = (int)((unsigned)e->tile_xy >> 16);
-    const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
-    const int xg = lane & 7, yb = lane >> 3;
-    const int W = P.dst.width, H = P.dst.height;
-    const int h = P.src.height, w = P.src.width;
-    unsigned* win = pb_wave_window(P, wave);
-    const unsigned rowbytes = 3u * (unsigned)w;
-    const unsigned frame_bytes = rowbytes * (unsigned)h;
-    const unsigned safe_len = frame_bytes & ~15u;
-    const uint8_t* s = src;
-    uint8_t* d = dst;
-    const int x = X0 + 4 * xg;
-    if ((flags & PB_TILE_LEAN) && windows) {  // (windows == 0: frames LDS-DMA cannot address)
-        const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
-        const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
-        // the model is evaluated in the order the direct-gather path below uses for this tile (column-first when the source row
-        // changes least along x): the LDS budget moves a tile between the two paths and must not move a bit of its coordinates
-        pb_f2 fv[4][4];
-        if (fabsf(e->c[1][0]) <= fabsf(e->c[5][0])) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                pb_f2 b[5];
-                pb_collapse_col(e, 4 * xg + k, b);
-#pragma unroll
-                for (int jr = 0; jr < 4; ++jr) fv[jr][k] = pb_eval_row(b, pb_tile_coord(yb + 8 * jr));
-            }
-        } else {
-#pragma unroll
-            for (int jr = 0; jr < 4; ++jr) {
-                pb_f2 a[5];
-                pb_collapse_row(e, yb + 8 * jr, a);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) fv[jr][k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
-            }
-        }
-        asm volatile("" ::: "memory");
-        pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pb_wave_sync();
-#pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            unsigned a[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = pb_bilinear_lds(win, fv[jr][k].x - 0.5f, fv[jr][k].y - 0.5f, pitch, a0);
-            // LEAN tiles lie fully inside the image
-            const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
-            if ((((uintptr_t)d + off) & 3u) == 0) {
-                pb_store3<SRC_KIND == PB_KIND_CAMERA>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
-                    d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
-                    d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
-                }
-            }
-        }
-        return;
-    }
-    if ((flags & (PB_TILE_LEAN | PB_TILE_DIRECT)) && !(flags & PB_TILE_MASKED)) {  // (MASKED: invalid pixels inside - the guarded path below)
-        // The four taps straight from the frame, unguarded (the tile's bounding box, margin texel included, lies inside the
-        // frame with room for the last 4-byte read).  wide: an 8-byte load takes both taps of a row - allowed when even the
-        // box's last tap has 8 bytes of frame behind it.  The gathers run like the nearest mode's (pb_win_tile, DIRECT): lane =
-        // pixel column (or row), 16 pixels down the other direction, sheared along the line of constant source row, so that one
-        // load instruction touches few lines whatever the tile's orientation in the source; the blended pixels are regrouped
-        // for the 12-byte stores through the wave's LDS window.  Either evaluation order of the model is certified.
-        // (round 3: c2 118 -> see experiments/README.md; the row-group order it replaces issued 4 dependent rounds of loads
-        // whose 64 lanes touched up to 64 lines each.)
-        const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
-        const bool wide = gbase + (unsigned)(e->win_rows - 1) * rowbytes + 3u * (unsigned)(e->win_cols - 1) + 8u <= frame_bytes;
-        const bool along_x = fabsf(e->c[1][0]) <= fabsf(e->c[5][0]);  // |d row / du| <= |d row / dv|
-        const int p = lane & 31, hh = lane >> 5;
-        const float num = along_x ? e->c[1][0] : e->c[5][0], den = along_x ? e->c[5][0] : e->c[1][0];
-        const float slope = (den != 0.0f) ? -num / den : 0.0f;
-        const int shift = (int)rintf(slope * ((float)p - 15.5f));
-        pb_f2 cf[5];
-        if (along_x) pb_collapse_col(e, p, cf);
-        else pb_collapse_row(e, p, cf);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {  // 8 pixels' loads in flight together (16 x 8 bytes per lane)
-            unsigned long long t8[8][2];
-            unsigned t[8][4];
-            float wy[8], wx[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int n = 8 * half + m, q = (2 * n + hh + shift) & 31;
-                const pb_f2 fv = pb_eval_row(cf, pb_tile_coord(q));
-                const float sy = fv.x - 0.5f, sx = fv.y - 0.5f;
-                const float fy0 = floorf(sy), fx0 = floorf(sx);
-                wy[m] = sy - fy0;
-                wx[m] = sx - fx0;
-                const unsigned g = gbase + (unsigned)(int)fy0 * rowbytes + __umul24((unsigned)(int)fx0, 3u);
-                if (wide) {
-                    __builtin_memcpy(&t8[m][0], s + g, 8);
-                    __builtin_memcpy(&t8[m][1], s + g + rowbytes, 8);
-                } else {
-                    __builtin_memcpy(&t[m][0], s + g, 4);
-                    __builtin_memcpy(&t[m][1], s + g + 3u, 4);
-                    __builtin_memcpy(&t[m][2], s + g + rowbytes, 4);
-                    __builtin_memcpy(&t[m][3], s + g + rowbytes + 3u, 4);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int n = 8 * half + m, q = (2 * n + hh + shift) & 31;
-                if (wide) {
-                    t[m][0] = (unsigned)t8[m][0];
-                    t[m][1] = (unsigned)(t8[m][0] >> 24);
-                    t[m][2] = (unsigned)t8[m][1];
-                    t[m][3] = (unsigned)(t8[m][1] >> 24);
-                }
-                // park as [y][x] with a 33-dword pitch (the lane's pixel is (p, q) or (q, p))
-                win[along_x ? q * 33 + p : p * 33 + q] = pb_bilinear_mix(t[m][0], t[m][1], t[m][2], t[m][3], wx[m], wy[m]);
-            }
-        }
-        pb_wave_sync();
-#pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            const unsigned* r = win + (yb + 8 * jr) * 33 + 4 * xg;
-            const unsigned long long off = 3ull * ((unsigned long long)(Y0 + yb + 8 * jr) * W + x);
-            if ((((uintptr_t)d + off) & 3u) == 0) {
-                pb_store3<SRC_KIND == PB_KIND_CAMERA>(pb_pack_px4(r[0], r[1], r[2], r[3]), d + off);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    d[off + 3 * k + 0] = (uint8_t)(r[k] & 0xFF);
-                    d[off + 3 * k + 1] = (uint8_t)((r[k] >> 8) & 0xFF);
-                    d[off + 3 * k + 2] = (uint8_t)((r[k] >> 16) & 0xFF);
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int jr = 0; jr < 4; ++jr) {
-        const int y = Y0 + yb + 8 * jr;
-        PbRowModel R;
-        pb_model_row(P, e, X0, Y0, yb + 8 * jr, 4 * xg, R);
-        unsigned a[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const pb_f2 fv = pb_eval_row(R.a, pb_tile_coord(4 * xg + k));
-            unsigned px = 0;
-            // black where the nearest mode is black: invalid destination pixel / camera position outside the image
-            const float ay = (float)R.anchor_r + fv.x, ax = (float)R.anchor_c + fv.y;
-            bool live = !(flags & PB_TILE_BLACK) && !pb_row_px_invalid(R, k) && y < H && x + k < W;
-            if (SRC_KIND == PB_KIND_CAMERA) live = live && ay >= 0.0f && ay < (float)h && ax >= 0.0f && ax < (float)w;
-            if (live) px = pb_bilinear_taps<SRC_KIND>(P, s, fv.x - 0.5f, fv.y - 0.5f, R.anchor_r, R.anchor_c);
-            a[k] = px;
-        }
-        if (y < H) {
-            const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
-            if (x + 3 < W && (((uintptr_t)d + off) & 3u) == 0) {
-                pb_store3<SRC_KIND == PB_KIND_CAMERA>(pb_pack_px4(a[0], a[1], a[2], a[3]), d + off);
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (x + k < W) {
-                        d[off + 3 * k + 0] = (uint8_t)(a[k] & 0xFF);
-                        d[off + 3 * k + 1] = (uint8_t)((a[k] >> 8) & 0xFF);
-                        d[off + 3 * k + 2] = (uint8_t)((a[k] >> 16) & 0xFF);
-                    }
-            }
+    unsigned v[16];
+    pb_bil_vals<SRC_KIND == PB_KIND_PANO>(Hd, e, flags, lane, pb_dyn_lds + (size_t)wave * ((Hd.win_budget >> 2) + 4), windows, src, bil_xy, 0, Hd.src_w, v);
+    pb_bil_store<SRC_KIND == PB_KIND_CAMERA>(v, dst, tx * PB_TILE, ty * PB_TILE, lane, Hd.dst_w, Hd.dst_h);
+    const int n_fix = e->fix_cnt;
+    if (n_fix > 0 && fix_xy && e->bil_off < 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own stores have completed
+        if (lane < n_fix) {
+            const unsigned p = (unsigned)fix_px[e->fix_off + lane];
+            const PbBilCoord q = fix_xy[e->fix_off + lane];
+            const unsigned px = pb_bil_table_px<SRC_KIND == PB_KIND_PANO>(src, q.y, q.x, Hd.src_h, Hd.src_w, 0, Hd.src_w, 3u * (unsigned)Hd.src_w * (unsigned)Hd.src_h);
+            uint8_t* o = dst + 3ull * p;
+            o[0] = (uint8_t)(px & 0xFF);
+            o[1] = (uint8_t)((px >> 8) & 0xFF);
+            o[2] = (uint8_t)((px >> 16) & 0xFF);
         }
     }
 }
@@ -404,137 +683,14 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_kernel(const PbPa
     }
 }
 
-// ---- double-fisheye source through the per-eye tile models (round 3) -----------------------------------------------------
-// The bilinear taps of ONE eye for a lane's 16 pixels (4 consecutive pixels x 4 rows, as everywhere), from the eye's tile
-// entry of the nearest mode's plan.  Coordinates are the model's, in FRAME space: the right eye's model already runs over
-// the mirrored half (its column coordinate is w - x_eye), and bilinear interpolation commutes with the mirror, so the taps
-// are the frame's texels floor(s), floor(s) + 1 of either eye - clamped to the eye's own columns [cmin, cmax) and to the
-// frame's rows, as the definition clamps them to the eye's image.  Three paths, like the single-source kernel:
-//   window   LEAN tile whose box (margin texel = the taps' reach included) lies inside the eye: the nearest mode's LDS window;
-//   direct   plain tile inside the eye: unguarded 8-byte loads of both taps of a row;
-//   clamped  a plain tile at the edge of its eye: taps clamped one by one.
-// Tiles that are not plain for an eye that sees them (partly outside the eye's image, partly invalid) are NOT served here: the
-// nearest mode's certification lets their models be sloppy where almost no pixel samples (the truncation absorbs it), which a
-// bilinear tap does not forgive - such tiles go to the float64 pass whole (pb_bilinear_double_fix_kernel, the plan's list).
-__device__ __forceinline__ unsigned pb_bilinear_taps_clamped(const uint8_t* __restrict__ s, int h, int w, int cmin, int cmax, float sy, float sx, int by, int bx) {
-    const float fy0 = floorf(sy), fx0 = floorf(sx);
-    const float ty = sy - fy0, tx = sx - fx0;
-    int r0 = by + (int)fy0, c0 = bx + (int)fx0;
-    int r1 = r0 + 1, c1 = c0 + 1;
-    r0 = min(max(r0, 0), h - 1);
-    r1 = min(max(r1, 0), h - 1);
-    c0 = min(max(c0, cmin), cmax - 1);
-    c1 = min(max(c1, cmin), cmax - 1);
-    return pb_bilinear_mix(pb_load_px(s, r0 * w + c0), pb_load_px(s, r0 * w + c1), pb_load_px(s, r1 * w + c0), pb_load_px(s, r1 * w + c1), tx, ty);
-}
-
-template <int EYE>
-__device__ __forceinline__ void pb_bilinear_eye_vals(const PbParams& P, const PbTileEntry* __restrict__ e, const int flags, const int X0, const int Y0,
-                                                     const int lane, unsigned* win, const int windows, const uint8_t* __restrict__ s, unsigned v[16]) {
-    const int xg = lane & 7, yb = lane >> 3;
-    const int h = P.src.height, w = P.src.width;
-    const unsigned rowbytes = 3u * (unsigned)w, frame_bytes = rowbytes * (unsigned)h, safe_len = frame_bytes & ~15u;
-    int cmin, cmax;
-    pb_src_col_range<EYE>(P, cmin, cmax);
-    if (!(flags & (PB_TILE_LEAN | PB_TILE_DIRECT))) {  // BLACK (callers never pass anything else that is not plain)
-#pragma unroll
-        for (int n = 0; n < 16; ++n) v[n] = 0u;
-        return;
-    }
-    const bool inside = e->win_c0 >= cmin && e->win_c0 + e->win_cols <= cmax;
-    if (inside && (flags & PB_TILE_LEAN) && windows) {
-        const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
-        const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
-        // the model is evaluated in the order the direct-gather path below uses for this tile (column-first when the source row
-        // changes least along x): the LDS budget moves a tile between the two paths and must not move a bit of its coordinates
-        pb_f2 fv[4][4];
-        if (fabsf(e->c[1][0]) <= fabsf(e->c[5][0])) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                pb_f2 b[5];
-                pb_collapse_col(e, 4 * xg + k, b);
-#pragma unroll
-                for (int jr = 0; jr < 4; ++jr) fv[jr][k] = pb_eval_row(b, pb_tile_coord(yb + 8 * jr));
-            }
-        } else {
-#pragma unroll
-            for (int jr = 0; jr < 4; ++jr) {
-                pb_f2 a[5];
-                pb_collapse_row(e, yb + 8 * jr, a);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) fv[jr][k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
-            }
-        }
-        asm volatile("" ::: "memory");
-        pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pb_wave_sync();
-#pragma unroll
-        for (int jr = 0; jr < 4; ++jr)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[jr * 4 + k] = pb_bilinear_lds(win, fv[jr][k].x - 0.5f, fv[jr][k].y - 0.5f, pitch, a0);
-        pb_wave_sync();  // the window may be refilled (the other eye)
-        return;
-    }
-    if (inside) {
-        const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
-        const bool wide = gbase + (unsigned)(e->win_rows - 1) * rowbytes + 3u * (unsigned)(e->win_cols - 1) + 8u <= frame_bytes;
-#pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            pb_f2 c[5];
-            pb_collapse_row(e, yb + 8 * jr, c);
-            unsigned long long t8[4][2];
-            unsigned t[4][4];
-            float wy[4], wx[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const pb_f2 fv = pb_eval_row(c, pb_tile_coord(4 * xg + k));
-                const float sy = fv.x - 0.5f, sx = fv.y - 0.5f;
-                const float fy0 = floorf(sy), fx0 = floorf(sx);
-                wy[k] = sy - fy0;
-                wx[k] = sx - fx0;
-                const unsigned g = gbase + (unsigned)(int)fy0 * rowbytes + __umul24((unsigned)(int)fx0, 3u);
-                if (wide) {
-                    __builtin_memcpy(&t8[k][0], s + g, 8);
-                    __builtin_memcpy(&t8[k][1], s + g + rowbytes, 8);
-                } else {
-                    __builtin_memcpy(&t[k][0], s + g, 4);
-                    __builtin_memcpy(&t[k][1], s + g + 3u, 4);
-                    __builtin_memcpy(&t[k][2], s + g + rowbytes, 4);
-                    __builtin_memcpy(&t[k][3], s + g + rowbytes + 3u, 4);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (wide) {
-                    t[k][0] = (unsigned)t8[k][0];
-                    t[k][1] = (unsigned)(t8[k][0] >> 24);
-                    t[k][2] = (unsigned)t8[k][1];
-                    t[k][3] = (unsigned)(t8[k][1] >> 24);
-                }
-                v[jr * 4 + k] = pb_bilinear_mix(t[k][0], t[k][1], t[k][2], t[k][3], wx[k], wy[k]);
-            }
-        }
-        return;
-    }
-    // a plain tile at the edge of its eye: every pixel is live (that is what plain means), the taps are clamped one by one
-#pragma unroll
-    for (int jr = 0; jr < 4; ++jr) {
-        pb_f2 c[5];
-        pb_collapse_row(e, yb + 8 * jr, c);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const pb_f2 fv = pb_eval_row(c, pb_tile_coord(4 * xg + k));
-            v[jr * 4 + k] = pb_bilinear_taps_clamped(s, h, w, cmin, cmax, fv.x - 0.5f, fv.y - 0.5f, e->anchor_r, e->anchor_c);
-        }
-    }
-}
-
-// One wave per tile, launched like pb_hot_double_kernel over the plan's launch-order table (frames of a batch: a grid
-// dimension).  A tile that sees ONE eye with weight exactly 1 (PB_TILE_SOLO: its slot carries the live eye's entry) is that
-// eye's bilinear sample; a two-eye tile samples the left eye, then the right eye (through the same LDS window), and blends
-// with the tile's weight class like the nearest mode - UNIT: the integer sum, ROW: the row table, LAT: the stored latitudes.
-// Failed tiles and the plan's fix pixels take the float64 chain (pb_bilinear_double_fix_kernel, behind this launch).
+// ---- double-fisheye source -------------------------------------------------------------------------------------------------
+// One wave per tile, launched like pb_hot_double_kernel over the plan's launch-order table (frames of a batch: a grid dimension).
+// A tile that sees ONE eye with weight exactly 1 (PB_TILE_SOLO: its slot carries the live eye's entry) is that eye's bilinear sample
+// - the single-source tile code with the eye's column range.  A two-eye tile samples the left eye, then the right eye (through the
+// same LDS window), each by its own entry's path (table / black / window / direct), and blends with the tile's weight class like the
+// nearest mode: UNIT the integer sum, ROW the row table, LAT the stored latitudes; a FAILED tile (both eyes from the coordinate
+// table) blends with the faithful factors the nearest mode stores for its pixels (PbDoubleFix).  The fix pixels of either eye's
+// list are redone from their exact coordinates and stored factors after the wave's stores.
 template <int WMODE>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_double_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
                                                                                      const PbTileEntry* __restrict__ table_r,
@@ -543,7 +699,13 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_double_hot_ker
                                                                                      const double* __restrict__ lat_tab,
                                                                                      const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                                      const unsigned groups_per_frame, unsigned long long src_stride,
-                                                                                     unsigned long long dst_stride, int windows) {
+                                                                                     unsigned long long dst_stride, int windows,
+                                                                                     const PbBilCoord* __restrict__ bil_xy, const int32_t* __restrict__ fix_px,
+                                                                                     const PbBilCoord* __restrict__ fix_xy,
+                                                                                     const PbDoubleFix* __restrict__ tile_fix,
+                                                                                     const PbDoubleFix* __restrict__ px_fix) {
+    const PbHot Hd = pb_hot_of(P);
+    asm volatile("" ::"s"(ltable), "s"(Hd.dst_w), "s"(Hd.dst_h), "s"(Hd.src_w), "s"(Hd.src_h), "s"(Hd.win_budget), "s"(groups_per_frame));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned wg = blockIdx.x;
@@ -560,26 +722,37 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_double_hot_ker
     const int tx = entry.tile_xy & 0xFFFF, ty = (int)((unsigned)entry.tile_xy >> 16);
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
     const int xg = lane & 7, yb = lane >> 3;
-    const int W = P.dst.width, H = P.dst.height;
-    unsigned* win = pb_wave_window(P, wave, 8);
+    const int W = Hd.dst_w, H = Hd.dst_h, eye_w = P.src_eye_w;
+    unsigned* win = pb_dyn_lds + (size_t)wave * ((Hd.win_budget >> 2) + 8);
     unsigned a[16];
     if (entry.flags & PB_TILE_SOLO) {
-        if (entry.flags & PB_TILE_COARSE) return;  // (on the plan's float64 list)
-        if (entry.flags & PB_TILE_EYE_R)
-            pb_bilinear_eye_vals<PB_KIND_EYE_R>(P, &entry, entry.flags, X0, Y0, lane, win, windows, src, a);
-        else
-            pb_bilinear_eye_vals<PB_KIND_EYE_L>(P, &entry, entry.flags, X0, Y0, lane, win, windows, src, a);
+        if (entry.bil_off >= 0 && !bil_xy) return;  // (no coordinate table: on the plan's float64 list)
+        const bool right = (entry.flags & PB_TILE_EYE_R) != 0;
+        pb_bil_vals<false>(Hd, &entry, entry.flags, lane, win, windows, src, bil_xy, right ? eye_w : 0, right ? Hd.src_w : eye_w, a);
+        pb_bil_store<false>(a, dst, X0, Y0, lane, W, H);
+        return;
+    }
+    const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
+    pb_load_entry(table_l + tile, entry);
+    const int fl0 = entry.flags, lat_slot = entry.aux_off, nl = entry.fix_cnt, off_l = entry.fix_off;
+    if (entry.bil_off >= 0 && !bil_xy) return;
+    unsigned al[16];
+    pb_bil_vals<false>(Hd, &entry, fl0, lane, win, windows, src, bil_xy, 0, eye_w, al);
+    pb_load_entry(table_r + tile, entry);
+    if (entry.bil_off >= 0 && !bil_xy) return;
+    const int nr = entry.fix_cnt, off_r = entry.fix_off;
+    pb_bil_vals<false>(Hd, &entry, entry.flags, lane, win, windows, src, bil_xy, eye_w, Hd.src_w, a);
+    if (fl0 & PB_TILE_FAILED) {
+        // the faithful factors of every pixel of a failed tile (slot = the right-eye entry's aux_off, pb_double_tables_kernel)
+        const PbDoubleFix* __restrict__ slot = tile_fix + (size_t)entry.aux_off * (PB_TILE * PB_TILE);
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const PbDoubleFix* __restrict__ t = slot + (yb + 8 * jr) * PB_TILE + 4 * xg + k;
+                a[jr * 4 + k] = pb_sep_blend(al[jr * 4 + k], a[jr * 4 + k], t->fl, t->fr);
+            }
     } else {
-        const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
-        pb_load_entry(table_l + tile, entry);
-        const int fl0 = entry.flags, lat_slot = entry.aux_off;
-        const int served = PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK;
-        if ((fl0 & (PB_TILE_FAILED | PB_TILE_COARSE)) || !(fl0 & served)) return;  // failed, coarse, or not plain for the left eye: the float64 pass's (pb_bilinear_tile_list_kernel)
-        unsigned al[16];
-        pb_bilinear_eye_vals<PB_KIND_EYE_L>(P, &entry, fl0, X0, Y0, lane, win, windows, src, al);
-        pb_load_entry(table_r + tile, entry);
-        if (!(entry.flags & served) || (entry.flags & PB_TILE_COARSE)) return;
-        pb_bilinear_eye_vals<PB_KIND_EYE_R>(P, &entry, entry.flags, X0, Y0, lane, win, windows, src, a);
         const bool by_row = WMODE == 1 && (fl0 & PB_TILE_W_ROW) != 0;
         const bool by_lat = WMODE == 2 && (fl0 & PB_TILE_W_LAT) != 0;
 #pragma unroll
@@ -601,39 +774,80 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_double_hot_ker
             }
         }
     }
-    const int x = X0 + 4 * xg;
-#pragma unroll
-    for (int jr = 0; jr < 4; ++jr) {
-        const int y = Y0 + yb + 8 * jr;
-        if (y >= H) continue;
-        const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
-        if (x + 3 < W && (((uintptr_t)dst + off) & 3u) == 0) {
-            pb_store3<false>(pb_pack_px4(a[jr * 4], a[jr * 4 + 1], a[jr * 4 + 2], a[jr * 4 + 3]), dst + off);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (x + k < W) {
-                    dst[off + 3 * k + 0] = (uint8_t)(a[jr * 4 + k] & 0xFF);
-                    dst[off + 3 * k + 1] = (uint8_t)((a[jr * 4 + k] >> 8) & 0xFF);
-                    dst[off + 3 * k + 2] = (uint8_t)((a[jr * 4 + k] >> 16) & 0xFF);
-                }
+    pb_bil_store<false>(a, dst, X0, Y0, lane, W, H);
+    if (nl + nr > 0 && fix_xy) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own stores have completed
+        const unsigned frame_bytes = 3u * (unsigned)Hd.src_w * (unsigned)Hd.src_h;
+        for (int base = 0; base < nl + nr; base += 64) {
+            const int n = base + lane;
+            if (n < nl + nr) {
+                const int item = n < nl ? off_l + n : off_r + (n - nl);
+                const unsigned p = (unsigned)fix_px[item];
+                const PbBilCoord ql = fix_xy[2 * item], qr = fix_xy[2 * item + 1];
+                const unsigned l = pb_bil_table_px<false>(src, ql.y, ql.x, Hd.src_h, Hd.src_w, 0, eye_w, frame_bytes);
+                const unsigned r = pb_bil_table_px<false>(src, qr.y, qr.x, Hd.src_h, Hd.src_w, eye_w, Hd.src_w, frame_bytes);
+                const unsigned px = pb_sep_blend(l, r, px_fix[item].fl, px_fix[item].fr);
+                uint8_t* o = dst + 3ull * p;
+                o[0] = (uint8_t)(px & 0xFF);
+                o[1] = (uint8_t)((px >> 8) & 0xFF);
+                o[2] = (uint8_t)((px >> 16) & 0xFF);
+            }
         }
     }
 }
 
-// Plan creation (double-fisheye plans): the tiles pb_bilinear_double_hot_kernel does not serve - an eye sees the tile but the
-// tile is not plain for it - listed once (the budget only moves tiles between LEAN and DIRECT, never in or out of this list).
-__global__ void pb_bilinear_tile_list_kernel(const PbTileEntry* __restrict__ table_l, const PbTileEntry* __restrict__ table_r, unsigned n_tiles,
-                                             int32_t* __restrict__ list, unsigned* __restrict__ count) {
+// ---- plan creation -------------------------------------------------------------------------------------------------------------
+// Which tiles the models cannot serve in this mode, per source / eye: failed tiles, COARSE models (beyond 1/1024 px of the faithful
+// coordinate somewhere: fine for the truncating sampler, whose exceptions are tabulated; too coarse to interpolate at), tiles that
+// are not plain (generic: partly outside the image or the eye, wrapping; MASKED: invalid destination pixels inside), and - an eye -
+// plain tiles whose taps' reach leaves the eye's own columns.  Each gets a slot of the coordinate table (PbTileEntry::bil_off);
+// `list` names the tiles with a slot that are not on the fail list (what the float64 fallback pass recomputes besides the failed
+// tiles).  counters: [0] tiles listed, [1] slots handed out.  The LDS budget only moves tiles between LEAN and DIRECT, never in or
+// out of this set.
+__device__ __forceinline__ bool pb_bil_needs_table(const PbTileEntry& e, bool eye, int cmin, int cmax) {
+    const int f = e.flags;
+    if (f & PB_TILE_FAILED) return true;
+    if (f & PB_TILE_BLACK) return false;
+    if (!(f & (PB_TILE_LEAN | PB_TILE_DIRECT))) return true;
+    if (f & (PB_TILE_COARSE | PB_TILE_MASKED)) return true;
+    return eye && !(e.win_c0 >= cmin && e.win_c0 + e.win_cols <= cmax);
+}
+__global__ void pb_bilinear_tile_list_kernel(PbTileEntry* __restrict__ table_l, PbTileEntry* __restrict__ table_r, unsigned n_tiles, int eye_w, int src_w,
+                                             int32_t* __restrict__ list, unsigned* __restrict__ counters) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
-    // (single-source plans: table_r == nullptr, and only COARSE tiles are listed - the single-source bilinear kernel serves
-    // generic tiles itself)
-    const int fl = table_l[t].flags, fr = table_r ? table_r[t].flags : 0;
-    const int served = PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK;
-    if ((fl | fr) & PB_TILE_FAILED) return;  // on the fail list already
-    const bool coarse = ((fl | fr) & PB_TILE_COARSE) != 0;
-    if (coarse || (table_r && (!(fl & served) || !(fr & served)))) list[atomicAdd(count, 1u)] = (int32_t)t;
+    const bool need_l = pb_bil_needs_table(table_l[t], table_r != nullptr, 0, eye_w);
+    const bool need_r = table_r && pb_bil_needs_table(table_r[t], true, eye_w, src_w);
+    table_l[t].bil_off = need_l ? (int)atomicAdd(&counters[1], 1u) : -1;
+    if (table_r) table_r[t].bil_off = need_r ? (int)atomicAdd(&counters[1], 1u) : -1;
+    const bool failed = ((table_l[t].flags | (table_r ? table_r[t].flags : 0)) & PB_TILE_FAILED) != 0;
+    if ((need_l || need_r) && !failed) list[atomicAdd(&counters[0], 1u)] = (int32_t)t;
+}
+
+// fills the coordinate table: 4 blocks per tile, every tile with a slot (pixels beyond the image repeat the edge: never stored)
+template <int SRC_KIND>
+__global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_coord_kernel(const PbParams P, const PbTileEntry* __restrict__ table, PbBilCoord* __restrict__ bil_xy) {
+    const int t = blockIdx.x >> 2;
+    const int slot = table[t].bil_off;
+    if (slot < 0) return;
+    const int ty = t / pb_tiles_x(P), tx = t - ty * pb_tiles_x(P);
+    const int local = (blockIdx.x & 3) * 256 + threadIdx.x;
+    const int i = min(ty * PB_TILE + (local >> 5), P.dst.height - 1), j = min(tx * PB_TILE + (local & 31), P.dst.width - 1);
+    PbCoord c = pb_dst_coord(P, i, j);
+    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    bil_xy[(size_t)slot * (PB_TILE * PB_TILE) + local] = pb_bil_coord_of<SRC_KIND>(P, c);
+}
+// ... and the fix list's: out[item * stride + offset]
+template <int SRC_KIND>
+__global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_fix_coord_kernel(const PbParams P, const int32_t* __restrict__ fix_px, int n_fix_px,
+                                                                         PbBilCoord* __restrict__ out, int stride, int offset) {
+    const unsigned item = blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (item >= (unsigned)n_fix_px) return;
+    const unsigned p = (unsigned)fix_px[item];
+    const int i = (int)(p / (unsigned)P.dst.width), j = (int)(p - (unsigned)i * (unsigned)P.dst.width);
+    PbCoord c = pb_dst_coord(P, i, j);
+    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    out[(size_t)item * stride + offset] = pb_bil_coord_of<SRC_KIND>(P, c);
 }
 
 // behind pb_bilinear_double_hot_kernel: the plan's failed tiles and the tiles of the list above (4 blocks each), then the fix

@@ -819,8 +819,11 @@ __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, 
     if (lane == offsetof(PbTileEntry, tile_xy) / 4) w = (ty << 16) | tx;
     out[lane] = w;
 }
-__device__ __forceinline__ float pb_tile_cost(const PbTileEntry& e) {
+// bil: the opt-in bilinear mode's launch order - a tile served from the exact coordinate table (bil_off >= 0: four clamped gathers per
+// pixel) is the slowest class there
+__device__ __forceinline__ float pb_tile_cost(const PbTileEntry& e, const bool bil = false) {
     const int f = e.flags;
+    if (bil && e.bil_off >= 0) return 2.5f;
     return (f & PB_TILE_BLACK) ? 0.3f
          : (f & PB_TILE_LEAN) ? 0.55f + 0.055f * (float)(e.win_rows * 16 * e.win_n16) / 1024.0f
          : (f & PB_TILE_DIRECT) ? fminf(2.0f, 0.85f + 0.0027f * (float)e.win_cols)
@@ -831,11 +834,11 @@ __device__ __forceinline__ float pb_tile_cost(const PbTileEntry& e) {
 // 9.5 + 0.03 per source column on a direct-gather tile - here relative to a direct-gather tile of ordinary width.
 __global__ void pb_unit_cost_kernel(const PbTileEntry* __restrict__ table, unsigned n_tiles, unsigned tiles_x, unsigned unit_tiles,
                                     unsigned units_x, unsigned* __restrict__ unit_cost, const PbTileEntry* __restrict__ table_r = nullptr,
-                                    unsigned unit_tiles_y = 0) {
+                                    unsigned unit_tiles_y = 0, int bil = 0) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
-    float c = pb_tile_cost(table[t]);
-    if (table_r) c += pb_tile_cost(table_r[t]) - 0.3f;  // double-fisheye source: both eyes' work (a one-eye tile costs its live eye's)
+    float c = pb_tile_cost(table[t], bil != 0);
+    if (table_r) c += pb_tile_cost(table_r[t], bil != 0) - 0.3f;  // double-fisheye source: both eyes' work (a one-eye tile costs its live eye's)
     const unsigned ty = t / tiles_x, tx = t - ty * tiles_x;
     atomicAdd(&unit_cost[(ty / (unit_tiles_y ? unit_tiles_y : unit_tiles)) * units_x + tx / unit_tiles], (unsigned)(c * 1024.0f + 0.5f));
 }
@@ -984,6 +987,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_model_kernel(const PbPa
         e->win_rows = 0;
         e->win_r0 = e->win_c0 = e->win_cols = e->win_n16 = e->win_a0 = 0;
         e->fix_off = e->fix_cnt = 0;
+        e->aux_off = 0;
+        e->bil_off = -1;
     }
 }
 

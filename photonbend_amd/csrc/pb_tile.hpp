@@ -67,7 +67,7 @@ struct __attribute__((aligned(256))) PbTileEntry {
     int32_t aux_off;             // double sources, left-eye entry: the tile's slot in the plan's latitude table (PB_TILE_W_LAT)
     int32_t tile_xy;             // launch-order copy (pb_launch_table_kernel): the tile this entry belongs to, ty << 16 | tx
                                  // (16 bits each: tile plans exist for destinations up to 16384 px a side - pb_fast_possible)
-    int32_t pad1;
+    int32_t bil_off;             // opt-in bilinear mode: the tile's slot in the plan's exact coordinate table (pb_kernels_bilinear.hpp), -1 = the model serves it
 };
 static_assert(sizeof(PbTileEntry) == 256, "PbTileEntry must be 256 bytes");
 

@@ -63,6 +63,17 @@ struct pb_plan {
     PbTileEntry* ltable = nullptr;
     int32_t* bil_tiles = nullptr;  // tiles the bilinear tile kernels leave to the float64 pass: PB_TILE_COARSE models; double-fisheye plans also tiles an eye sees but that are not plain for it
     unsigned n_bil_tiles = 0;
+    // the bilinear mode's exact coordinate tables (pb_kernels_bilinear.hpp): 8 KiB per slot (PbTileEntry::bil_off), and the fix list's
+    // coordinates (two per pixel for a double-fisheye source); nullptr = the tables would not fit, those tiles take the float64 pass
+    PbBilCoord* bil_xy = nullptr;
+    PbBilCoord* bil_fix_xy = nullptr;
+    unsigned n_bil_slots = 0;
+    // ... and its own launch-order table, classified under ITS window budget (PB_BIL_WIN_BUDGET: a direct-gather tile costs the
+    // bilinear mode two 8-byte loads per pixel, the nearest mode one dword - its best budget is larger) and ordered by its own costs;
+    // built once per plan (pb_build_bilinear_launch), untouched by pb_plan_set_window_budget
+    PbTileEntry* ltable_bil = nullptr;
+    unsigned launch_groups_bil = 0;
+    int bil_budget = 0;
     PbParams* P_dev = nullptr;   // device copy of P as the hot launches see it (refreshed with every budget change)
     unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
     int walk = 0;                // launch-order rule: 0 = by policy (pb_build_launch_table), 1 = plain, 2 = rows from the heaviest outwards,
@@ -170,26 +181,66 @@ static bool pb_fast_possible(const PbParams& P) {
            P.src.height < (1 << 24);
 }
 
-// the bilinear mode's float64 tile list (pb_bilinear_tile_list_kernel); derived state, not serialized
+// the bilinear mode's plan state (pb_kernels_bilinear.hpp): which tiles the models cannot serve, their slots in the exact coordinate
+// table, the table itself and the fix list's coordinates - all from the faithful float64 chain, once per plan; derived state, not
+// serialized (rebuilt from the tile tables).  Synchronous.
 static int pb_build_bilinear_list(pb_plan* pl) {
+    const PbParams& P = pl->P;
     unsigned* cnt = nullptr;
     (void)hipFree(pl->bil_tiles);
+    (void)hipFree(pl->bil_xy);
+    (void)hipFree(pl->bil_fix_xy);
     pl->bil_tiles = nullptr;
-    pl->n_bil_tiles = 0;
-    PB_HIP(hipMalloc((void**)&cnt, sizeof(unsigned)));
-    hipError_t e = hipMemset(cnt, 0, sizeof(unsigned));
+    pl->bil_xy = pl->bil_fix_xy = nullptr;
+    pl->n_bil_tiles = pl->n_bil_slots = 0;
+    PB_HIP(hipMalloc((void**)&cnt, 2 * sizeof(unsigned)));
+    hipError_t e = hipMemset(cnt, 0, 2 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc((void**)&pl->bil_tiles, (size_t)(pl->n_tiles ? pl->n_tiles : 1) * sizeof(int32_t));
+    unsigned res[2] = {0u, 0u};
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(pb_bilinear_tile_list_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->table_r, pl->n_tiles, pl->bil_tiles, cnt);
-        e = hipMemcpy(&pl->n_bil_tiles, cnt, sizeof(unsigned), hipMemcpyDeviceToHost);
+        hipLaunchKernelGGL(pb_bilinear_tile_list_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->table_r, pl->n_tiles, P.src_eye_w,
+                           P.src.width, pl->bil_tiles, cnt);
+        e = hipMemcpy(res, cnt, sizeof(res), hipMemcpyDeviceToHost);
     }
     (void)hipFree(cnt);
+    const bool dbl = pl->table_r != nullptr;
+    // the tables: sources the 1/4096-px fixed point holds, and at most 1 GiB of coordinates (a geometry the models mostly cannot
+    // follow keeps the float64 pass)
+    const bool tables = e == hipSuccess && P.src.width < PB_BIL_MAX_DIM && P.src.height < PB_BIL_MAX_DIM && (size_t)P.src.width * P.src.height >= 3 &&
+                        (size_t)res[1] * PB_TILE * PB_TILE * sizeof(PbBilCoord) <= ((size_t)1 << 30);
+    if (tables) {
+        const unsigned np = pl->n_fix_px, stride = dbl ? 2u : 1u;
+        e = hipMalloc((void**)&pl->bil_xy, (size_t)(res[1] ? res[1] : 1u) * PB_TILE * PB_TILE * sizeof(PbBilCoord));
+        if (e == hipSuccess) e = hipMalloc((void**)&pl->bil_fix_xy, (size_t)(np ? np : 1u) * stride * sizeof(PbBilCoord));
+        if (e == hipSuccess) {
+            const dim3 grid(4u * pl->n_tiles), block(PB_BLOCK), fgrid((np + PB_BLOCK - 1) / PB_BLOCK);
+            if (dbl) {
+                hipLaunchKernelGGL(pb_bilinear_coord_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table, pl->bil_xy);
+                hipLaunchKernelGGL(pb_bilinear_coord_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r, pl->bil_xy);
+                if (np) {
+                    hipLaunchKernelGGL(pb_bilinear_fix_coord_kernel<PB_KIND_EYE_L>, fgrid, block, 0, 0, P, pl->fix_px, (int)np, pl->bil_fix_xy, 2, 0);
+                    hipLaunchKernelGGL(pb_bilinear_fix_coord_kernel<PB_KIND_EYE_R>, fgrid, block, 0, 0, P, pl->fix_px, (int)np, pl->bil_fix_xy, 2, 1);
+                }
+            } else if (P.src.kind == PB_KIND_PANO) {
+                hipLaunchKernelGGL(pb_bilinear_coord_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table, pl->bil_xy);
+                if (np) hipLaunchKernelGGL(pb_bilinear_fix_coord_kernel<PB_KIND_PANO>, fgrid, block, 0, 0, P, pl->fix_px, (int)np, pl->bil_fix_xy, 1, 0);
+            } else {
+                hipLaunchKernelGGL(pb_bilinear_coord_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table, pl->bil_xy);
+                if (np) hipLaunchKernelGGL(pb_bilinear_fix_coord_kernel<PB_KIND_CAMERA>, fgrid, block, 0, 0, P, pl->fix_px, (int)np, pl->bil_fix_xy, 1, 0);
+            }
+            e = hipDeviceSynchronize();
+        }
+    }
     if (e != hipSuccess) {
         (void)hipFree(pl->bil_tiles);
+        (void)hipFree(pl->bil_xy);
+        (void)hipFree(pl->bil_fix_xy);
         pl->bil_tiles = nullptr;
-        pl->n_bil_tiles = 0;
-        return pb_fail(PB_ERR_HIP, std::string("bilinear tile list: ") + hipGetErrorString(e));
+        pl->bil_xy = pl->bil_fix_xy = nullptr;
+        return pb_fail(PB_ERR_HIP, std::string("bilinear tables: ") + hipGetErrorString(e));
     }
+    pl->n_bil_tiles = res[0];
+    pl->n_bil_slots = res[1];
     return PB_OK;
 }
 
@@ -271,7 +322,6 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                 }
             }
             pl->n_tiles = ntiles;
-            if (pb_build_bilinear_list(pl) != PB_OK) { rc = PB_ERR_HIP; break; }
             pl->n_lean_tiles = res[4];
             pl->n_black_tiles = res[5];
             pl->n_direct_tiles = res[6];
@@ -279,7 +329,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             pl->n_fix_px = res[0] > cap ? cap : res[0];
             pl->n_fail_tiles = res[1];
             pl->diff_pixels = res[2];
-            pl->n_tiles = ntiles;
+            if (pb_build_bilinear_list(pl) != PB_OK) { rc = PB_ERR_HIP; break; }
             pl->dbl_ready = 1;
             break;
         }
@@ -333,8 +383,9 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         (void)hipFree(pl->table); (void)hipFree(pl->fail_tiles); (void)hipFree(pl->fix_px); (void)hipFree(pl->idx_tab); (void)hipFree(pl->fix_idx);
         pl->idx_tab = nullptr; pl->fix_idx = nullptr;
         (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols); (void)hipFree(pl->table_r); (void)hipFree(pl->lat_tab);
-        (void)hipFree(pl->dbl_tile_fix); (void)hipFree(pl->dbl_px_fix); (void)hipFree(pl->bil_tiles);
+        (void)hipFree(pl->dbl_tile_fix); (void)hipFree(pl->dbl_px_fix); (void)hipFree(pl->bil_tiles); (void)hipFree(pl->bil_xy); (void)hipFree(pl->bil_fix_xy);
         pl->dbl_tile_fix = nullptr; pl->dbl_px_fix = nullptr; pl->bil_tiles = nullptr; pl->n_bil_tiles = 0;
+        pl->bil_xy = pl->bil_fix_xy = nullptr; pl->n_bil_slots = 0;
         pl->table_r = nullptr; pl->lat_tab = nullptr; pl->sep_ready = 0; pl->dbl_ready = 0;
         pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr; pl->sep_rows = nullptr; pl->sep_cols = nullptr;
     }
@@ -430,8 +481,10 @@ static int pb_clamp_budget(int budget) {
 // failed and direct-gather tiles): then the super-tiles go heaviest first, dealt round-robin (c3 37.9 -> 35.1 us).  Double-fisheye
 // plans walk top to bottom and let columns of super-tiles change XCD when one XCD runs ahead (the policy is spelled out where it
 // is applied, below).  -DPB_ABLATION builds: PB_ORDER=1 forces top-to-bottom.  Synchronous.
-static int pb_build_launch_table(pb_plan* pl) {
+static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
     PbParams& P = pl->P;
+    PbTileEntry*& out_table = bil ? pl->ltable_bil : pl->ltable;
+    unsigned& out_groups = bil ? pl->launch_groups_bil : pl->launch_groups;
     if (!pl->fast_ready && !pl->dbl_ready) return PB_OK;  // (a double-fisheye plan: the left eye's table + PB_TILE_SOLO entries)
     const unsigned tiles_x = (P.dst.width + PB_TILE - 1) / PB_TILE, tiles_y = (P.dst.height + PB_TILE - 1) / PB_TILE;
     const unsigned gx = (tiles_x + 1) / 2, gy = (tiles_y + 1) / 2;
@@ -465,20 +518,20 @@ static int pb_build_launch_table(pb_plan* pl) {
             std::vector<unsigned> fixed(ns, 0u);
             unsigned* cost_dev = nullptr;
             if (hipMalloc((void**)&cost_dev, ns * sizeof(unsigned)) != hipSuccess) {
-                (void)hipFree(pl->ltable);  // (the old table may be classified under another budget)
-                pl->ltable = nullptr;
-                pl->launch_groups = 0;
+                (void)hipFree(out_table);  // (the old table may be classified under another budget)
+                out_table = nullptr;
+                out_groups = 0;
                 return pb_fail(PB_ERR_HIP, "launch table: out of device memory");
             }
             (void)hipMemsetAsync(cost_dev, 0, ns * sizeof(unsigned), 0);
             hipLaunchKernelGGL(pb_unit_cost_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->n_tiles, tiles_x, 2u * U, sgx, cost_dev,
-                               pl->dbl_ready ? pl->table_r : nullptr, 2u * UY);
+                               pl->dbl_ready ? pl->table_r : nullptr, 2u * UY, bil ? 1 : 0);
             const hipError_t ce = hipMemcpy(fixed.data(), cost_dev, ns * sizeof(unsigned), hipMemcpyDeviceToHost);
             (void)hipFree(cost_dev);
             if (ce != hipSuccess) {
-                (void)hipFree(pl->ltable);
-                pl->ltable = nullptr;
-                pl->launch_groups = 0;
+                (void)hipFree(out_table);
+                out_table = nullptr;
+                out_groups = 0;
                 return pb_fail(PB_ERR_HIP, std::string("launch table: ") + hipGetErrorString(ce));
             }
             std::vector<float> row_cost(sgy, 0.f);
@@ -568,12 +621,12 @@ static int pb_build_launch_table(pb_plan* pl) {
     // launch table (ltable == nullptr, launch_groups == 0 - its launches then take the direct-gather kernels), never with a
     // half-written one or one classified under another budget
     const unsigned n_slots = 4u * n_groups;
-    (void)hipFree(pl->ltable);
-    pl->ltable = nullptr;
-    pl->launch_groups = 0;
+    (void)hipFree(out_table);
+    out_table = nullptr;
+    out_groups = 0;
     PbTileEntry* fresh = nullptr;
     int* unit_dev = nullptr;
-    hipError_t e = pb_test_alloc_fails() ? hipErrorOutOfMemory : hipMalloc((void**)&fresh, (size_t)n_slots * sizeof(PbTileEntry));
+    hipError_t e = (!bil && pb_test_alloc_fails()) ? hipErrorOutOfMemory : hipMalloc((void**)&fresh, (size_t)n_slots * sizeof(PbTileEntry));  // (the test hook counts the nearest mode's tables)
     if (e == hipSuccess && units) {
         e = hipMalloc((void**)&unit_dev, unit_of.size() * sizeof(int));
         if (e == hipSuccess) e = hipMemcpy(unit_dev, unit_of.data(), unit_of.size() * sizeof(int), hipMemcpyHostToDevice);
@@ -589,15 +642,13 @@ static int pb_build_launch_table(pb_plan* pl) {
         (void)hipGetLastError();
         return pb_fail(PB_ERR_HIP, std::string("launch table: ") + hipGetErrorString(e));
     }
-    pl->ltable = fresh;
-    pl->launch_groups = n_groups;
+    out_table = fresh;
+    out_groups = n_groups;
     return PB_OK;
 }
 
-// keeps the certified flags (once) and applies `budget` to them; synchronous on the default stream
-static int pb_apply_budget(pb_plan* pl, int budget) {
-    PbParams& P = pl->P;
-    if (!(pl->fast_ready || pl->dbl_ready)) return PB_OK;
+// keeps the certified flags (once) and writes the flags under `budget` into the tile tables; counts = {LEAN, DIRECT} tiles.  Synchronous.
+static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2]) {
     const unsigned nt = pl->n_tiles;
     const dim3 g((nt + 255) / 256), b(256);
     if (!pl->saved_l) {
@@ -611,20 +662,58 @@ static int pb_apply_budget(pb_plan* pl, int budget) {
     unsigned* counters = nullptr;
     PB_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
     (void)hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
-    budget = pb_clamp_budget(budget);
     if (pl->dbl_ready)
         hipLaunchKernelGGL(pb_budget_double_kernel, g, b, 0, 0, pl->table, pl->table_r, pl->saved_l, pl->saved_r, nt, budget, counters);
     else
         hipLaunchKernelGGL(pb_budget_kernel, g, b, 0, 0, pl->table, pl->saved_l, nt, budget, counters);
-    P.win_budget = budget;
     unsigned res[4] = {0, 0, 0, 0};
     const hipError_t e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
     (void)hipFree(counters);
     PB_HIP(e);
-    pl->n_lean_tiles = res[0];
-    pl->n_direct_tiles = res[1];
+    counts[0] = res[0];
+    counts[1] = res[1];
+    return PB_OK;
+}
+
+// The bilinear mode's launch-order table: the tiles classified under PB_BIL_WIN_BUDGET, ordered by the bilinear mode's costs.  Leaves
+// the tile tables' flags under THAT budget: pb_apply_budget (the nearest mode's) must follow.  A failure leaves the plan without the
+// table (the bilinear launches then take the float64 kernels), never with a stale one.  Synchronous.
+#define PB_BIL_WIN_BUDGET PB_WINLDS_MAX  // measured on MI355X (experiments/r4/budget_bil.sh): c1 28.7 us at 7 KiB, 25.2 at 12; c2 68.9 / 62.0; c5 109.8 / 103.4; c3 58.3 / 58.9
+static int pb_build_bilinear_launch(pb_plan* pl) {
+    if (!(pl->fast_ready || pl->dbl_ready)) return PB_OK;
+    (void)hipFree(pl->ltable_bil);
+    pl->ltable_bil = nullptr;
+    pl->launch_groups_bil = 0;
+    pl->bil_budget = pb_clamp_budget(PB_BIL_WIN_BUDGET);
+    unsigned counts[2];
+    int rc = pb_classify_under_budget(pl, pl->bil_budget, counts);
+    if (rc == PB_OK) rc = pb_build_launch_table(pl, true);
+    return rc;
+}
+
+// applies `budget` to the certified flags and rebuilds the nearest mode's launch-order table; synchronous on the default stream
+static int pb_apply_budget(pb_plan* pl, int budget) {
+    PbParams& P = pl->P;
+    if (!(pl->fast_ready || pl->dbl_ready)) return PB_OK;
+    budget = pb_clamp_budget(budget);
+    // the parameter block as the launches will see it goes up BEFORE anything of the plan changes (a failure used to
+    // leave the old launch table, classified under the old budget, next to the new budget)
+    PbParams Q = P;
+    Q.win_budget = budget;
     if (!pl->P_dev) PB_HIP(hipMalloc((void**)&pl->P_dev, sizeof(PbParams)));
-    PB_HIP(hipMemcpy(pl->P_dev, &P, sizeof(PbParams), hipMemcpyHostToDevice));
+    unsigned counts[2];
+    int rc = pb_classify_under_budget(pl, budget, counts);
+    if (rc == PB_OK && hipMemcpy(pl->P_dev, &Q, sizeof(PbParams), hipMemcpyHostToDevice) != hipSuccess) rc = pb_fail(PB_ERR_HIP, "parameter block upload failed");
+    if (rc != PB_OK) {
+        // the table may be half reclassified: no launch table at all (launches take the direct-gather kernels, which read no budget)
+        (void)hipFree(pl->ltable);
+        pl->ltable = nullptr;
+        pl->launch_groups = 0;
+        return rc;
+    }
+    P.win_budget = budget;
+    pl->n_lean_tiles = counts[0];
+    pl->n_direct_tiles = counts[1];
     return pb_build_launch_table(pl);
 }
 
@@ -755,6 +844,8 @@ static int pb_plan_prepare_full(pb_plan* pl, unsigned flags, int win_budget) {
     }
     int budget = win_budget > 0 ? win_budget : PB_DEFAULT_WIN_BUDGET;
     if (win_budget <= 0 && pb_knob("PB_WIN_BUDGET", 0) > 0) budget = pb_knob("PB_WIN_BUDGET", 0);
+    rc = pb_build_bilinear_launch(pl);
+    if (rc != PB_OK) return rc;
     rc = pb_apply_budget(pl, budget);
     if (rc != PB_OK) return rc;
     PB_HIP(hipDeviceSynchronize());
@@ -881,8 +972,11 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->saved_l);
     (void)hipFree(plan->saved_r);
     (void)hipFree(plan->ltable);
+    (void)hipFree(plan->ltable_bil);
     (void)hipFree(plan->P_dev);
     (void)hipFree(plan->bil_tiles);
+    (void)hipFree(plan->bil_xy);
+    (void)hipFree(plan->bil_fix_xy);
     delete plan;
 }
 
@@ -894,6 +988,7 @@ int pb_plan_dst_shape(const pb_plan* plan, int* height, int* width) {
 }
 int pb_plan_bilinear_float64_tiles(const pb_plan* plan) {
     if (!plan || !(plan->fast_ready || plan->dbl_ready)) return 0;
+    if (plan->bil_xy) return 0;  // every tile the models cannot serve has its exact coordinates in the plan's table
     return (int)(plan->n_fail_tiles + (plan->bil_tiles ? plan->n_bil_tiles : 0u));
 }
 int pb_plan_window_budget(const pb_plan* plan) {
@@ -992,9 +1087,11 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         return pb_fail(PB_ERR_INVALID, "src_frame_stride smaller than a frame");
     hipStream_t st = (hipStream_t)stream;
     if (P.src.kind == PB_KIND_DOUBLE) {
-        if (plan->dbl_ready && plan->ltable && plan->launch_groups > 0 && plan->bil_tiles && plan->mode != PB_MODE_FAITHFUL) {
-            // the per-eye tile models of the nearest mode's plan: one wave per tile, then the failed tiles / fix pixels in float64
-            const unsigned gpf = plan->launch_groups;
+        if (plan->dbl_ready && plan->ltable_bil && plan->launch_groups_bil > 0 && plan->bil_tiles && plan->mode != PB_MODE_FAITHFUL) {
+            // the per-eye tile models of the nearest mode's plan + the exact coordinate tables: one wave per tile, ONE launch
+            const unsigned gpf = plan->launch_groups_bil;
+            PbParams Pb = P;  // (the kernel takes the block by value: the bilinear mode's window budget travels in it)
+            Pb.win_budget = plan->bil_budget;
             const int windows = plan->mode != PB_MODE_FAST_DIRECT && ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
             const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
             const int per_launch = (int)(0x7FFFFFFFu / gpf);
@@ -1004,18 +1101,21 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
                 const uint8_t* sf = src_dev + (unsigned long long)f0 * src_frame_stride;
                 uint8_t* df = dst_dev + (unsigned long long)f0 * dst_frame_stride;
 #define PB_LAUNCH_BILINEAR_DOUBLE(WMODE)                                                                                                       \
-    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, pb_window_lds_bytes(P, 8), st, P, plan->table, plan->table_r, plan->ltable, rows, \
-                       plan->lat_tab, sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows)
+    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, pb_window_lds_bytes(Pb, 8), st, Pb, plan->table, plan->table_r, plan->ltable_bil, rows, \
+                       plan->lat_tab, sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy,  \
+                       plan->fix_px, plan->bil_fix_xy, plan->dbl_tile_fix, plan->dbl_px_fix)
                 if (rows) PB_LAUNCH_BILINEAR_DOUBLE(1);
                 else if (plan->n_lat_tiles) PB_LAUNCH_BILINEAR_DOUBLE(2);
                 else PB_LAUNCH_BILINEAR_DOUBLE(0);
 #undef PB_LAUNCH_BILINEAR_DOUBLE
             }
-            const unsigned n_tiles64 = plan->n_fail_tiles + plan->n_bil_tiles;
-            const unsigned fix_blocks = 4u * n_tiles64 + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
-            if (fix_blocks)
-                hipLaunchKernelGGL(pb_bilinear_double_fix_kernel, dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, plan->fail_tiles, (int)plan->n_fail_tiles, plan->bil_tiles,
-                                   (int)n_tiles64, plan->fix_px, (int)plan->n_fix_px, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
+            if (!plan->bil_xy) {  // no coordinate tables (they would not fit): the failed / listed tiles and the fix pixels from the float64 chain
+                const unsigned n_tiles64 = plan->n_fail_tiles + plan->n_bil_tiles;
+                const unsigned fix_blocks = 4u * n_tiles64 + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK;
+                if (fix_blocks)
+                    hipLaunchKernelGGL(pb_bilinear_double_fix_kernel, dim3(fix_blocks), dim3(PB_BLOCK), 0, st, P, plan->fail_tiles, (int)plan->n_fail_tiles, plan->bil_tiles,
+                                       (int)n_tiles64, plan->fix_px, (int)plan->n_fix_px, src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
+            }
         } else {
             hipLaunchKernelGGL(pb_bilinear_double_kernel, dim3(pb_blocks(npx)), dim3(PB_BLOCK), 0, st, P, src_dev, dst_dev, n_frames, src_frame_stride,
                                dst_frame_stride);
@@ -1023,10 +1123,12 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         PB_HIP(hipGetLastError());
         return PB_OK;
     }
-    if (pb_use_fast(plan) && plan->ltable && plan->launch_groups > 0 && plan->bil_tiles) {
-        // launched like the nearest hot kernel: the plan's launch-order table, frames of a batch as a grid dimension;
+    if (pb_use_fast(plan) && plan->ltable_bil && plan->launch_groups_bil > 0 && plan->bil_tiles) {
+        // launched like the nearest hot kernel: the mode's launch-order table, frames of a batch as a grid dimension, ONE launch;
         // LEAN tiles take their taps from LDS windows, except for frames LDS-DMA cannot address (not 16-byte aligned)
-        const unsigned gpf = plan->launch_groups;
+        const unsigned gpf = plan->launch_groups_bil;
+        PbParams Pb = P;
+        Pb.win_budget = plan->bil_budget;
         const dim3 block(64 * PB_TILE_WAVES);
         const int windows = plan->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
                             ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
@@ -1035,12 +1137,13 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
     do {                                                                                                                             \
         for (int f0 = 0; f0 < n_frames; f0 += per_launch) {                                                                          \
             const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;                                                  \
-            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, pb_window_lds_bytes(P), st, P, plan->ltable, \
+            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, pb_window_lds_bytes(Pb), st, pb_hot_of_host(Pb), plan->ltable_bil, \
                                src_dev + (unsigned long long)f0 * src_frame_stride, dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, \
-                               (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows);                 \
+                               (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy, plan->fix_px, \
+                               plan->bil_fix_xy);                                                                                    \
         }                                                                                                                            \
-        const unsigned n64 = plan->n_fail_tiles + (plan->bil_tiles ? plan->n_bil_tiles : 0u); /* failed + coarse tiles */          \
-        if (n64 || plan->n_fix_px)                                                                                                   \
+        const unsigned n64 = plan->n_fail_tiles + plan->n_bil_tiles; /* failed + listed tiles */                                    \
+        if (!plan->bil_xy && (n64 || plan->n_fix_px)) /* no coordinate tables (they would not fit): the float64 chain */             \
             hipLaunchKernelGGL(pb_bilinear_fix_kernel<KIND>, dim3(4u * n64 + (plan->n_fix_px + PB_BLOCK - 1) / PB_BLOCK),            \
                                dim3(PB_BLOCK), 0, st, P, plan->fail_tiles, 0, src_dev, dst_dev, n_frames, src_frame_stride,          \
                                dst_frame_stride, (int)n64, plan->fix_px, (int)plan->n_fix_px, plan->bil_tiles,                       \
@@ -1457,7 +1560,8 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
         pb_plan_destroy(pl);
         return PB_ERR_HIP;
     }
-    rc = pb_build_launch_table(pl);  // derived state: rebuilt, not stored
+    rc = pb_build_bilinear_launch(pl);  // derived state: rebuilt, not stored
+    if (rc == PB_OK) rc = pb_apply_budget(pl, pl->P.win_budget);
     if (rc != PB_OK) {
         pb_plan_destroy(pl);
         return rc;
