@@ -15,7 +15,7 @@ for case in full_cases():
         p = nat.Plan(d, r, s)
         torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
         tm = p.timing()
-        t1 = time.perf_counter(); blob = p.serialize(); t2 = time.perf_counter(); q = nat.Plan.deserialize(blob, d, s, len(r)); torch.cuda.synchronize(); t3 = time.perf_counter()
+        t1 = time.perf_counter(); blob = p.serialize(); t2 = time.perf_counter(); q = nat.Plan.deserialize(blob, d, r, s); torch.cuda.synchronize(); t3 = time.perf_counter()
         del p, q
     t0 = time.perf_counter(); p = nat.Plan(d, r, s, defer=True); t_def = (time.perf_counter() - t0) * 1e3
     print('%-7s create ms %s (library timer %.2f); deferred %.3f ms; serialize %.1f ms (%d KB), deserialize %.1f ms' % (case.name, ['%.2f' % t for t in ts], tm['prepare_ms'], t_def, (t2 - t1) * 1e3, len(blob) // 1024, (t3 - t2) * 1e3))

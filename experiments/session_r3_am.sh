@@ -3,6 +3,6 @@
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r3am; mkdir -p $O
 for shape in "4 0" "8 2" "16 1" "2 8" "4 0" "8 2"; do
   set -- $shape
-  PB_UNIT=$1 PB_UNIT_Y=$2 timeout -k 10 300 python experiments/ab_case.py photonbend_amd/libphotonbend_hip_diag.so c2 c2:8 c5 c3 c1 2>> $O/ab.err | cut -c24-112 | sed "s/^/UNIT=$1x$2 /" >> $O/ab.log
+  PB_UNIT=$1 PB_UNIT_Y=$2 timeout -k 10 300 python experiments/ab_case.py build/libphotonbend_hip_diag.so c2 c2:8 c5 c3 c1 2>> $O/ab.err | cut -c24-112 | sed "s/^/UNIT=$1x$2 /" >> $O/ab.log
 done
 cat $O/ab.log

@@ -12,5 +12,5 @@ for name in ['c2','c1','c3','c5_180']:
     _, h, w, *_ = case.src
     f = nat.synth_frame(h, w, frame=3, circle_mask=case.mask)
     a = plain.remap(f).clone(); b = tuned.remap(f)
-    blob = tuned.serialize(); twin = nat.Plan.deserialize(blob, d, s, len(rots)); c = twin.remap(f)
+    blob = tuned.serialize(); twin = nat.Plan.deserialize(blob, d, rots, s); c = twin.remap(f)
     print(name, 'tuned budget', tuned.info()['window_budget'], 'tune_ms %.1f'%tuned.timing()['tune_ms'], 'wall %.2fs'%dt, 'equal', bool(torch.equal(a,b)), bool(torch.equal(a,c)))

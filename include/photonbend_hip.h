@@ -203,7 +203,10 @@ int pb_index_map_i32(const pb_plan* plan, int32_t* idx_dev, double* weights_dev,
  *   pb_comm_unique_id   rank 0 makes the 128-byte rendezvous id (ncclGetUniqueId); the launcher hands it to the other ranks
  *   pb_comm_init        collective: every rank, on ITS current device (ncclCommInitRank)
  *   pb_bcast_params     collective: root's dst / rot3x3[9 * n_rot] / n_rot / src overwrite everyone else's (rot3x3 must hold
- *                       9 * PB_MAX_ROTATIONS doubles); synchronises `stream`
+ *                       9 * PB_MAX_ROTATIONS doubles); synchronises `stream`.  PRECONDITION: non-null pointers and a root inside
+ *                       [0, n_ranks) on EVERY rank - those are checked before anyone enters the collective and must not differ
+ *                       between ranks; everything only the root can know (its n_rot, its upload) travels WITH the broadcast: an
+ *                       invalid root request makes every rank return PB_ERR_INVALID together, none is left waiting
  *   pb_shard_range      first = rank * q + min(rank, r), count = q + (rank < r)  (q, r = divmod(n_items, n_ranks))
  *   pb_remap_batch_sharded  remaps THIS rank's share of a batch of n_frames_total frames: its count frames, resident in its own
  *                       buffers from src_dev / dst_dev on (frame k of the share = batch frame first + k); one pb_remap_u8 */

@@ -26,7 +26,35 @@ static uint64_t rnd() {
 static double uni() { return (double)(rnd() >> 11) * 0x1p-53; }
 static bool same(double a, double b) { return memcmp(&a, &b, 8) == 0 || (a != a && b != b); }
 
+// --eval <fn> <in> <out>: evaluates the header's functions on the doubles of a binary file (fn 0: sin, cos of each value, interleaved;
+// 1: atan2 of consecutive (y, x) pairs; 2: atan) - the host half of tests/test_hip_math.py, which compares the gfx950 build of the
+// same header with this one bit for bit.
+static int eval_file(int fn, const char* in, const char* out) {
+    FILE* f = fopen(in, "rb");
+    if (!f) return 2;
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f) / 8;
+    fseek(f, 0, SEEK_SET);
+    double* x = (double*)malloc(8 * (n > 0 ? n : 1));
+    if (fread(x, 8, n, f) != (size_t)n) return 2;
+    fclose(f);
+    FILE* g = fopen(out, "wb");
+    if (!g) return 2;
+    for (long i = 0; i < n; ++i) {
+        double r[2];
+        int k = 1;
+        if (fn == 0) { pb_sincos_cr(x[i], &r[0], &r[1]); k = 2; }
+        else if (fn == 1) { if (i & 1) continue; r[0] = (i + 1 < n) ? pb_atan2_cr(x[i], x[i + 1]) : 0.0; }
+        else r[0] = pb_atan_cr(x[i]);
+        fwrite(r, 8, k, g);
+    }
+    fclose(g);
+    free(x);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc == 5 && !strcmp(argv[1], "--eval")) return eval_file(atoi(argv[2]), argv[3], argv[4]);
     const long n = argc > 1 ? atol(argv[1]) : 2000000;
     const double pi = 3.141592653589793;
     long bad_g = 0, bad_q = 0, g_q = 0;

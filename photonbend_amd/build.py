@@ -64,7 +64,8 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, d
     return out
 
 
-DIAG_LIB_PATH = os.path.join(HERE, "libphotonbend_hip_diag.so")
+# NOT in the package directory: only the product library sits next to _native.py (build/ is git-ignored and travels to the GPU box)
+DIAG_LIB_PATH = os.path.join(os.path.dirname(HERE), "build", "libphotonbend_hip_diag.so")
 
 
 def build_diagnostic(force: bool = False, verbose: bool = False) -> str:
@@ -72,6 +73,7 @@ def build_diagnostic(force: bool = False, verbose: bool = False) -> str:
     the error-path test): it alone reads the experiment knobs and the allocation-failure hook from the environment."""
     if not force and os.path.exists(DIAG_LIB_PATH) and not _stale_against(DIAG_LIB_PATH):
         return DIAG_LIB_PATH
+    os.makedirs(os.path.dirname(DIAG_LIB_PATH), exist_ok=True)
     return build_library(force=True, verbose=verbose, out=DIAG_LIB_PATH, defines=("PB_ABLATION",))
 
 

@@ -320,17 +320,23 @@ class _GpuProjection:
                 raise NotImplementedError("bilinear sampling needs a lazy coordinate map (a recipe), not a materialised array")
             if not rgb8 or custom_src:
                 raise NotImplementedError("bilinear sampling takes uint8 (H, W, 3) images and built-in lenses")
-            if len(coordinate_map.rotations) > nat.PB_MAX_ROTATIONS:
-                # (such a chain leaves the fused plan for the materialised-map kernels, which sample nearest-by-truncation only)
-                raise NotImplementedError(f"bilinear sampling takes at most {nat.PB_MAX_ROTATIONS} chained rotations")
         on_device = isinstance(self.image, torch.Tensor)
         fused = rgb8 and not custom_src
         img = _device_image(self.image, h, w) if fused else _device_bytes(self.image)
         dev = img.device
-        too_many = lazy and len(coordinate_map.rotations) > nat.PB_MAX_ROTATIONS
+        rotations = coordinate_map.rotations if lazy else ()
+        if interpolation == "bilinear" and len(rotations) > nat.PB_MAX_ROTATIONS:
+            # The reference applies any number of -r rotations one after the other (scripts/commands/make_photo.py:128-131).  A chain
+            # longer than one fused plan takes leaves the plan for the materialised-map kernels, which only truncate; in THIS mode
+            # (our own definition, no reference bits to keep) the chain folds into one matrix product R_k ... R_1 instead.
+            folded = np.eye(3)
+            for r in rotations:
+                folded = np.asarray(r, dtype=np.float64).reshape(3, 3) @ folded
+            rotations = [folded]
+        too_many = lazy and len(rotations) > nat.PB_MAX_ROTATIONS
         if lazy and not too_many and not custom_src:
             # bilinear taps come from the tile models: that mode needs the prepared plan from the first use on
-            plan = _plan_for(coordinate_map.dst_proj, coordinate_map.rotations, src, device=dev, eager=interpolation != "nearest")
+            plan = _plan_for(coordinate_map.dst_proj, rotations, src, device=dev, eager=interpolation != "nearest")
             if fused:
                 out = plan.remap(img, interpolation=interpolation)
             else:

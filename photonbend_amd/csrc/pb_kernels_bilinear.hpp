@@ -27,6 +27,9 @@
 #pragma once
 #include "pb_kernels_tile.hpp"
 
+#ifndef PB_BIL_WPE  // waves per SIMD the bilinear tile kernels are compiled for (the register budget: 512 / PB_BIL_WPE VGPRs)
+#define PB_BIL_WPE 3
+#endif
 #ifndef PB_BIL_ABL  // timing experiments only (experiments/r4/): bits skip parts of the bilinear tile code (wrong pixels); 0 in the product
 #define PB_BIL_ABL 0
 #endif
@@ -526,7 +529,7 @@ __device__ __forceinline__ void pb_bil_store(const unsigned v[16], uint8_t* __re
 // coordinates by the tile's wave after its stores, like the nearest mode's.  bil_xy == nullptr: the plan has no coordinate table
 // (it would not fit); tiles that need one, and the fix pixels, are then left to pb_bilinear_fix_kernel.
 template <int SRC_KIND>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_hot_kernel(const PbHot Hd, const PbTileEntry* __restrict__ table,
+__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_hot_kernel(const PbHot Hd, const PbTileEntry* __restrict__ table,
                                                                               const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                               const unsigned groups_per_frame, unsigned long long src_stride,
                                                                               unsigned long long dst_stride, int windows,
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_kernel(const PbPa
 // table) blends with the faithful factors the nearest mode stores for its pixels (PbDoubleFix).  The fix pixels of either eye's
 // list are redone from their exact coordinates and stored factors after the wave's stores.
 template <int WMODE>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_double_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
+__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_double_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
                                                                                      const PbTileEntry* __restrict__ table_r,
                                                                                      const PbTileEntry* __restrict__ ltable,
                                                                                      const PbSepRow* __restrict__ rows,
@@ -725,6 +728,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_bilinear_double_hot_ker
     const int W = Hd.dst_w, H = Hd.dst_h, eye_w = P.src_eye_w;
     unsigned* win = pb_dyn_lds + (size_t)wave * ((Hd.win_budget >> 2) + 8);
     unsigned a[16];
+    if ((PB_BIL_ABL & 128) && (entry.flags & PB_TILE_SOLO)) return;   // skip one-eye tiles
+    if ((PB_BIL_ABL & 256) && !(entry.flags & PB_TILE_SOLO)) return;  // skip two-eye tiles
     if (entry.flags & PB_TILE_SOLO) {
         if (entry.bil_off >= 0 && !bil_xy) return;  // (no coordinate table: on the plan's float64 list)
         const bool right = (entry.flags & PB_TILE_EYE_R) != 0;

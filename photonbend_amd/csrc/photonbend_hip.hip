@@ -678,7 +678,10 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
 // The bilinear mode's launch-order table: the tiles classified under PB_BIL_WIN_BUDGET, ordered by the bilinear mode's costs.  Leaves
 // the tile tables' flags under THAT budget: pb_apply_budget (the nearest mode's) must follow.  A failure leaves the plan without the
 // table (the bilinear launches then take the float64 kernels), never with a stale one.  Synchronous.
-#define PB_BIL_WIN_BUDGET PB_WINLDS_MAX  // measured on MI355X (experiments/r4/budget_bil.sh): c1 28.7 us at 7 KiB, 25.2 at 12; c2 68.9 / 62.0; c5 109.8 / 103.4; c3 58.3 / 58.9
+#ifndef PB_BIL_WIN_BUDGET
+#define PB_BIL_WIN_BUDGET PB_WINLDS_MAX
+#endif
+//  // measured on MI355X (experiments/r4/budget_bil.sh): c1 28.7 us at 7 KiB, 25.2 at 12; c2 68.9 / 62.0; c5 109.8 / 103.4; c3 58.3 / 58.9
 static int pb_build_bilinear_launch(pb_plan* pl) {
     if (!(pl->fast_ready || pl->dbl_ready)) return PB_OK;
     (void)hipFree(pl->ltable_bil);
@@ -1181,6 +1184,25 @@ int pb_index_map_i32(const pb_plan* plan, int32_t* idx_dev, double* weights_dev,
     PB_HIP(hipGetLastError());
     return PB_OK;
 }
+
+#ifdef PB_ABLATION  // diagnostic build only (tests/test_hip_math.py): pb_math.hpp's correctly rounded functions as the gfx950 build evaluates them
+}  // extern "C"
+__global__ void pb_debug_math_kernel(int fn, const double* __restrict__ in, double* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (fn == 0) pb_sincos_cr(in[i], &out[2 * i], &out[2 * i + 1]);
+    else if (fn == 1) out[i] = pb_atan2_cr(in[2 * i], in[2 * i + 1]);
+    else out[i] = pb_atan_cr(in[i]);
+}
+extern "C" {
+// fn 0: n values -> (sin, cos) interleaved; 1: n (y, x) pairs -> atan2; 2: n values -> atan
+__attribute__((visibility("default"))) int pb_debug_math(int fn, const double* in_dev, double* out_dev, size_t n, void* stream) {
+    if (!in_dev || !out_dev || fn < 0 || fn > 2) return pb_fail(PB_ERR_INVALID, "bad argument");
+    if (n) hipLaunchKernelGGL(pb_debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, in_dev, out_dev, n);
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+#endif
 
 #ifdef PB_TRACE
 __attribute__((visibility("default"))) int pb_debug_trace(unsigned long long* out, size_t n_words, int reset) {
@@ -1718,20 +1740,29 @@ int pb_bcast_params(pb_comm* comm, pb_proj* dst, double* rot3x3, int* n_rot, pb_
     memset(block, 0, sizeof(block));
     auto put = [](double* b, const pb_proj& p) { b[0] = p.kind; b[1] = p.lens; b[2] = p.height; b[3] = p.width; b[4] = p.fov; b[5] = p.magnitude; b[6] = p.f_distance; };
     auto get = [](const double* b, pb_proj& p) { p.kind = (int32_t)b[0]; p.lens = (int32_t)b[1]; p.height = (int32_t)b[2]; p.width = (int32_t)b[3]; p.fov = b[4]; p.magnitude = b[5]; p.f_distance = b[6]; };
+    // A collective: once the arguments every rank can check alike have passed (above), EVERY rank reaches the broadcast - a root that
+    // finds its own request invalid, or cannot upload it, sends a block with a poisoned magic instead of returning early, and all ranks
+    // return PB_ERR_INVALID together (the other ranks used to block in ncclBroadcast forever).
     if (comm->rank == root) {
-        if (*n_rot < 0 || *n_rot > PB_MAX_ROTATIONS) return pb_fail(PB_ERR_INVALID, "n_rot outside [0, PB_MAX_ROTATIONS]");
-        block[0] = 1346522692.0;  // "PBND": the Python package's magic (photonbend_amd/parallel.py), same layout
-        block[1] = *n_rot;
-        put(block + 2, *dst);
-        put(block + 9, *src);
-        for (int k = 0; k < 9 * *n_rot; ++k) block[16 + k] = rot3x3[k];
-        PB_HIP(hipMemcpyAsync(comm->block_dev, block, sizeof(block), hipMemcpyHostToDevice, st));
+        const bool ok = *n_rot >= 0 && *n_rot <= PB_MAX_ROTATIONS;
+        block[0] = ok ? 1346522692.0 : -1.0;  // "PBND": the Python package's magic (photonbend_amd/parallel.py), same layout
+        if (ok) {
+            block[1] = *n_rot;
+            put(block + 2, *dst);
+            put(block + 9, *src);
+            for (int k = 0; k < 9 * *n_rot; ++k) block[16 + k] = rot3x3[k];
+        }
+        if (hipMemcpyAsync(comm->block_dev, block, sizeof(block), hipMemcpyHostToDevice, st) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipMemsetAsync(comm->block_dev, 0xFF, sizeof(block), st);  // (NaN magic: poisoned)
+        }
     }
     const int rc = r->bcast(comm->block_dev, comm->block_dev, PB_BLOCK_DOUBLES, 8 /* ncclFloat64 */, root, comm->comm, st);
     if (rc != 0) return pb_nccl_fail(r, "ncclBroadcast", rc);
     PB_HIP(hipMemcpyAsync(block, comm->block_dev, sizeof(block), hipMemcpyDeviceToHost, st));
     PB_HIP(hipStreamSynchronize(st));
-    if (block[0] != 1346522692.0 || !(block[1] >= 0 && block[1] <= PB_MAX_ROTATIONS)) return pb_fail(PB_ERR_INVALID, "corrupt parameter block");
+    if (block[0] != 1346522692.0 || !(block[1] >= 0 && block[1] <= PB_MAX_ROTATIONS))
+        return pb_fail(PB_ERR_INVALID, "the root's parameter block is invalid (n_rot outside [0, PB_MAX_ROTATIONS], a failed upload, or corrupt)");
     *n_rot = (int)block[1];
     get(block + 2, *dst);
     get(block + 9, *src);

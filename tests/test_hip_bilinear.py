@@ -94,20 +94,25 @@ def test_bilinear_api_and_noise_frame():
         grey.process_coordinate_map(cmap, interpolation="bilinear")
 
 
-def test_bilinear_rejects_chains_beyond_one_fused_plan():
-    """nine rotations leave the fused plan for the materialised-map kernels, which only truncate - bilinear used to come
-    back nearest-sampled without a word.  It raises now; the same chain in the nearest mode still works."""
+def test_bilinear_folds_chains_beyond_one_fused_plan():
+    """the reference applies every -r in turn (scripts/commands/make_photo.py:128-131).  Nine rotations leave the
+    fused plan; the nearest mode then goes through the materialised-map kernels, the bilinear mode (no reference bits to keep) folds
+    the chain into one matrix product and stays on the tile path: within 1 LSB of the definition applied rotation by rotation."""
     import photonbend_amd as pb
 
-    frame = synth_frame(64, 128, frame=3)
-    dst = pb.CameraImage(np.zeros((48, 48, 3), np.uint8), pb.utils.to_radians(180), pb.equidistant())
+    frame = smooth_frame(128, 256)
+    dst = pb.CameraImage(np.zeros((96, 96, 3), np.uint8), pb.utils.to_radians(180), pb.equidistant())
     cmap = dst.get_coordinate_map()
-    for k in range(9):
-        cmap = pb.Rotation(0.1 * k, -0.05 * k, 0.02).rotate_coordinate_map(cmap)
+    rots = [(0.1 * k, -0.05 * k, 0.02) for k in range(9)]
+    for r in rots:
+        cmap = pb.Rotation(*r).rotate_coordinate_map(cmap)
     src = pb.PanoramaImage(frame)
-    with pytest.raises(NotImplementedError, match="chained rotations"):
-        src.process_coordinate_map(cmap, interpolation="bilinear")
-    assert src.process_coordinate_map(cmap).shape == (48, 48, 3)
+    got = src.process_coordinate_map(cmap, interpolation="bilinear")
+    want = orc.remap_bilinear(orc.Proj("camera", 96, 96, "equidistant", orc.to_radians(180), None), orc.Proj("pano", 128, 256), frame, rots)
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16)).max(axis=2)
+    rim = _rim_of((want == 0).all(axis=2))
+    assert int((d[~rim] > 1).sum()) == 0, f"{int((d[~rim] > 1).sum())} pixels beyond 1 LSB (max {int(d[~rim].max())})"
+    assert src.process_coordinate_map(cmap).shape == (96, 96, 3)  # the nearest mode: every rotation in turn, as before
 
 
 def _rim_of(black):
