@@ -36,7 +36,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define PB_ABI_VERSION 3
+#define PB_ABI_VERSION 4
 #define PB_MAX_ROTATIONS 8
 
 typedef enum pb_status {
@@ -276,6 +276,23 @@ int pb_event_destroy(void* event);
 int pb_event_record(void* event, void* stream);
 int pb_event_sync(void* event);
 int pb_event_elapsed_ms(void* start, void* stop, float* ms);
+/* ABI 4: what a host that moves frames between ITS memory and the device needs beyond the above (the reference's contract is
+ * ndarray in, fresh ndarray out: core/__init__.py:66-92; the Python package's NumPy path is built on these, without PyTorch).
+ *   pb_device_count / pb_set_device / pb_get_device   the device ordinals pb_init takes
+ *   pb_device_sync          hipDeviceSynchronize
+ *   pb_stream_wait_event    work queued on `stream` after this call waits for `event` (cross-stream ordering: upload -> remap -> download)
+ *   pb_host_alloc / _free   page-locked host memory (hipHostMalloc): DMA reads / writes it without a staging copy
+ *   pb_host_register / _unregister   page-lock memory the CALLER allocated (hipHostRegister) for as long as it is registered; the
+ *                           caller must unregister before the memory is freed or unmapped */
+int pb_device_count(int* n);
+int pb_set_device(int device);
+int pb_get_device(int* device);
+int pb_device_sync(void);
+int pb_stream_wait_event(void* stream, void* event);
+int pb_host_alloc(void** host_ptr, size_t bytes);
+int pb_host_free(void* host_ptr);
+int pb_host_register(void* host_ptr, size_t bytes);
+int pb_host_unregister(void* host_ptr);
 /* measurement utility: a plain 16-byte-per-lane device copy (pointers and size multiples of 16) - the practical
  * HBM ceiling bench.py reports next to the remap kernel */
 int pb_stream_copy(void* dst_dev, const void* src_dev, size_t bytes, void* stream);

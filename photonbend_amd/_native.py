@@ -1,24 +1,33 @@
 """ctypes binding of include/photonbend_hip.h (the C ABI of the HIP library).
 
 There is no fallback: if ``libphotonbend_hip.so`` is missing or a call fails,
-this module raises.  PyTorch is imported FIRST on purpose - it ships its own
-``libamdhip64.so`` (SONAME libamdhip64.so.7); loading it before our library
-makes both share one HIP runtime, so torch device pointers and streams can be
-handed straight to the kernels.
+this module raises.
+
+PyTorch is OPTIONAL.  The reference needs numpy / Pillow / click (pyproject.toml:9-14) and so does this package: device memory,
+streams and page-locked host memory come from the library itself (``_device.py`` over pb_malloc / pb_memcpy_* / pb_stream_* /
+pb_host_*).  Where torch IS installed it is imported FIRST, on purpose - it ships its own ``libamdhip64.so`` (SONAME
+libamdhip64.so.7); loading it before our library makes both share one HIP runtime, so torch device pointers and streams can be
+handed straight to the kernels - and CUDA tensors are accepted wherever a device array is (frames that stay on the device).
 """
 
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import threading
 
 import numpy as np
-import torch  # noqa: F401  (must precede the CDLL below - see module docstring)
 
+try:  # must precede the CDLL below - see module docstring
+    import torch
+except ImportError:  # the NumPy workflow needs no torch
+    torch = None
+
+from ._device import DeviceArray
 from .build import LIB_PATH
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PB_MAX_ROTATIONS = 8
 PLAN_DEFER, PLAN_TUNE = 1, 2
 MODE_AUTO, MODE_FAITHFUL, MODE_FAST, MODE_FAST_DIRECT = 0, 1, 2, 3
@@ -108,6 +117,15 @@ SIGNATURES = {
     "pb_bcast_params": (C.c_int, [_VP, C.POINTER(pb_proj), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(pb_proj), C.c_int, _VP]),
     "pb_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_remap_batch_sharded": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), _VP]),
+    "pb_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pb_set_device": (C.c_int, [C.c_int]),
+    "pb_get_device": (C.c_int, [C.POINTER(C.c_int)]),
+    "pb_device_sync": (C.c_int, []),
+    "pb_stream_wait_event": (C.c_int, [_VP, _VP]),
+    "pb_host_alloc": (C.c_int, [C.POINTER(_VP), C.c_size_t]),
+    "pb_host_free": (C.c_int, [_VP]),
+    "pb_host_register": (C.c_int, [_VP, C.c_size_t]),
+    "pb_host_unregister": (C.c_int, [_VP]),
 }
 
 _lib = None
@@ -144,13 +162,102 @@ def check(status: int) -> None:
         raise PbError(f"photonbend_hip error {status}: {msg.decode() if msg else '?'}")
 
 
+def is_tensor(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def is_device_array(x) -> bool:
+    """A CUDA tensor or a DeviceArray: something the kernels can be pointed at."""
+    return isinstance(x, DeviceArray) or (is_tensor(x) and x.is_cuda)
+
+
 def current_stream() -> int:
-    return int(torch.cuda.current_stream().cuda_stream)
+    """The stream launches go to: torch's current stream where torch is installed (its tensors are ordered on it), the
+    default stream otherwise."""
+    return int(torch.cuda.current_stream().cuda_stream) if (torch is not None and torch.cuda.is_available()) else 0
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(load().pb_device_count(C.byref(n)))
+    return int(n.value)
+
+
+def current_device() -> int:
+    if torch is not None and torch.cuda.is_available():
+        return int(torch.cuda.current_device())
+    d = C.c_int(0)
+    check(load().pb_get_device(C.byref(d)))
+    return int(d.value)
+
+
+@contextlib.contextmanager
+def on_device(index):
+    """Runs the block with device `index` current (None: whatever is current)."""
+    if index is None:
+        yield
+    elif torch is not None and torch.cuda.is_available():
+        with torch.cuda.device(int(index)):
+            yield
+    else:
+        prev = current_device()
+        if prev != int(index):
+            check(load().pb_set_device(int(index)))
+        try:
+            yield
+        finally:
+            if prev != int(index):
+                check(load().pb_set_device(prev))
+
+
+def device_index_of(x):
+    """Device ordinal a device array lives on (DeviceArrays: the current device, where they were allocated)."""
+    if is_tensor(x):
+        return x.device.index if x.device.index is not None else current_device()
+    return None
+
+
+_gpu_ok = None
 
 
 def require_gpu() -> None:
-    if not torch.cuda.is_available():
+    global _gpu_ok
+    if _gpu_ok is None:
+        _gpu_ok = (torch.cuda.is_available() if torch is not None else False) or device_count() > 0
+    if not _gpu_ok:
         raise PbError("no HIP device is visible; photonbend_amd has no CPU path")
+
+
+def torch_dtype(dt):
+    return torch.from_numpy(np.empty(0, np.dtype(dt))).dtype
+
+
+def empty(shape, dtype, like=None, device=None):
+    """Uninitialised device array: a CUDA tensor where torch is installed (on `like`'s device / `device` / the current one),
+    else a DeviceArray.  `like` a DeviceArray forces a DeviceArray."""
+    if isinstance(like, DeviceArray) or torch is None:
+        return DeviceArray(shape, dtype)
+    dev = like.device if is_tensor(like) else (device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    return torch.empty(tuple(shape), dtype=torch_dtype(dtype), device=dev)
+
+
+def to_host(x) -> np.ndarray:
+    """Device array -> fresh ndarray (synchronous)."""
+    return x.cpu().numpy() if is_tensor(x) else x.numpy()
+
+
+def to_device(a: np.ndarray, device=None):
+    """ndarray -> device array of the default kind (CUDA tensor with torch, DeviceArray without); synchronous."""
+    a = np.ascontiguousarray(a)
+    if torch is None:
+        return DeviceArray(a.shape, a.dtype).copy_from_host(a)
+    if not a.flags.writeable:
+        a = a.copy()  # (torch refuses read-only arrays)
+    return torch.from_numpy(a).to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+
+
+def _on(x):
+    return on_device(device_index_of(x))
 
 
 class Plan:
@@ -248,42 +355,54 @@ class Plan:
         if h and _lib is not None:
             _lib.pb_plan_destroy(h)
 
-    # -- launches (torch tensors in, torch tensors out; all on the current stream)
-    def remap(self, src: torch.Tensor, out: torch.Tensor | None = None, interpolation: str = "nearest") -> torch.Tensor:
-        """src: uint8 cuda tensor (h, w, 3) or (N, h, w, 3) -> (H, W, 3) / (N, H, W, 3).
+    # -- launches (device arrays in, device arrays out: CUDA tensors or DeviceArrays; on the current stream unless told otherwise)
+    def launch(self, src_ptr: int, dst_ptr: int, n_frames: int = 1, stream: int | None = None, interpolation: str = "nearest",
+               src_stride: int = 0, dst_stride: int = 0) -> None:
+        """The raw call: n_frames frames at src_ptr / dst_ptr (device addresses, strides in bytes, 0 = packed) on `stream`."""
+        fn = load().pb_remap_u8 if interpolation == "nearest" else load().pb_remap_bilinear_u8
+        check(fn(self._h, src_ptr, dst_ptr, int(n_frames), int(src_stride), int(dst_stride), current_stream() if stream is None else stream))
+
+    def remap(self, src, out=None, interpolation: str = "nearest"):
+        """src: uint8 device array (h, w, 3) or (N, h, w, 3) -> (H, W, 3) / (N, H, W, 3), of src's kind.
         interpolation: "nearest" (the reference's truncating sample) or the opt-in "bilinear"."""
         if interpolation not in ("nearest", "bilinear"):
             raise ValueError("interpolation must be 'nearest' or 'bilinear'")
         require_gpu()
-        batched = src.dim() == 4
-        s = src if batched else src.unsqueeze(0)
-        if s.dtype != torch.uint8 or not s.is_cuda or tuple(s.shape[1:]) != (self.src.height, self.src.width, 3):
-            raise PbError(f"source frames must be uint8 cuda (N, {self.src.height}, {self.src.width}, 3), got {tuple(src.shape)} {src.dtype}")
-        s = s.contiguous()
-        n = s.shape[0]
+        if not is_device_array(src):
+            raise PbError(f"source frames must be uint8 device arrays (CUDA tensors or DeviceArrays), got {type(src).__name__}")
+        tens = is_tensor(src)
+        batched = len(src.shape) == 4
+        shp = tuple(src.shape)
+        n = shp[0] if batched else 1
+        u8 = (src.dtype == torch.uint8) if tens else (src.dtype == np.uint8)
+        if not u8 or shp[-3:] != (self.src.height, self.src.width, 3) or len(shp) not in (3, 4):
+            raise PbError(f"source frames must be uint8 cuda (N, {self.src.height}, {self.src.width}, 3), got {shp} {src.dtype}")
+        s = src.contiguous() if tens else src
+        oshape = (n, self.dst.height, self.dst.width, 3)
         if out is None:
-            out = torch.empty((n, self.dst.height, self.dst.width, 3), dtype=torch.uint8, device=s.device)
-            o = out
+            o = empty(oshape, np.uint8, like=s)
         else:
-            o = out if out.dim() == 4 else out.unsqueeze(0)
-            if o.dtype != torch.uint8 or not o.is_contiguous() or tuple(o.shape) != (n, self.dst.height, self.dst.width, 3):
+            o = out
+            if tuple(o.shape) not in (oshape, oshape[1:] if not batched else oshape):
                 raise PbError("out must be a contiguous uint8 cuda tensor of the destination shape")
-            if not o.is_cuda or o.device != s.device:
+            if is_tensor(o) != tens or (tens and (o.dtype != torch.uint8 or not o.is_contiguous())) or (not tens and o.dtype != np.uint8):
+                raise PbError("out must be a contiguous uint8 cuda tensor of the destination shape")
+            if tens and (not o.is_cuda or o.device != s.device):
                 raise PbError(f"out must live on the source's device ({s.device}), got {o.device}")
-        fn = load().pb_remap_u8 if interpolation == "nearest" else load().pb_remap_bilinear_u8
-        with torch.cuda.device(s.device):
-            check(fn(self._h, s.data_ptr(), o.data_ptr(), n, 0, 0, current_stream()))
+        with _on(s):
+            self.launch(s.data_ptr(), o.data_ptr(), n, None, interpolation)
+        if out is not None:
+            return out
         return o if batched else o[0]
 
     def index_map(self, weights: bool = False, device=None):
         """int32 (H, W) index map, or for a double source (2, H, W) [+ float64 (2, H, W) weights]."""
         require_gpu()
-        device = device or torch.device("cuda", torch.cuda.current_device())
         H, W = self.dst.height, self.dst.width
         shape = (2, H, W) if self.double_src else (H, W)
-        idx = torch.empty(shape, dtype=torch.int32, device=device)
-        w = torch.empty((2, H, W), dtype=torch.float64, device=device) if (weights and self.double_src) else None
-        with torch.cuda.device(device):
+        idx = empty(shape, np.int32, device=device)
+        w = empty((2, H, W), np.float64, like=idx) if (weights and self.double_src) else None
+        with _on(idx):
             check(load().pb_index_map_i32(self._h, idx.data_ptr(), w.data_ptr() if w is not None else None, current_stream()))
         return (idx, w) if weights else idx
 
@@ -292,88 +411,93 @@ def make_proj(kind: int, height: int, width: int, lens: int = 0, fov: float = 0.
     return pb_proj(int(kind), int(lens), int(height), int(width), float(fov), float(magnitude), float(f_distance))
 
 
-def coordmap(dst: pb_proj, device=None) -> torch.Tensor:
+def coordmap(dst: pb_proj, device=None):
     require_gpu()
-    device = device or torch.device("cuda", torch.cuda.current_device())
-    out = torch.empty((dst.height, dst.width, 3), dtype=torch.float64, device=device)
-    with torch.cuda.device(device):
+    out = empty((dst.height, dst.width, 3), np.float64, device=device)
+    with _on(out):
         check(load().pb_coordmap_f64(C.byref(dst), out.data_ptr(), current_stream()))
     return out
 
 
-def rotate(matrix: np.ndarray, cmap: torch.Tensor) -> torch.Tensor:
-    """cmap (H, W, 3) float64 cuda, contiguous; invalid lat/lon are zeroed in it."""
+def rotate(matrix: np.ndarray, cmap):
+    """cmap (H, W, 3) float64 device array, contiguous; invalid lat/lon are zeroed in it."""
     require_gpu()
     m = np.ascontiguousarray(matrix, dtype=np.float64).reshape(9)
-    out = torch.empty_like(cmap)
-    with torch.cuda.device(cmap.device):
+    out = empty(tuple(cmap.shape), np.float64, like=cmap)
+    with _on(cmap):
         check(load().pb_rotate_f64(m.ctypes.data_as(C.POINTER(C.c_double)), cmap.data_ptr(), out.data_ptr(), cmap.shape[0], cmap.shape[1], current_stream()))
     return out
 
 
-def sample_map(src: pb_proj, cmap: torch.Tensor, image: torch.Tensor) -> torch.Tensor:
+def sample_map(src: pb_proj, cmap, image):
     require_gpu()
-    out = torch.empty((cmap.shape[0], cmap.shape[1], 3), dtype=torch.uint8, device=cmap.device)
-    with torch.cuda.device(cmap.device):
+    out = empty((cmap.shape[0], cmap.shape[1], 3), np.uint8, like=cmap)
+    with _on(cmap):
         check(load().pb_sample_map_u8(C.byref(src), cmap.data_ptr(), cmap.shape[0], cmap.shape[1], image.data_ptr(), out.data_ptr(), current_stream()))
     return out
 
 
-def index_from_map(src: pb_proj, cmap: torch.Tensor, dist_l: torch.Tensor | None = None, dist_r: torch.Tensor | None = None):
-    """cmap (H, W, 3) float64 cuda -> (int32 indices (H, W) or (2, H, W) for a double source, float64 weights (2, H, W) or None).
+def index_from_map(src: pb_proj, cmap, dist_l=None, dist_r=None):
+    """cmap (H, W, 3) float64 device array -> (int32 indices (H, W) or (2, H, W) for a double source, float64 weights (2, H, W) or None).
     Zeroes invalid lat/lon in cmap for a panorama source, like the reference."""
     require_gpu()
     H, W = cmap.shape[0], cmap.shape[1]
     double = src.kind == KIND_DOUBLE
-    idx = torch.empty((2, H, W) if double else (H, W), dtype=torch.int32, device=cmap.device)
-    w = torch.empty((2, H, W), dtype=torch.float64, device=cmap.device) if double else None
+    idx = empty((2, H, W) if double else (H, W), np.int32, like=cmap)
+    w = empty((2, H, W), np.float64, like=cmap) if double else None
     for d in (dist_l, dist_r):
-        if d is not None and not (d.is_cuda and d.dtype == torch.float64 and d.is_contiguous() and d.numel() == H * W and d.device == cmap.device):
+        if d is None:
+            continue
+        if is_tensor(d):
+            ok = d.is_cuda and d.dtype == torch.float64 and d.is_contiguous() and d.numel() == H * W and (not is_tensor(cmap) or d.device == cmap.device)
+        else:
+            ok = isinstance(d, DeviceArray) and d.dtype == np.float64 and d.size == H * W
+        if not ok:
             raise PbError("distance planes must be contiguous float64 CUDA tensors of the map's size on the map's device")
-    with torch.cuda.device(cmap.device):
+    with _on(cmap):
         check(load().pb_index_from_map_i32(C.byref(src), cmap.data_ptr(), H, W, dist_l.data_ptr() if dist_l is not None else None,
                                            dist_r.data_ptr() if dist_r is not None else None, idx.data_ptr(), w.data_ptr() if w is not None else None, current_stream()))
     return idx, w
 
 
-def gather_px(idx: torch.Tensor, img_bytes: torch.Tensor) -> torch.Tensor:
+def gather_px(idx, img_bytes):
     """idx int32 (H, W), img_bytes uint8 (h, w, bpp) -> uint8 (H, W, bpp): src[idx] or zeros where idx < 0."""
     require_gpu()
     bpp = img_bytes.shape[2]
-    out = torch.empty((idx.shape[0], idx.shape[1], bpp), dtype=torch.uint8, device=idx.device)
-    with torch.cuda.device(idx.device):
-        check(load().pb_gather_px(idx.data_ptr(), img_bytes.data_ptr(), out.data_ptr(), idx.numel(), bpp, current_stream()))
+    n = int(idx.shape[0]) * int(idx.shape[1])
+    out = empty((idx.shape[0], idx.shape[1], bpp), np.uint8, like=idx)
+    with _on(idx):
+        check(load().pb_gather_px(idx.data_ptr(), img_bytes.data_ptr(), out.data_ptr(), n, bpp, current_stream()))
     return out
 
 
-def gather_blend(idx2: torch.Tensor, w2: torch.Tensor, img_bytes: torch.Tensor, channels: int, sample_bytes: int) -> torch.Tensor:
+def gather_blend(idx2, w2, img_bytes, channels: int, sample_bytes: int):
     """The double-fisheye blend of arbitrary-width images: uint8 (H * W * channels)."""
     require_gpu()
-    n = idx2.shape[1] * idx2.shape[2]
-    out = torch.empty(n * channels, dtype=torch.uint8, device=idx2.device)
-    with torch.cuda.device(idx2.device):
+    n = int(idx2.shape[1]) * int(idx2.shape[2])
+    out = empty((n * channels,), np.uint8, like=idx2)
+    with _on(idx2):
         check(load().pb_gather_blend_u8(idx2.data_ptr(), w2.data_ptr(), img_bytes.data_ptr(), out.data_ptr(), n, channels, sample_bytes, current_stream()))
     return out
 
 
-def map_projection(cmap: torch.Tensor) -> torch.Tensor:
-    """cmap (H, W, 3) float64 cuda, contiguous -> uint8 (H, W, 3); invalid lat/lon are zeroed in cmap."""
+def map_projection(cmap):
+    """cmap (H, W, 3) float64 device array, contiguous -> uint8 (H, W, 3); invalid lat/lon are zeroed in cmap."""
     require_gpu()
-    out = torch.empty((cmap.shape[0], cmap.shape[1], 3), dtype=torch.uint8, device=cmap.device)
-    ws = torch.empty(3, dtype=torch.int64, device=cmap.device)
-    with torch.cuda.device(cmap.device):
+    out = empty((cmap.shape[0], cmap.shape[1], 3), np.uint8, like=cmap)
+    ws = empty((3,), np.int64, like=cmap)
+    with _on(cmap):
         check(load().pb_map_projection_u8(cmap.data_ptr(), cmap.shape[0], cmap.shape[1], out.data_ptr(), ws.data_ptr(), current_stream()))
-    if int(ws[2].item()) == 0:
+    if int(to_host(ws)[2]) == 0:
         raise ValueError("zero-size array to reduction operation minimum which has no identity")  # np.min of no valid pixel
     return out
 
 
-def synth_frame(height: int, width: int, frame: int = 0, seed: int = 0, circle_mask: int = 0, device=None, out: torch.Tensor | None = None) -> torch.Tensor:
+def synth_frame(height: int, width: int, frame: int = 0, seed: int = 0, circle_mask: int = 0, device=None, out=None):
     require_gpu()
     if out is None:
-        device = device or torch.device("cuda", torch.cuda.current_device())
-        out = torch.empty((height, width, 3), dtype=torch.uint8, device=device)
-    with torch.cuda.device(out.device):
+        out = empty((height, width, 3), np.uint8, device=device)
+    with _on(out):
         check(load().pb_synth_frame_u8(out.data_ptr(), height, width, frame & 0xFFFFFFFF, seed & 0xFFFFFFFF, circle_mask, current_stream()))
     return out
 

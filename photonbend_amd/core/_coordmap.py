@@ -76,17 +76,19 @@ class CoordinateMap:
         return self._dst.height
 
     def device_tensor(self):
-        """The map as a float64 CUDA tensor (H, W, 3), computed on the GPU."""
+        """The map as a float64 device array (H, W, 3), computed on the GPU."""
         t = nat.coordmap(self._dst, self._device)
         for R in self._rotations:
             t = nat.rotate(R, t)
         if self._zero_invalid:
-            t[..., :2][t[..., 2] != 0.0] = 0.0
+            # lat / lon of invalid pixels become 0 IN PLACE - exactly the side effect pb_rotate_f64 has on its input map
+            # (rotation.py:119-125); its output is dropped
+            nat.rotate(np.eye(3), t)
         return t
 
     def materialize(self) -> np.ndarray:
         if self._array is None:
-            self._array = self.device_tensor().cpu().numpy()
+            self._array = nat.to_host(self.device_tensor())
         return self._array
 
     def __array__(self, dtype=None, copy=None):

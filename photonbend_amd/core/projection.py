@@ -11,8 +11,9 @@ that was looked at or edited, or a hand-made map) is sampled by the
 materialised-map kernel (pb_sample_map_u8).  There is no NumPy path.
 
 ``image`` may be a NumPy uint8 array (H, W, 3) - uploaded per call, result
-returned as a fresh ndarray like the reference - or a uint8 CUDA tensor, which
-stays on the device and yields a CUDA tensor.
+returned as a fresh ndarray like the reference (``_hostpipe.py``: no PyTorch
+involved) - or, where PyTorch is installed, a uint8 CUDA tensor, which stays on
+the device and yields a CUDA tensor.
 """
 
 from __future__ import annotations
@@ -26,10 +27,8 @@ from collections import OrderedDict
 from typing import Protocol, Union
 
 import numpy as np
-import torch
 
-from ..utils.hostcopy import par_copy, row_chunks
-
+from .. import _hostpipe
 from .. import _native as nat
 from ._coordmap import CoordinateMap
 from .lens import Lens, lens_id
@@ -88,13 +87,19 @@ def _plan_for(dst: nat.pb_proj, rotations, src: nat.pb_proj, device=None, eager:
     rotations = list(rotations)
     if len(rotations) > nat.PB_MAX_ROTATIONS:
         raise nat.PbError(f"at most {nat.PB_MAX_ROTATIONS} rotations fit one fused plan")
-    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
-    dev_index = dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    have_gpu = _have_gpu()
+    if device is None:
+        dev_index = nat.current_device() if have_gpu else 0
+    elif isinstance(device, int):
+        dev_index = device
+    else:  # a torch.device (or its string form)
+        idx = getattr(device, "index", None)
+        dev_index = idx if idx is not None else (nat.current_device() if have_gpu else 0)
     eager = eager or os.environ.get("PB_PLAN_EAGER") == "1"
     key = _plan_key(dst, rotations, src, dev_index)
     with _PLAN_LOCK:
         entry = _PLAN_CACHE.get(key)
-        ctx = torch.cuda.device(dev_index) if torch.cuda.is_available() else contextlib.nullcontext()
+        ctx = nat.on_device(dev_index) if have_gpu else contextlib.nullcontext()
         with ctx:
             if entry is None:
                 plan = nat.Plan(dst, rotations, src, defer=True)
@@ -102,11 +107,19 @@ def _plan_for(dst: nat.pb_proj, rotations, src: nat.pb_proj, device=None, eager:
                 while len(_PLAN_CACHE) > _PLAN_CACHE_MAX:
                     _PLAN_CACHE.popitem(last=False)  # evict ONE entry, the least recently used
             entry[1] += 1
-            if not entry[2] and (eager or entry[1] >= 2) and torch.cuda.is_available():
+            if not entry[2] and (eager or entry[1] >= 2) and have_gpu:
                 entry[0] = _prepare(entry[0], key, rotations)
                 entry[2] = True
         _PLAN_CACHE.move_to_end(key)
         return entry[0]
+
+
+def _have_gpu() -> bool:
+    try:
+        nat.require_gpu()
+        return True
+    except nat.PbError:
+        return False
 
 
 def _shape_hw(image) -> tuple:
@@ -116,99 +129,71 @@ def _shape_hw(image) -> tuple:
     return int(shp[0]), int(shp[1])
 
 
-# page-locked staging buffers: per THREAD (two threads remapping at once never share one) and guarded by the event
-# of the last asynchronous copy that used them (a transfer still in flight on any stream is waited for before reuse)
-_TLS = threading.local()
-_PINNED_MAX = 4
+def _to_host(t) -> np.ndarray:
+    """Device array -> fresh ndarray (the reference returns freshly allocated arrays)."""
+    if nat.is_tensor(t):
+        pipe = _hostpipe.pipe_for(nat.device_index_of(t))
+        out = _hostpipe.PINNED.ndarray(tuple(t.shape), nat.to_host(t[:0]).dtype) if t.numel() >= (1 << 20) else None
+        if out is None:
+            return t.cpu().numpy()
+        t = t.contiguous()
+        with nat.on_device(pipe.device):
+            nat.torch.cuda.current_stream().synchronize()  # the tensor's producer runs on torch's stream
+            nat.check(nat.load().pb_memcpy_d2h(out.ctypes.data, t.data_ptr(), out.nbytes, pipe.stream.handle))
+            pipe.stream.sync()
+        return out
+    return t.numpy()
 
 
-def _pinned(shape, dtype, slot: str):
-    """-> [buffer, event of its last async use or None]"""
-    cache = getattr(_TLS, "pinned", None)
-    if cache is None:
-        cache = _TLS.pinned = OrderedDict()
-    key = (tuple(shape), dtype, slot)
-    entry = cache.get(key)
-    if entry is None:
-        while len(cache) >= _PINNED_MAX:
-            cache.popitem(last=False)
-        entry = cache[key] = [torch.empty(tuple(shape), dtype=dtype).pin_memory(), None]
-    cache.move_to_end(key)
-    if entry[1] is not None:
-        entry[1].synchronize()
-        entry[1] = None
-    return entry
+def _upload(a: np.ndarray, device=None):
+    """ndarray -> device array on `device` (default: current); synchronous."""
+    with nat.on_device(getattr(device, "index", device) if device is not None else None):
+        return nat.to_device(a, device if nat.torch is not None else None)
 
 
-def _to_host(t: torch.Tensor) -> np.ndarray:
-    """Device tensor -> fresh ndarray (the reference returns freshly allocated arrays) via pinned staging,
-    in row chunks: a chunk is copied out of the staging buffer (a few threads) while the next crosses PCIe."""
-    entry = _pinned(t.shape, t.dtype, "d2h")
-    stage = entry[0]
-    chunks = row_chunks(t.shape[0], t.numel() * t.element_size()) if t.dim() >= 2 else [(0, t.shape[0])]
-    events = []
-    with torch.cuda.device(t.device):
-        for a, b in chunks:
-            stage[a:b].copy_(t[a:b], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            events.append(ev)
-    out = np.empty(tuple(t.shape), stage.numpy().dtype)
-    sn = stage.numpy()
-    for (a, b), ev in zip(chunks, events):
-        ev.synchronize()
-        par_copy(out[a:b], sn[a:b])
-    return out
-
-
-def _upload(a: np.ndarray, device=None) -> torch.Tensor:
-    """ndarray -> CUDA tensor on `device` (default: current) via pinned staging, in row chunks (the host copy of
-    chunk k overlaps the PCIe transfer of chunk k - 1)."""
-    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-    tdtype = torch.from_numpy(np.empty(0, a.dtype)).dtype
-    entry = _pinned(a.shape, tdtype, "h2d")
-    stage = entry[0]
-    with torch.cuda.device(dev):
-        out = torch.empty(tuple(a.shape), dtype=tdtype, device=dev)
-        sn = stage.numpy()
-        for lo, hi in row_chunks(a.shape[0], a.nbytes):
-            par_copy(sn[lo:hi], a[lo:hi])
-            out[lo:hi].copy_(stage[lo:hi], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        entry[1] = ev
-    return out
-
-
-def _device_image(image, height: int, width: int) -> torch.Tensor:
-    """uint8 CUDA tensor (h, w, 3) of the pixels behind ``.image`` (a tensor stays on ITS device)."""
+def _device_image(image, height: int, width: int):
+    """uint8 device array (h, w, 3) of the pixels behind ``.image`` (a tensor stays on ITS device)."""
     nat.require_gpu()
-    if isinstance(image, torch.Tensor):
+    if nat.is_tensor(image):
         t = image
-        if t.dtype != torch.uint8:
+        if t.dtype != nat.torch.uint8:
             raise TypeError("image tensors must be uint8")
         if not t.is_cuda:
             t = t.cuda()
-    else:
-        a = np.asarray(image)
-        if a.dtype != np.uint8:
-            raise TypeError(f"images are uint8 (H, W, 3) RGB arrays (core/__init__.py:31-36), got {a.dtype}")
-        if tuple(a.shape) != (height, width, 3):
-            raise ValueError(f"image must have shape ({height}, {width}, 3), got {tuple(a.shape)}")
-        t = _upload(a)
-    if tuple(t.shape) != (height, width, 3):
-        raise ValueError(f"image must have shape ({height}, {width}, 3), got {tuple(t.shape)}")
-    return t.contiguous()
+        if tuple(t.shape) != (height, width, 3):
+            raise ValueError(f"image must have shape ({height}, {width}, 3), got {tuple(t.shape)}")
+        return t.contiguous()
+    if isinstance(image, nat.DeviceArray):
+        if image.dtype != np.uint8 or tuple(image.shape) != (height, width, 3):
+            raise ValueError(f"image must be uint8 ({height}, {width}, 3), got {image.dtype} {tuple(image.shape)}")
+        return image
+    a = _checked_rgb8(image, height, width)
+    return _upload(a)
 
 
-def _check_map_tensor(cmap: torch.Tensor, device=None) -> None:
+def _checked_rgb8(image, height: int, width: int) -> np.ndarray:
+    a = np.asarray(image)
+    if a.dtype != np.uint8:
+        raise TypeError(f"images are uint8 (H, W, 3) RGB arrays (core/__init__.py:31-36), got {a.dtype}")
+    if tuple(a.shape) != (height, width, 3):
+        raise ValueError(f"image must have shape ({height}, {width}, 3), got {tuple(a.shape)}")
+    return a
+
+
+def _check_map_tensor(cmap, device=None) -> None:
     """A tensor coordinate map must be what the kernels index: contiguous float64 (H, W, 3) on the image's device."""
-    if not (cmap.is_cuda and cmap.dtype == torch.float64 and cmap.is_contiguous()):
-        raise TypeError("tensor coordinate maps must be contiguous float64 CUDA tensors")
-    if cmap.dim() != 3 or cmap.shape[2] != 3:
-        raise ValueError(f"a coordinate map has shape (H, W, 3), got {tuple(cmap.shape)}")
-    if device is not None and cmap.device != device:
-        raise ValueError(f"coordinate map on {cmap.device} but the image on {device}")
+    if nat.is_tensor(cmap):
+        if not (cmap.is_cuda and cmap.dtype == nat.torch.float64 and cmap.is_contiguous()):
+            raise TypeError("tensor coordinate maps must be contiguous float64 CUDA tensors")
+        shp = tuple(cmap.shape)
+        if device is not None and cmap.device != device:
+            raise ValueError(f"coordinate map on {cmap.device} but the image on {device}")
+    else:
+        if cmap.dtype != np.float64:
+            raise TypeError("device coordinate maps must be float64")
+        shp = tuple(cmap.shape)
+    if len(shp) != 3 or shp[2] != 3:
+        raise ValueError(f"a coordinate map has shape (H, W, 3), got {shp}")
 
 
 class ProjectionImage(Protocol):
@@ -231,29 +216,40 @@ def _image_info(image):
     shp = tuple(int(v) for v in image.shape)
     if len(shp) < 2:
         raise ValueError("an image needs at least (height, width)")
-    if isinstance(image, torch.Tensor):
-        dt = torch.empty(0, dtype=image.dtype).numpy().dtype
+    if nat.is_tensor(image):
+        dt = nat.torch.empty(0, dtype=image.dtype).numpy().dtype
+    elif isinstance(image, nat.DeviceArray):
+        dt = image.dtype
     else:
         dt = np.asarray(image).dtype
     return shp[0], shp[1], shp[2:], np.dtype(dt)
 
 
-def _device_bytes(image, device=None) -> torch.Tensor:
-    """The image's pixels as a contiguous uint8 CUDA tensor (h, w, bytes per pixel)."""
+def _device_bytes(image, device=None):
+    """The image's pixels as a contiguous uint8 device array (h, w, bytes per pixel)."""
     nat.require_gpu()
     h, w, tail, dt = _image_info(image)
     bpp = int(np.prod(tail, dtype=np.int64)) * dt.itemsize
-    if isinstance(image, torch.Tensor):
+    if nat.is_tensor(image):
         t = image if image.is_cuda else image.cuda()
-        return t.contiguous().view(torch.uint8).reshape(h, w, bpp)
+        return t.contiguous().view(nat.torch.uint8).reshape(h, w, bpp)
+    if isinstance(image, nat.DeviceArray):
+        return image.view(np.uint8, (h, w, bpp))
     a = np.ascontiguousarray(image)
     return _upload(a.view(np.uint8).reshape(h, w, bpp), device)
+
+
+def _typed(out, tail, dt: np.dtype, H: int, W: int):
+    """uint8 device bytes (H, W, bpp) as the image's sample type and trailing shape."""
+    if nat.is_tensor(out):
+        return out.view(nat.torch_dtype(dt)).reshape((H, W) + tuple(tail))
+    return out.view(dt, (H, W) + tuple(tail))
 
 
 class _GpuProjection:
     """Shared GPU plumbing of the three projection classes."""
 
-    image: Union[np.ndarray, torch.Tensor]
+    image: np.ndarray  # (or a uint8 CUDA tensor / DeviceArray: the pixels then stay on the device)
 
     def _proj(self, role: str = "src") -> nat.pb_proj:  # pragma: no cover - overridden
         raise NotImplementedError
@@ -271,19 +267,20 @@ class _GpuProjection:
     def _source_distances(self, lat: np.ndarray):  # pragma: no cover - overridden by the camera classes
         raise NotImplementedError
 
-    def _index_from_map(self, src: nat.pb_proj, dev_map: torch.Tensor):
+    def _index_from_map(self, src: nat.pb_proj, dev_map):
         """int32 source indices (and float64 weights for a double source) of a materialised map on the device."""
         dl = dr = None
         if src.kind != nat.KIND_PANO and src.lens == nat.LENS_CUSTOM:
             # forward_function is host Python by definition: latitude plane down, distances up (projection.py:251)
-            lat = dev_map[..., 0].contiguous().cpu().numpy()
+            lat = np.ascontiguousarray(nat.to_host(dev_map)[..., 0])
             planes = self._source_distances(lat)
-            dl = torch.from_numpy(np.ascontiguousarray(planes[0], dtype=np.float64)).to(dev_map.device)
+            dev = dev_map.device if nat.is_tensor(dev_map) else None
+            dl = _upload(np.ascontiguousarray(planes[0], dtype=np.float64), dev)
             if src.kind == nat.KIND_DOUBLE:
-                dr = torch.from_numpy(np.ascontiguousarray(planes[1], dtype=np.float64)).to(dev_map.device)
+                dr = _upload(np.ascontiguousarray(planes[1], dtype=np.float64), dev)
         return nat.index_from_map(src, dev_map, dl, dr)
 
-    def _gather(self, src: nat.pb_proj, idx: torch.Tensor, weights, img_bytes: torch.Tensor, tail, dt: np.dtype):
+    def _gather(self, src: nat.pb_proj, idx, weights, img_bytes, tail, dt: np.dtype):
         """index map -> output pixels, any channel count / sample width; returns a CUDA tensor of the output dtype."""
         H, W = (idx.shape[-2], idx.shape[-1])
         if src.kind == nat.KIND_DOUBLE:
@@ -294,9 +291,7 @@ class _GpuProjection:
                 raise NotImplementedError(f"the double-fisheye blend takes uint8 or uint16 images, got {dt}")
             out = nat.gather_blend(idx, weights, img_bytes, tail[0], dt.itemsize)  # uint8, like .astype(np.uint8)
             return out.reshape(H, W, tail[0])
-        out = nat.gather_px(idx, img_bytes)
-        tdt = torch.from_numpy(np.empty(0, dt)).dtype
-        return out.view(tdt).reshape((H, W) + tuple(tail))
+        return _typed(nat.gather_px(idx, img_bytes), tail, dt, H, W)
 
     def process_coordinate_map(self, coordinate_map, interpolation: str = "nearest"):
         """Maps this image's pixels through ``coordinate_map`` and returns the new image
@@ -320,10 +315,8 @@ class _GpuProjection:
                 raise NotImplementedError("bilinear sampling needs a lazy coordinate map (a recipe), not a materialised array")
             if not rgb8 or custom_src:
                 raise NotImplementedError("bilinear sampling takes uint8 (H, W, 3) images and built-in lenses")
-        on_device = isinstance(self.image, torch.Tensor)
+        on_device = nat.is_device_array(self.image)  # the pixels live on the device: so does the result
         fused = rgb8 and not custom_src
-        img = _device_image(self.image, h, w) if fused else _device_bytes(self.image)
-        dev = img.device
         rotations = coordinate_map.rotations if lazy else ()
         if interpolation == "bilinear" and len(rotations) > nat.PB_MAX_ROTATIONS:
             # The reference applies any number of -r rotations one after the other (scripts/commands/make_photo.py:128-131).  A chain
@@ -334,41 +327,54 @@ class _GpuProjection:
                 folded = np.asarray(r, dtype=np.float64).reshape(3, 3) @ folded
             rotations = [folded]
         too_many = lazy and len(rotations) > nat.PB_MAX_ROTATIONS
+        if fused and not on_device and lazy and not too_many:
+            # THE path of a user who swapped imports: ndarray in, fresh ndarray out - upload, ONE fused launch, download, on the
+            # package's own device buffers, stream and page-locked memory (_hostpipe.py; no PyTorch involved)
+            nat.require_gpu()
+            a = _checked_rgb8(self.image, h, w)
+            plan = _plan_for(coordinate_map.dst_proj, rotations, src, eager=interpolation != "nearest")
+            out = _hostpipe.remap_ndarray(plan, a, interpolation)
+            if src.kind == nat.KIND_PANO:
+                coordinate_map.note_invalid_zeroed()  # projection.py:534-536
+            return out
+        img = _device_image(self.image, h, w) if fused else _device_bytes(self.image)
+        dev = img.device if nat.is_tensor(img) else None
         if lazy and not too_many and not custom_src:
             # bilinear taps come from the tile models: that mode needs the prepared plan from the first use on
             plan = _plan_for(coordinate_map.dst_proj, rotations, src, device=dev, eager=interpolation != "nearest")
-            if fused:
-                out = plan.remap(img, interpolation=interpolation)
-            else:
-                idx, wts = plan.index_map(weights=True, device=dev) if src.kind == nat.KIND_DOUBLE else (plan.index_map(device=dev), None)
-                out = self._gather(src, idx, wts, img, tail, dt)
+            with nat.on_device(nat.device_index_of(img)):
+                if fused:
+                    out = plan.remap(img, interpolation=interpolation)
+                else:
+                    idx, wts = plan.index_map(weights=True, device=dev) if src.kind == nat.KIND_DOUBLE else (plan.index_map(device=dev), None)
+                    out = self._gather(src, idx, wts, img, tail, dt)
             if src.kind == nat.KIND_PANO:
                 coordinate_map.note_invalid_zeroed()  # projection.py:534-536
             return out if on_device else _to_host(out)
         # a materialised map: the caller's tensor / ndarray, or a recipe that has to become one (more rotations than one
         # fused plan takes: the reference accepts any number of -r options; a source lens evaluated on the host)
         host = None
-        if isinstance(coordinate_map, torch.Tensor):
-            _check_map_tensor(coordinate_map, dev)
-            dmap = coordinate_map
-        elif lazy:
-            with torch.cuda.device(dev):
+        with nat.on_device(nat.device_index_of(img)):
+            if nat.is_device_array(coordinate_map):
+                _check_map_tensor(coordinate_map, dev)
+                dmap = coordinate_map
+            elif lazy:
                 dmap = coordinate_map.device_tensor()
-            if src.kind == nat.KIND_PANO:
-                coordinate_map.note_invalid_zeroed()
-        else:
-            host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
-            if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
-                raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
-            dmap = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
-        if fused:
-            out = nat.sample_map(src, dmap, img)
-        else:
-            idx, wts = self._index_from_map(src, dmap)
-            out = self._gather(src, idx, wts, img, tail, dt)
-        if host is not None and src.kind == nat.KIND_PANO:
-            host[...] = dmap.cpu().numpy()  # the in-place zeroing of invalid pixels
-        return out if on_device else _to_host(out)
+                if src.kind == nat.KIND_PANO:
+                    coordinate_map.note_invalid_zeroed()
+            else:
+                host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
+                if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
+                    raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
+                dmap = _upload(host, dev)
+            if fused:
+                out = nat.sample_map(src, dmap, img)
+            else:
+                idx, wts = self._index_from_map(src, dmap)
+                out = self._gather(src, idx, wts, img, tail, dt)
+            if host is not None and src.kind == nat.KIND_PANO:
+                host[...] = nat.to_host(dmap)  # the in-place zeroing of invalid pixels
+            return out if on_device else _to_host(out)
 
 
 def _role_lens_id(lens: Lens, role: str) -> int:
@@ -408,7 +414,7 @@ class CameraImage(_GpuProjection):
         the equidistant lens (whose inverse is the identity), the longitudes with it; the callable and the
         validity rule run here."""
         eq = nat.make_proj(nat.KIND_CAMERA, proj.height, proj.width, nat.LENS_IDS["equidistant"], proj.fov, proj.magnitude, proj.f_distance)
-        m = nat.coordmap(eq).cpu().numpy()
+        m = nat.to_host(nat.coordmap(eq))
         lat = np.asarray(self.reverse_lens(m[:, :, 0].copy()), dtype=np.float64)
         m[:, :, 0] = lat
         with np.errstate(invalid="ignore"):
@@ -450,8 +456,8 @@ class DoubleCameraImage(_GpuProjection):
         (the right eye's x axis is the left one negated), taken from the device like CameraImage's."""
         half = proj.width // 2
         eq = nat.LENS_IDS["equidistant"]
-        dist = nat.coordmap(nat.make_proj(nat.KIND_CAMERA, proj.height, half, eq, proj.fov, proj.magnitude, proj.f_distance))[:, :, 0].cpu().numpy()
-        m = nat.coordmap(nat.make_proj(nat.KIND_DOUBLE, proj.height, proj.width, eq, proj.fov, proj.magnitude, proj.f_distance)).cpu().numpy()
+        dist = nat.to_host(nat.coordmap(nat.make_proj(nat.KIND_CAMERA, proj.height, half, eq, proj.fov, proj.magnitude, proj.f_distance)))[:, :, 0]
+        m = nat.to_host(nat.coordmap(nat.make_proj(nat.KIND_DOUBLE, proj.height, proj.width, eq, proj.fov, proj.magnitude, proj.f_distance)))
         lat = np.asarray(self.reverse_lens(np.concatenate([dist, dist], axis=1)), dtype=np.float64)
         lat[:, half:] *= -1
         lat[:, half:] += np.pi
@@ -484,14 +490,14 @@ def map_projection(coordinate_map):
     """Coordinate map -> RGB colour map for eyeballing a projection (projection.py:550-599): latitude in
     red (stretched over the valid pixels), longitude in green, the invalid flag in blue.  Runs on the GPU
     (pb_map_projection_u8); like the reference it zeroes lat/lon of invalid pixels in the map it is given."""
-    if isinstance(coordinate_map, torch.Tensor):
+    if nat.is_device_array(coordinate_map):
         _check_map_tensor(coordinate_map)
         return nat.map_projection(coordinate_map)
     host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
     if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
         raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
     nat.require_gpu()
-    dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+    dev = _upload(host)
     out = nat.map_projection(dev)
-    host[...] = dev.cpu().numpy()
+    host[...] = nat.to_host(dev)
     return _to_host(out)

@@ -7,7 +7,6 @@ inside the fused remap kernel) or run by pb_rotate_f64 on a materialised map.
 from __future__ import annotations
 
 import numpy as np
-import torch
 
 from .. import _native as nat
 from ._coordmap import CoordinateMap
@@ -37,17 +36,20 @@ class Rotation:
         if isinstance(coordinate_map, CoordinateMap) and coordinate_map.is_lazy:
             coordinate_map.note_invalid_zeroed()
             return coordinate_map.rotated(self.rotation_matrix)
-        if isinstance(coordinate_map, torch.Tensor):
-            if not (coordinate_map.is_cuda and coordinate_map.dtype == torch.float64 and coordinate_map.is_contiguous()):
+        if nat.is_device_array(coordinate_map):
+            if nat.is_tensor(coordinate_map) and not (coordinate_map.is_cuda and coordinate_map.dtype == nat.torch.float64 and coordinate_map.is_contiguous()):
                 raise TypeError("tensor coordinate maps must be contiguous float64 CUDA tensors")
-            if coordinate_map.dim() != 3 or coordinate_map.shape[2] != 3:
+            if not nat.is_tensor(coordinate_map) and coordinate_map.dtype != np.float64:
+                raise TypeError("device coordinate maps must be float64")
+            if len(coordinate_map.shape) != 3 or coordinate_map.shape[2] != 3:
                 raise ValueError(f"a coordinate map has shape (H, W, 3), got {tuple(coordinate_map.shape)}")
-            return nat.rotate(self.rotation_matrix, coordinate_map)
+            with nat.on_device(nat.device_index_of(coordinate_map)):
+                return nat.rotate(self.rotation_matrix, coordinate_map)
         host = coordinate_map.materialize() if isinstance(coordinate_map, CoordinateMap) else coordinate_map
         if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
             raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
         nat.require_gpu()
-        dev = torch.from_numpy(np.ascontiguousarray(host)).cuda()
+        dev = nat.to_device(host)
         out = nat.rotate(self.rotation_matrix, dev)
-        host[...] = dev.cpu().numpy()  # the in-place zeroing of invalid pixels
-        return out.cpu().numpy()
+        host[...] = nat.to_host(dev)  # the in-place zeroing of invalid pixels
+        return nat.to_host(out)

@@ -1856,5 +1856,51 @@ int pb_event_elapsed_ms(void* start, void* stop, float* ms) {
     PB_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return PB_OK;
 }
+int pb_device_count(int* n) {
+    if (!n) return pb_fail(PB_ERR_INVALID, "null argument");
+    *n = 0;
+    if (hipGetDeviceCount(n) != hipSuccess) {
+        (void)hipGetLastError();
+        *n = 0;
+    }
+    return PB_OK;
+}
+int pb_set_device(int device) {
+    PB_HIP(hipSetDevice(device));
+    return PB_OK;
+}
+int pb_get_device(int* device) {
+    if (!device) return pb_fail(PB_ERR_INVALID, "null argument");
+    PB_HIP(hipGetDevice(device));
+    return PB_OK;
+}
+int pb_device_sync(void) {
+    PB_HIP(hipDeviceSynchronize());
+    return PB_OK;
+}
+int pb_stream_wait_event(void* stream, void* event) {
+    if (!event) return pb_fail(PB_ERR_INVALID, "null argument");
+    PB_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return PB_OK;
+}
+int pb_host_alloc(void** host_ptr, size_t bytes) {
+    if (!host_ptr) return pb_fail(PB_ERR_INVALID, "null argument");
+    PB_HIP(hipHostMalloc(host_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return PB_OK;
+}
+int pb_host_free(void* host_ptr) {
+    if (host_ptr) PB_HIP(hipHostFree(host_ptr));
+    return PB_OK;
+}
+int pb_host_register(void* host_ptr, size_t bytes) {
+    if (!host_ptr || !bytes) return pb_fail(PB_ERR_INVALID, "null argument");
+    PB_HIP(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    return PB_OK;
+}
+int pb_host_unregister(void* host_ptr) {
+    if (!host_ptr) return pb_fail(PB_ERR_INVALID, "null argument");
+    PB_HIP(hipHostUnregister(host_ptr));
+    return PB_OK;
+}
 
 }  // extern "C"

@@ -14,10 +14,25 @@ from __future__ import annotations
 from typing import List, Sequence, Tuple
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 from . import _native as nat
+
+try:  # the multi-process host logic rides on torch.distributed (nccl = RCCL on ROCm; gloo on CPU); a host without PyTorch binds the
+    import torch  # same five steps through the C ABI instead (pb_comm_* / pb_bcast_params / pb_remap_batch_sharded)
+    import torch.distributed as dist
+except ImportError:
+    torch = None
+
+    class _NoDist:
+        @staticmethod
+        def is_available():
+            return False
+
+        @staticmethod
+        def is_initialized():
+            return False
+
+    dist = _NoDist()
 
 _MAGIC = 0x50424E44  # "PBND"
 _HEADER = 2
