@@ -316,12 +316,23 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
         durs.append(ms.value / every / batch)
     for e in ev:
         lib.pb_event_destroy(e)
-    if bilinear:  # the opt-in 4-tap mode (no reference behaviour): time only
+    if bilinear:  # the opt-in 4-tap mode (no reference behaviour; its parity is pinned to OUR definition: tests/test_hip_bilinear.py)
         per_frame_ms = float(np.mean(durs))
+        alg, must = byte_accounting(plan, (sh, sw), device)
+        alg4 = alg + 3 * ((alg - 3 * dh * dw) // 3) * 3  # four taps of 3 bytes per in-bounds sample instead of one
+        info = plan.info()
+        out = {"workload": cfg["text"] + " - OPT-IN bilinear sampling (pb_remap_bilinear_u8; not the reference's sampler)", "frames_per_launch": batch,
+               "kernel_ms_per_frame": round(per_frame_ms, 5), "kernel_ms_per_frame_p10": round(float(np.percentile(durs, 10)), 5),
+               "kernel_ms_per_frame_p90": round(float(np.percentile(durs, 90)), 5),
+               "mpx_per_s": round(dh * dw / 1e6 / (per_frame_ms * 1e-3), 1), "launches_timed": n_groups * every,
+               "algorithmic_bytes_per_frame": alg4, "must_move_bytes_per_frame": must,
+               "frac": round(alg4 / (per_frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "frac_note": "4-tap algorithmic bytes (3 B written per output pixel + 4 x 3 B read per in-bounds sample) / kernel time / 8 TB/s; the bytes that must cross HBM are the nearest mode's",
+               "bilinear_float64_tiles": info["bilinear_float64_tiles"], "tiles": info["tiles"],
+               "nearest_over_bilinear_note": "one launch per call: tile models where certified to 1/1024 px, the plan's exact coordinate table elsewhere; no float64 per frame"}
         del srcs, dsts, plan
         torch.cuda.empty_cache()
-        return {"workload": cfg["text"] + " - OPT-IN bilinear sampling (pb_remap_bilinear_u8; not the reference's sampler)", "frames_per_launch": batch,
-                "kernel_ms_per_frame": round(per_frame_ms, 5), "mpx_per_s": round(dh * dw / 1e6 / (per_frame_ms * 1e-3), 1), "launches_timed": n_groups * every}
+        return out
     alg, must = byte_accounting(plan, (sh, sw), device)
     pins = json.load(open(os.path.join(ROOT, "tests", "golden", "full.json")))
     ref_alg = int(pins[cfg["pin"]]["algorithmic_bytes"])
@@ -333,16 +344,9 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
     if batch == 1:
         for n in (1, 2, 3):
             wall[str(n)] = round(multi_stream_ms(fn, h, sp0, dp0, sbytes, dbytes, pool, batch, device, n), 5)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", f"traffic_{name}_{info['window_budget']}.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            traffic = tj.get("hbm_bytes_per_launch")
-            if traffic and tj.get("frames_per_launch", 1) > 1:
-                traffic = traffic / tj["frames_per_launch"]
-        except Exception:
-            traffic = None
+    traffic, _ = traffic_for(name, info)
+    if traffic and batch > 1:
+        traffic = traffic / batch
     out = {
         "workload": cfg["text"],
         "frames_per_launch": batch,
@@ -366,6 +370,27 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
     del srcs, dsts, plan
     torch.cuda.empty_cache()
     return out
+
+
+TILE_MIX_KEYS = ("tiles", "fix_tiles", "fix_pixels", "lean_tiles", "black_tiles", "direct_tiles", "window_budget")
+
+
+def traffic_for(name, info):
+    """HBM bytes per launch from the committed PMC pass (profiles/traffic_<config>_<budget>.json: FETCH_SIZE x 2 + WRITE_SIZE, separate
+    --pmc runs) - or (None, why) when that file describes ANOTHER tile mix than the running plan's (a counter figure
+    taken on a plan with other tile classes says nothing about this launch)."""
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{name}_{info['window_budget']}.json")
+    if not os.path.exists(tpath):
+        return None, "no PMC pass committed for this config and budget"
+    try:
+        tj = json.load(open(tpath))
+    except Exception as exc:
+        return None, repr(exc)
+    theirs = tj.get("plan") or {}
+    diff = [k for k in TILE_MIX_KEYS if theirs.get(k) != info.get(k)]
+    if diff:
+        return None, f"{os.path.relpath(tpath, ROOT)} was taken on another tile mix ({', '.join(f'{k}: {theirs.get(k)} vs {info.get(k)}' for k in diff)})"
+    return tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
 
 
 def headline_extras(lib, nat, d, rots, s, cfg, device, stream, budget):
@@ -448,6 +473,133 @@ def graph_replay_ms(lib, nat, plan, srcs, dsts, sbytes, dbytes, n_pool, device, 
         e1.record(side)
         side.synchronize()
     return e0.elapsed_time(e1) / (replays * launches)
+
+
+def host_path(cfg, d, rots, s):
+    """The drop-in's REAL path for the headline config: NumPy in -> NumPy out through the facade.  The
+    reference's contract is ndarray in, fresh ndarray out (core/__init__.py:66-92), so a user who swaps imports pays upload +
+    kernel + download per frame - never `value`, always next to it."""
+    import photonbend_amd as pb
+    from photonbend_amd import _device, _hostpipe, batch
+    from photonbend_amd import _native as nat
+
+    sh, dh = (s.height, s.width, 3), (d.height, d.width, 3)
+    n_pool = 4
+    rng = np.random.default_rng(7)
+    pool = [rng.integers(0, 256, size=sh, dtype=np.uint8) for _ in range(n_pool)]
+    plan = nat.Plan(d, rots, s)
+
+    def med_ms(ts):
+        return round(sorted(ts)[len(ts) // 2] * 1e3, 3)
+
+    def singles(make, reps=8):
+        ts = []
+        for k in range(reps):
+            a = make(k)
+            t0 = time.perf_counter()
+            out = _hostpipe.remap_ndarray(plan, a)
+            ts.append(time.perf_counter() - t0)
+        assert out.shape == dh
+        return med_ms(ts[2:])
+
+    fresh = singles(lambda k: pool[k % n_pool].copy())  # (the copy is made outside the timed region)
+    buf = np.empty(sh, np.uint8)
+
+    def refill(k):
+        buf[...] = pool[k % n_pool]
+        return buf
+
+    reused = singles(refill)
+    list(batch.remap_frames(plan, (pool[k % n_pool] for k in range(2 * n_pool))))  # (ring buffers: page-locked after their second sighting)
+    n = 16
+    t0 = time.perf_counter()
+    cnt = sum(1 for _ in batch.remap_frames(plan, (pool[k % n_pool] for k in range(n))))
+    ring = (time.perf_counter() - t0) / n * 1e3
+    once = [pool[k % n_pool].copy() for k in range(n)]
+    t0 = time.perf_counter()
+    cnt += sum(1 for _ in batch.remap_frames(plan, iter(once)))
+    staged = (time.perf_counter() - t0) / n * 1e3
+    assert cnt == 2 * n
+    del once
+    lib = nat.load()
+    pipe = _hostpipe.pipe_for()
+    hin = _device.PINNED.ndarray(sh, np.uint8)
+    hout = _device.PINNED.ndarray(dh, np.uint8)
+    din, dout = _device.DeviceArray((hin.nbytes,), np.uint8), _device.DeviceArray((hout.nbytes,), np.uint8)
+    dma = {}
+    for key, fn in (("h2d_ms", lambda: lib.pb_memcpy_h2d(din.data_ptr(), hin.ctypes.data, hin.nbytes, pipe.stream.handle)),
+                    ("d2h_ms", lambda: lib.pb_memcpy_d2h(hout.ctypes.data, dout.data_ptr(), hout.nbytes, pipe.stream.handle))):
+        fn()
+        pipe.stream.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        pipe.stream.sync()
+        dma[key] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    return {
+        "workload": cfg["text"] + " - uint8 ndarray in host memory in, fresh uint8 ndarray out",
+        "ms_per_frame_single_call": fresh,
+        "ms_per_frame_single_call_note": "remap of an ndarray never seen before (upload staged through page-locked chunks on a few threads) -> fresh ndarray (page-locked, written by the download DMA directly)",
+        "ms_per_frame_single_call_reused_buffer": reused,
+        "ms_per_frame_single_call_reused_buffer_note": "the caller refills ONE buffer: page-locked in place on its second sighting, then one DMA straight out of the caller's memory",
+        "ms_per_frame_streamed": round(max(ring, staged), 3),
+        "ms_per_frame_streamed_ring_of_caller_buffers": round(ring, 3),
+        "ms_per_frame_streamed_never_seen_arrays": round(staged, 3),
+        "ms_per_frame_streamed_note": "batch.remap_frames: upload of frame k + 1, kernel of frame k and download of frame k - 1 on three streams; `ms_per_frame_streamed` is the slower of the two source kinds",
+        **dma,
+        "bytes_up": int(np.prod(sh)), "bytes_down": int(np.prod(dh)),
+        "mpx_per_s_streamed": round(d.height * d.width / 1e6 / (max(ring, staged) * 1e-3), 1),
+        "torch_in_the_path": False,
+    }
+
+
+def sharded_workload(lib, nat, parallel, name, per_rank, rank, world, device, coll_device, stream, dist, passes=3, chunk=8):
+    """BASELINE configs 4 / 5 as north_star states them: a batch of per_rank x world distinct frames sharded contiguously over the
+    ranks (parallel.shard_range), every rank remapping ITS frames, resident in its own HBM, `chunk` per launch; the only collective
+    on the data path is the broadcast of the parameter block.  Returns this rank's view: (seconds for `passes` passes over its
+    share - max-reduced by the caller -, frames per pass, SHA-256 of its first output frame, global index of that frame, plan)."""
+    import hashlib
+
+    import torch
+
+    cfg = CONFIGS[name]
+    block = None
+    if rank == 0:
+        d, rots, s = build_projs(cfg)
+        block = parallel.pack_params(d, rots, s)
+    d, rots, s = parallel.unpack_params(parallel.broadcast_params(block, device=coll_device, src=0))
+    plan = nat.Plan(d, rots, s, budget=BENCH_BUDGET[name])
+    total = per_rank * world
+    mine = parallel.shard_range(total, world, rank)
+    n = len(mine)
+    sh, sw, dh, dw = s.height, s.width, d.height, d.width
+    sbytes, dbytes = 3 * sh * sw, 3 * dh * dw
+    srcs = torch.empty((n, sh, sw, 3), dtype=torch.uint8, device=device)
+    for i, k in enumerate(mine):
+        nat.synth_frame(sh, sw, frame=k, seed=0, circle_mask=cfg["mask"], out=srcs[i])
+    dsts = torch.empty((n, dh, dw, 3), dtype=torch.uint8, device=device)
+
+    def one_pass():
+        for a in range(0, n, chunk):
+            m = min(chunk, n - a)
+            rc = lib.pb_remap_u8(plan.handle, srcs.data_ptr() + a * sbytes, dsts.data_ptr() + a * dbytes, m, sbytes, dbytes, stream)
+            if rc:
+                nat.check(rc)
+
+    one_pass()
+    torch.cuda.synchronize(device)
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        one_pass()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    digest = hashlib.sha256(dsts[0].cpu().numpy().tobytes()).digest()
+    del srcs, dsts
+    torch.cuda.empty_cache()
+    return dt, n, digest, mine.start, plan, (d, s, cfg)
 
 
 def copy_ceiling_gbs(lib, nat, device, stream) -> float:
@@ -635,14 +787,7 @@ def main():
         achieved = alg_launch / (launch_ms * 1e-3) / 1e9
         ceiling = copy_ceiling_gbs(lib, nat, device, sts[0])
         info = plan.info()
-        traffic = traffic_src = None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}_{info['window_budget']}.json")
-        if os.path.exists(tpath) and not bilinear:
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-                traffic_src = os.path.relpath(tpath, ROOT)
-            except Exception:
-                traffic = None
+        traffic, traffic_src = (None, "bilinear run: the committed PMC passes are the nearest kernel's") if bilinear else traffic_for(args.config, info)
         line = {
             "metric": "Mpixels/s remapped, 8K equirect->equidistant" if cfg["pin"] == "c2" else f"Mpixels/s remapped ({args.config})",
             "value": round(value, 1),
@@ -717,11 +862,78 @@ def main():
             line["single_image_ms"] = single_ms
             line["single_image_note"] = "warm plan creation (thresholds, tile models, certification, launch table) + the first frame of a NEW geometry, device-resident input; a deferred plan instead runs faithful_kernel_ms with no preparation"
             line["faithful_kernel_ms"] = faithful_ms
+            # the un-amortised figures travel WITH the headline: `frac` above prices a launch of a prepared plan;
+            # one image of a new geometry pays either the preparation + one launch, or the float64 chain per pixel
+            line["roofline"]["frac_unamortised"] = {
+                "single_image": round(alg_frame / (single_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "faithful_kernel": round(alg_frame / (faithful_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "single_image_ms": single_ms, "faithful_kernel_ms": faithful_ms,
+                "break_even_frames": round(max(0.0, single_ms - launch_ms) / max(1e-9, faithful_ms - launch_ms), 1),
+                "note": "algorithmic bytes of ONE frame / (warm plan preparation + first launch) resp. / the float64 kernel's time, over 8 TB/s: what a caller who remaps a geometry once gets",
+            }
             block = {}
             for name in ("c1", "c3", "c5", "c4shard", "c5shard"):
                 block[name] = measure_config(lib, nat, name, device, sts[0])
-            block["c5_bilinear"] = measure_config(lib, nat, "c5", device, sts[0], steps=40, warmup=4, bilinear=True)
+            for name in ("c1", "c2", "c3", "c5"):
+                block[name + "_bilinear"] = measure_config(lib, nat, name, device, sts[0], steps=60, warmup=8, bilinear=True)
             line["configs"] = block
+            try:
+                line["host_path"] = host_path(cfg, d, rots, s)
+            except Exception as exc:  # a measurement extra: never fail the line over it
+                line["host_path"] = {"error": repr(exc)}
+    # ---- north_star's multi-GPU workloads, at ANY rank count: c4 = 64 frames per GPU, c5 = 32 per GPU, sharded
+    # with shard_range, 8 frames per launch; aggregate Mpx/s over all ranks; every rank's first output frame is re-made by rank 0
+    # from the same frame index and must be byte-identical (SURVEY 8 e's acceptance check)
+    sharded = None
+    if not bilinear and not args.no_configs and args.config == "c2":
+        import hashlib
+
+        try:
+            del srcs, dsts
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        sharded = {}
+        for wname, cname, per_rank in (("c4", "c2", 64), ("c5", "c5", 32)):
+            passes = 3
+            dt_w, n_mine, digest, first_k, wplan, (wd, ws, wcfg) = sharded_workload(lib, nat, parallel, cname, per_rank, rank, world, device, coll_device, sts[0], dist, passes=passes)
+            tw = torch.tensor([dt_w], dtype=torch.float64, device=coll_device)
+            mine_t = torch.tensor(list(digest) + [first_k & 0xFF, (first_k >> 8) & 0xFF, (first_k >> 16) & 0xFF, 0], dtype=torch.uint8, device=coll_device)
+            gathered = [mine_t]
+            if dist.is_initialized():
+                dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+                gathered = [torch.empty_like(mine_t) for _ in range(world)]
+                dist.all_gather(gathered, mine_t)
+            if rank == 0:
+                same = 0
+                for r, g in enumerate(gathered):
+                    gb = bytes(g.cpu().numpy().tolist())
+                    k = gb[32] | (gb[33] << 8) | (gb[34] << 16)
+                    assert k == parallel.shard_range(per_rank * world, world, r).start
+                    frame = nat.synth_frame(ws.height, ws.width, frame=k, seed=0, circle_mask=wcfg["mask"])
+                    mine_out = wplan.remap(frame)
+                    if hashlib.sha256(mine_out.cpu().numpy().tobytes()).digest() != gb[:32]:
+                        raise SystemExit(f"bench.py: {wname}: frame {k} remapped by rank {r} differs from rank 0's remap of the same frame")
+                    same += 1
+                    del frame, mine_out
+                mpx = wd.height * wd.width / 1e6
+                frames_total = world * per_rank * passes
+                sharded[wname] = {
+                    "workload": f"BASELINE config {wname[1]}: {per_rank * world} distinct frames of {CONFIGS[cname]['text'].split(':')[0]}'s geometry, {per_rank} per GPU resident in HBM, 8 per launch, sharded by parallel.shard_range",
+                    "frames_total": per_rank * world, "frames_per_gpu": per_rank, "frames_per_launch": 8, "passes_timed": passes,
+                    "mpx_per_s": round(frames_total * mpx / float(tw.item()), 1),
+                    "ms_per_frame_per_gpu": round(float(tw.item()) * 1e3 / (per_rank * passes), 5),
+                    "first_frames_identical_to_rank0": same,
+                    "timing": "barrier + device sync, `passes` passes over each rank's share, device sync; MAX over ranks",
+                }
+            del wplan
+            torch.cuda.empty_cache()
+    if rank == 0:
+        if sharded is not None:
+            sharded["ranks_seen"] = dist.get_world_size() if dist.is_initialized() else 1
+            sharded["collective_backend"] = dist.get_backend() if dist.is_initialized() else None
+            sharded["collective"] = "one broadcast of the 90-double parameter block per workload (RCCL when the backend is nccl); no pixel crosses a link"
+            line["sharded"] = sharded
         if world == 1 and not args.no_cpu_baseline and not bilinear:  # (the CPU leg times the reference's nearest sampler)
             line["cpu_baseline"] = cpu_baseline(cfg, mpx_per_frame)
             extra = cpu_baseline_all_cores(args.config, mpx_per_frame)
