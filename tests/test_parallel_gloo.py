@@ -240,3 +240,66 @@ def test_c_abi_comm_broadcast_and_sharded_remap_on_one_gpu():
     p.join(timeout=120)
     assert p.exitcode == 0
     assert same and ok and (first, count, n, r) == (0, 5, 1, 0)
+
+
+def _c4_share_worker(q):
+    """One GPU's share of BASELINE config 4 (64 distinct 8192x4096 panoramas, 9.7 GB resident) through the C ABI's sharded entry point."""
+    import ctypes
+    import hashlib
+
+    from tests import helpers as H
+    from tests.cases import full_cases
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    lib = nat.load()
+    uid = ctypes.create_string_buffer(128)
+    nat.check(lib.pb_comm_unique_id(uid))
+    comm = ctypes.c_void_p()
+    nat.check(lib.pb_comm_init(1, 0, uid, ctypes.byref(comm)))
+    case = [c for c in full_cases() if c.name == "c2"][0]
+    plan = H.pb_plan_private(case)
+    n = 64
+    h, w, Hd, Wd = case.src[1], case.src[2], case.dst[1], case.dst[2]
+    frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
+    for f in range(n):
+        nat.synth_frame(h, w, frame=f, seed=0, out=frames[f])
+    out = torch.empty((n, Hd, Wd, 3), dtype=torch.uint8, device="cuda")
+    out.fill_(0x5A)
+    first, count = ctypes.c_int(-1), ctypes.c_int(-1)
+    nat.check(lib.pb_remap_batch_sharded(comm, plan.handle, frames.data_ptr(), out.data_ptr(), n, 0, 0, ctypes.byref(first), ctypes.byref(count), nat.current_stream()))
+    torch.cuda.synchronize()
+    idx = plan.index_map()
+    idx_sha = hashlib.sha256(idx.contiguous().cpu().numpy().tobytes()).hexdigest()
+    flat = idx.reshape(-1).long()
+    live = (flat >= 0).unsqueeze(1)
+    safe = flat.clamp(min=0)
+    bad = 0
+    for f in range(n):
+        want = frames[f].reshape(-1, 3)[safe] * live
+        bad += int(not torch.equal(out[f].reshape(-1, 3), want))
+        del want
+    distinct = int(not torch.equal(out[0], out[1])) + int(not torch.equal(out[62], out[63]))
+    nat.check(lib.pb_comm_destroy(comm))
+    q.put((idx_sha, bad, distinct, first.value, count.value))
+
+
+@pytest.mark.gpu
+def test_64_frame_c4_share_through_the_sharded_entry_point():
+    """north_star's c4 workload is 64 frames per GPU.  One rank's whole share (64 distinct 8192x4096 frames, 6.4 GB
+    in + 3.2 GB out, resident) goes through pb_remap_batch_sharded in ONE call; every output frame equals frame[idx] with the plan's
+    index map, whose SHA-256 is the reference's (tests/golden/full.json: c2.idx_sha256)."""
+    from tests import helpers as H
+
+    pin = H.load_full()["c2"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_c4_share_worker, args=(q,))
+    p.start()
+    idx_sha, bad, distinct, first, count = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert idx_sha == pin["idx_sha256"], "the plan's index map is not the reference's"
+    assert (first, count) == (0, 64)
+    assert bad == 0, f"{bad} of 64 frames differ from frame[idx]"
+    assert distinct == 2
