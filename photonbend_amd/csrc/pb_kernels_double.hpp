@@ -548,9 +548,11 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_double_pair_kernel(cons
         if (i >= P.dst.height || j >= P.dst.width) continue;
         PbCoord c = pb_dst_coord(P, i, j);
         for (int r = 0; r < P.n_rot; ++r) c = pb_rotate(P.R[r], c);
-        const PbDoubleTap t = pb_src_double_taps(P, c);
-        unit = unit && t.fl == 1.0 && t.fr == 1.0;
-        if (row_ok) row_ok = rows[i].f_l == t.fl && rows[i].f_r == t.fr && !c.inv;
+        // the blend factors are functions of the latitude alone (projection.py:439-457): no taps, no sine / cosine here (round 4: this
+        // kernel used to evaluate both eyes' whole source stage per pixel for the sake of two numbers)
+        const double t_fl = pb_merge_factor(P, c.lat), t_fr = pb_merge_factor(P, (c.lat * -1.0) + PB_PI);
+        unit = unit && t_fl == 1.0 && t_fr == 1.0;
+        if (row_ok) row_ok = rows[i].f_l == t_fl && rows[i].f_r == t_fr && !c.inv;
     }
     const bool all_unit = __builtin_amdgcn_ballot_w64(!unit) == 0;
     const bool all_row = rows != nullptr && __builtin_amdgcn_ballot_w64(!row_ok) == 0;

@@ -49,8 +49,19 @@ __device__ __forceinline__ void pb_store_px4(uint8_t* __restrict__ out, unsigned
     }
 }
 
+// waves per SIMD the float64 remap kernel is compiled for (its register budget).  Measured on MI355X (experiments/r4/build_f64.sh):
+// four waves (128 VGPRs, a few spilled) against the compiler's own choice of three - c2 187 -> 163 us, c3 530 -> 499; the two-eye chain
+// is better left alone (434 against 454)
+#ifndef PB_FAITHFUL_WPE
+#define PB_FAITHFUL_WPE(kind) ((kind) == PB_KIND_DOUBLE ? 1 : 4)
+#endif
+#ifndef PB_FAITHFUL_UNROLL  // pixels of a work-item whose float64 chains the compiler may interleave
+#define PB_FAITHFUL_UNROLL 4
+#endif
+#define PB_PRAGMA(x) _Pragma(#x)
+#define PB_UNROLL(n) PB_PRAGMA(unroll n)
 template <int SRC_KIND>
-__global__ __launch_bounds__(PB_BLOCK) void pb_remap_kernel(const PbParams P, const uint8_t* __restrict__ src,
+__global__ __launch_bounds__(PB_BLOCK, PB_FAITHFUL_WPE(SRC_KIND)) void pb_remap_kernel(const PbParams P, const uint8_t* __restrict__ src,
                                                             uint8_t* __restrict__ dst, int n_frames,
                                                             unsigned long long src_stride,
                                                             unsigned long long dst_stride, int aligned) {
@@ -66,7 +77,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_remap_kernel(const PbParams P, co
     int idx2[PB_PX];
     double fl[PB_PX], fr[PB_PX];
     bool inv[PB_PX];
-#pragma unroll
+    PB_UNROLL(PB_FAITHFUL_UNROLL)
     for (int k = 0; k < PB_PX; ++k) {
         idx[k] = -1;
         idx2[k] = -1;

@@ -1089,12 +1089,29 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_window_kernel(const PbP
 // without a model) are marked failed.  A LEAN tile whose pixels do not all satisfy the lean
 // invariants (non-negative offsets inside the window) loses the flag.  counters: [0] fix pixels,
 // [1] failed tiles, [2] pixels differing in total (statistics), [3] tiles with a model, [4] LEAN tiles.
+// Plan creation, unrotated panorama destinations: an output pixel's longitude depends on its column alone (projection.py:502-512), so the
+// correctly rounded sine / cosine the source stage takes of it (np.exp(lon * 1j), projection.py:252) is evaluated once per COLUMN -
+// col_sc[2 j] = cos, col_sc[2 j + 1] = sin, the very bits a per-pixel evaluation returns - and certification looks them up (round 4:
+// c5's two certification passes were 2.4 of its 3.7 ms of plan preparation, most of it this one function).
+__global__ void pb_col_sincos_kernel(const PbParams P, double* __restrict__ col_sc) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.dst.width) return;
+    const PbCoord c = pb_dst_coord(P, 0, j);
+    pb_sincos_cr(c.lon, &col_sc[2 * j + 1], &col_sc[2 * j]);
+}
+
+#ifndef PB_CERTIFY_WPE
+#define PB_CERTIFY_WPE 1
+#endif
+#ifndef PB_CERTIFY_UNROLL
+#define PB_CERTIFY_UNROLL 0
+#endif
 template <int SRC_KIND>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const PbParams P, PbTileEntry* __restrict__ table,
+__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify_kernel(const PbParams P, PbTileEntry* __restrict__ table,
                                                                          int32_t* __restrict__ fail_tiles,
                                                                          int32_t* __restrict__ fix_px, unsigned fix_capacity,
-                                                                         unsigned* __restrict__ counters) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                                         unsigned* __restrict__ counters, const double* __restrict__ col_sc = nullptr) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (wave-uniform: the tile entry is read with scalar loads)
     int tx, ty;
     if (!pb_tile_of_wave(P, wave, tx, ty)) return;
     const int tile = ty * pb_tiles_x(P) + tx;
@@ -1110,17 +1127,34 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_certify_kernel(const Pb
         pb_model_row(P, e, X0, Y0, y, xh, R);
         bool lean_ok = true;
         double coarse = 0.0;  // largest |model - faithful| pre-truncation coordinate over this lane's sampled pixels, px
+#if PB_CERTIFY_UNROLL
+        PB_UNROLL(PB_CERTIFY_UNROLL)
+#endif
         for (int k = 0; k < 16; ++k) {
             const int j = X0 + xh + k;
             if (i < P.dst.height && j < P.dst.width) {
                 const int fast = pb_model_px<SRC_KIND>(P, R, xh, k);
                 PbCoord cc = pb_dst_coord(P, i, j);
                 for (int r = 0; r < P.n_rot; ++r) cc = pb_rotate(P.R[r], cc);
-                const int exact = pb_exact_index_of<SRC_KIND>(P, cc);
+                // the faithful index and the faithful pre-truncation coordinate from ONE evaluation of the longitude's sine / cosine
+                int exact;
+                double f0 = 0.0, f1 = 0.0;
+                if (SRC_KIND == PB_KIND_PANO) {
+                    exact = pb_src_pano_index(P, cc);
+                    if (exact >= 0) pb_src_pretrunc<PB_KIND_PANO>(P, cc, f0, f1);
+                } else {
+                    double sl, cl;
+                    if (col_sc) {  // (unrotated panorama destination: the column's table entry IS pb_sincos_cr(cc.lon))
+                        cl = col_sc[2 * j];
+                        sl = col_sc[2 * j + 1];
+                    } else {
+                        pb_sincos_cr(cc.lon, &sl, &cl);
+                    }
+                    exact = pb_src_index_sc<SRC_KIND>(P, cc, sl, cl);
+                    pb_src_pretrunc_sc<SRC_KIND>(P, cc, sl, cl, f0, f1);
+                }
                 diff |= (unsigned)(fast != exact) << k;
                 if (exact >= 0) {  // (what the bilinear mode needs to know: PB_TILE_COARSE)
-                    double f0, f1;
-                    pb_src_pretrunc<SRC_KIND>(P, cc, f0, f1);
                     int mr, mc;
                     pb_f2 mf;
                     pb_model_px_raw(R, xh, k, mr, mc, mf);

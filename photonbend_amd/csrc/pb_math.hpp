@@ -89,15 +89,35 @@ PB_MATH_FN pb_dd pb_dd_div(pb_dd a, pb_dd b) {
     return pb_dd_add_d(q, q3);
 }
 
-// x = kd * pi/2 + r, |r| <= pi/4 (+ an ulp), r a double-double good to ~2^-120 of pi/2; x finite, |x| < 2^19
+// 1 / x for the fast paths, whose quotients are corrected with an exact remainder (so 2^-47 is plenty): on the device the hardware
+// estimate and one Newton step - a full IEEE float64 division is ~25 instructions there; on the host the division itself.  The
+// RESULTS of the functions below are the correctly rounded ones either way (tests/test_hip_math.py compares the two builds bit for
+// bit).
+#if defined(__HIP_DEVICE_COMPILE__)
+PB_MATH_FN double pb_rcp(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+PB_MATH_FN float pb_quotf(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#else
+PB_MATH_FN double pb_rcp(double x) { return 1.0 / x; }
+PB_MATH_FN float pb_quotf(float a, float b) { return a / b; }
+#endif
+
+// x = kd * pi/2 + r, |r| <= pi/4 (+ an ulp), r a double-double good to ~2^-105 of ITSELF; x finite, |x| < 2^19.
+// Round 4 (the reduction was a third of the fast path): kd == 0 - a quarter of the chain's angles - has nothing to remove; otherwise
+// x - kd P1 is exact (P1 has 33 bits, so kd P1 is exact, and it lies within a factor of two of x: Sterbenz), kd P2 is exact, and the
+// 106-bit tail kd (P3H + P3L) comes off with one exact head difference and a float64 sum of the tails.
 PB_MATH_FN pb_dd pb_reduce_pio2(double x, double& kd) {
     kd = rint(x * PB_TWO_OVER_PI_DD[0]);
-    // the first two pieces of pi/2 have 33 bits, so their products with kd are exact
-    pb_dd r = pb_two_sum(x, -kd * PB_PIO2_1);
-    r = pb_dd_add_d(r, -kd * PB_PIO2_2);
+    if (kd == 0.0) return {x, 0.0};
+    const double a = fma(-kd, PB_PIO2_1, x);
+    pb_dd r = pb_two_sum(a, -kd * PB_PIO2_2);
     pb_dd t = pb_two_prod(kd, PB_PIO2_3H);
     t.l = fma(kd, PB_PIO2_3L, t.l);
-    return pb_dd_add(r, pb_dd_neg(t));
+    pb_dd s = pb_two_sum(r.h, -t.h);
+    s.l += r.l - t.l;
+    return pb_fast_two_sum(s.h, s.l);
 }
 
 // sin and cos of the reduced argument r as double-doubles (relative error < 2^-95): the SLOW path
@@ -256,16 +276,17 @@ PB_MATH_FN pb_dd pb_atan_dd01(pb_dd t) {
 // atan(num / den) = atan(c) + atan(u), c = i / 256 the table point next to the quotient, u = (num - c den) / (den + c num) formed
 // from the ARGUMENTS (one reciprocal in all), |u| <= 2^-9 (+): atan u = u + u^3 (-1/3 + u^2 / 5 - u^4 / 7) with the bracket in float64.
 PB_MATH_FN pb_dd pb_atan_fast(double num, double den) {
-    const int i = (int)rintf(256.0f * ((float)num / (float)den));  // 0 .. 256; a neighbour of the best index serves as well
+    int i = (int)rintf(256.0f * pb_quotf((float)num, (float)den));  // 0 .. 256; a neighbour of the best index serves as well
+    i = i < 0 ? 0 : (i > 256 ? 256 : i);
     const double c = (double)i * 0.00390625;
     const pb_dd p = pb_two_prod(c, den), q = pb_two_prod(c, num);
     pb_dd N = pb_two_sum(num, -p.h);
     N = pb_fast_two_sum(N.h, N.l - p.l);
     pb_dd D = pb_fast_two_sum(den, q.h);  // den >= c num
     D = pb_fast_two_sum(D.h, D.l + q.l);
-    const double inv = 1.0 / D.h;
+    const double inv = pb_rcp(D.h);
     const double u1 = N.h * inv;
-    double rem = fma(-u1, D.h, N.h);  // exact: u1 is within two ulps of N.h / D.h
+    double rem = fma(-u1, D.h, N.h);  // the remainder of u1 (exact to 2^-100 of N: u1 is within 2^-47 of the quotient)
     rem = fma(-u1, D.l, rem) + N.l;
     const double u2 = rem * inv;
     const double w = u1 * u1;

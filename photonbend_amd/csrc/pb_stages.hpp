@@ -252,12 +252,8 @@ __device__ __forceinline__ int pb_src_pano_index(const PbParams& P, const PbCoor
 }
 
 // one fisheye of size h x w centred at (cy, cx): (py, px) or ok == false
-// (projection.py:247-260, :223-231)
-__device__ __forceinline__ bool pb_src_camera_pos(const PbParams& P, double lat, double lon, int h, int w, double cy,
-                                                  double cx, int& py, int& px) {
-    const double dist = pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
-    double sl, cl;
-    pb_sincos_cr(lon, &sl, &cl);  // np.exp(lon * 1j)   projection.py:252
+// (projection.py:247-260, :223-231), from the distance and the sine / cosine of the longitude (np.exp(lon * 1j), projection.py:252)
+__device__ __forceinline__ bool pb_src_camera_pos_sc(double dist, double sl, double cl, int h, int w, double cy, double cx, int& py, int& px) {
     const double re = cl * dist, im = sl * dist;
     const long long y = pb_cvt_i64((im * -1.0) + cy);
     const long long x = pb_cvt_i64(re + cx);
@@ -266,11 +262,51 @@ __device__ __forceinline__ bool pb_src_camera_pos(const PbParams& P, double lat,
     px = (int)x;
     return true;
 }
+__device__ __forceinline__ bool pb_src_camera_pos(const PbParams& P, double lat, double lon, int h, int w, double cy,
+                                                  double cx, int& py, int& px) {
+    const double dist = pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
+    double sl, cl;
+    pb_sincos_cr(lon, &sl, &cl);  // np.exp(lon * 1j)   projection.py:252
+    return pb_src_camera_pos_sc(dist, sl, cl, h, w, cy, cx, py, px);
+}
 
 __device__ __forceinline__ int pb_src_camera_index(const PbParams& P, const PbCoord& c) {
     int py, px;
     const bool ok = pb_src_camera_pos(P, c.lat, c.lon, P.src.height, P.src.width, P.src_cy, P.src_cx, py, px);
     return (ok && !c.inv) ? py * P.src.width + px : -1;
+}
+
+// the index of ONE source (SRC_KIND camera, or one eye of a double frame: into the full side-by-side frame) from the sine / cosine of
+// the longitude: both eyes of a stitch see the same longitude (round 4: its correctly rounded sincos is evaluated once per pixel, not
+// once per eye - the float64 chain of c5 spent half its transcendental work on the repeat)
+template <int SRC_KIND>
+__device__ __forceinline__ int pb_src_index_sc(const PbParams& P, const PbCoord& c, double sl, double cl) {
+    int py, px;
+    if (SRC_KIND == PB_KIND_EYE_R) {
+        const double lat_r = (c.lat * -1.0) + PB_PI;  // projection.py:426-427
+        const double dist = pb_lens_forward(P.src.lens, lat_r, P.rect_max) * P.src.f_distance;
+        const bool ok = pb_src_camera_pos_sc(dist, sl, cl, P.src.height, P.src_eye_w_right, P.src_cy, P.src_cx_r, py, px);
+        // the right eye is mirrored before it is sampled (projection.py:430-431)
+        return (ok && !c.inv) ? py * P.src.width + (P.src_eye_w + (P.src_eye_w_right - 1 - px)) : -1;
+    }
+    const double dist = pb_lens_forward(P.src.lens, c.lat, P.rect_max) * P.src.f_distance;
+    const int we = (SRC_KIND == PB_KIND_EYE_L) ? P.src_eye_w : P.src.width;
+    const bool ok = pb_src_camera_pos_sc(dist, sl, cl, P.src.height, we, P.src_cy, P.src_cx, py, px);
+    return (ok && !c.inv) ? py * P.src.width + px : -1;
+}
+// ... and its pre-truncation coordinates (what pb_src_pretrunc gives, with the caller's sine / cosine)
+template <int SRC_KIND>
+__device__ __forceinline__ void pb_src_pretrunc_sc(const PbParams& P, const PbCoord& c, double sl, double cl, double& f0, double& f1) {
+    if (SRC_KIND == PB_KIND_EYE_R) {
+        const double lat_r = (c.lat * -1.0) + PB_PI;
+        const double dist = pb_lens_forward(P.src.lens, lat_r, P.rect_max) * P.src.f_distance;
+        f0 = ((sl * dist) * -1.0) + P.src_cy;
+        f1 = (double)P.src.width - ((cl * dist) + P.src_cx_r);
+    } else {
+        const double dist = pb_lens_forward(P.src.lens, c.lat, P.rect_max) * P.src.f_distance;
+        f0 = ((sl * dist) * -1.0) + P.src_cy;
+        f1 = (cl * dist) + P.src_cx;
+    }
 }
 
 struct PbDoubleTap {
@@ -287,12 +323,10 @@ __device__ __forceinline__ double pb_merge_factor(const PbParams& P, double lat)
 __device__ __forceinline__ PbDoubleTap pb_src_double_taps(const PbParams& P, const PbCoord& c) {
     PbDoubleTap t;
     const double lat_r = (c.lat * -1.0) + PB_PI;  // projection.py:426-427
-    int py, px;
-    bool ok = pb_src_camera_pos(P, c.lat, c.lon, P.src.height, P.src_eye_w, P.src_cy, P.src_cx, py, px);
-    t.il = (ok && !c.inv) ? py * P.src.width + px : -1;
-    ok = pb_src_camera_pos(P, lat_r, c.lon, P.src.height, P.src_eye_w_right, P.src_cy, P.src_cx_r, py, px);
-    // the right eye is mirrored before it is sampled (projection.py:430-431)
-    t.ir = (ok && !c.inv) ? py * P.src.width + (P.src_eye_w + (P.src_eye_w_right - 1 - px)) : -1;
+    double sl, cl;
+    pb_sincos_cr(c.lon, &sl, &cl);  // np.exp(lon * 1j): ONE evaluation serves both eyes (same argument, same bits)
+    t.il = pb_src_index_sc<PB_KIND_EYE_L>(P, c, sl, cl);
+    t.ir = pb_src_index_sc<PB_KIND_EYE_R>(P, c, sl, cl);
     t.fl = pb_merge_factor(P, c.lat);
     t.fr = pb_merge_factor(P, lat_r);
     return t;

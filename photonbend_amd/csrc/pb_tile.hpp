@@ -100,9 +100,10 @@ __device__ __forceinline__ void pb_chain_real(const PbParams& P, double fi, doub
 // faithful chain at an integer pixel -> source index (-1 = black); THE reference path
 template <int SRC_KIND>
 __device__ __forceinline__ int pb_exact_index_of(const PbParams& P, const PbCoord& c) {
-    if (SRC_KIND == PB_KIND_EYE_L) return pb_src_double_taps(P, c).il;
-    if (SRC_KIND == PB_KIND_EYE_R) return pb_src_double_taps(P, c).ir;
-    return (SRC_KIND == PB_KIND_PANO) ? pb_src_pano_index(P, c) : pb_src_camera_index(P, c);
+    if (SRC_KIND == PB_KIND_PANO) return pb_src_pano_index(P, c);
+    double sl, cl;
+    pb_sincos_cr(c.lon, &sl, &cl);
+    return pb_src_index_sc<SRC_KIND>(P, c, sl, cl);  // (one eye of a double frame: that eye alone)
 }
 template <int SRC_KIND>
 __device__ __forceinline__ int pb_exact_index(const PbParams& P, int i, int j) {

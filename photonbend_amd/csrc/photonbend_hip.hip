@@ -291,12 +291,14 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             unsigned* counters = reinterpret_cast<unsigned*>(scratch + 4);
             if (hipMemset(counters, 0, 12 * sizeof(unsigned)) != hipSuccess) { rc = PB_ERR_HIP; break; }
             const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
+            // (unrotated panorama destination: the separable path's column table holds the sine / cosine of every column's longitude)
+            const double* col_sc = (P.dst.kind == PB_KIND_PANO && P.n_rot == 0 && pl->sep_cols) ? reinterpret_cast<const double*>(pl->sep_cols) : nullptr;
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table);
-            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters);
+            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters, col_sc);
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r);
-            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r, pl->fail_tiles, pl->fix_px, cap, counters);
+            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r, pl->fail_tiles, pl->fix_px, cap, counters, col_sc);
             const unsigned lat_capacity = ntiles < 65536u ? ntiles : 65536u;  // <= 512 MiB of latitudes
             hipLaunchKernelGGL(pb_double_pair_kernel, grid, block, 0, 0, P, pl->table, pl->table_r, pl->sep_ready ? pl->sep_rows : nullptr,
                                pl->fail_tiles, counters, lat_capacity);
@@ -347,9 +349,16 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters);
         } else {
+            double* col_sc = nullptr;  // (unrotated panorama destination: one sine / cosine per column instead of one per pixel)
+            if (P.dst.kind == PB_KIND_PANO && P.n_rot == 0 && hipMalloc((void**)&col_sc, (size_t)P.dst.width * 2 * sizeof(double)) == hipSuccess)
+                hipLaunchKernelGGL(pb_col_sincos_kernel, dim3((P.dst.width + 255) / 256), dim3(256), 0, 0, P, col_sc);
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table);
-            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters);
+            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters, (const double*)col_sc);
+            if (col_sc) {
+                (void)hipDeviceSynchronize();
+                (void)hipFree(col_sc);
+            }
         }
         unsigned res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
