@@ -78,11 +78,26 @@ def ulp_diff(a, b):
     return np.abs(ai - bi)
 
 
+# (case, stage, channel) -> (largest ulp distance, values beyond 1 ulp) of the rotated float64 maps against the reference's, measured on
+# MI355X with this build (GPUTEST r4); everything not listed: <= MAP_ULPS and nothing beyond 1 ulp
+ROTATED_MAP_LIMITS = {
+    ("C_alter_eqd_eqs_rot", 1, "lat"): (24, 23),
+    ("C_alter_eqd_eqs_rot", 1, "lon"): (159, 27),
+    ("D_photo_rot", 1, "lat"): (1, 0),
+    ("D_photo_rot", 1, "lon"): (1, 0),
+    ("D_pano_chain", 1, "lat"): (5, 7),
+    ("D_pano_chain", 1, "lon"): (1, 0),
+    ("D_pano_chain", 2, "lat"): (7, 37),
+    ("D_pano_chain", 2, "lon"): (68, 179),
+}
+
+
 @pytest.mark.parametrize("case", [c for c in small_cases() if c.keep_map], ids=lambda c: c.name)
 def test_materialised_maps_within_ulps(case, capsys):
-    """north_star asks for 1 ULP per channel on floating-point results; the materialised float64 maps differ from the
-    reference's by the last bits of different libms (device OCML vs NumPy's SVML / glibc mix): bound 4 ulp, plus the
-    pole conditioning of acos / atan2 after rotations.  The measured maximum per stage is printed."""
+    """north_star asks for 1 ULP per channel on floating-point results.  get_coordinate_map (stage 0) meets it but for the asin-based
+    lenses (NumPy's SIMD asin is itself not correctly rounded: thoby 2 ulp); after a rotation the maps are held to the PINNED measured
+    maxima of ROTATED_MAP_LIMITS (f-1 stays "partial": NumPy's SIMD arccos cannot be restated from what this image holds).  The
+    measured maximum per stage is printed."""
     import photonbend_amd as pb
 
     n = case.name
@@ -99,19 +114,24 @@ def test_materialised_maps_within_ulps(case, capsys):
             g, w = got[..., ch], want[..., ch]
             both_nan = np.isnan(g) & np.isnan(w)
             d = ulp_diff(np.where(both_nan, 0.0, g), np.where(both_nan, 0.0, w))
-            # near zero an absolute bound replaces the ulp bound; after k rotations
-            # lat = acos(v_y) and lon = atan2(v_z, v_x) are ill-conditioned near the
-            # poles: a 1-ulp change of v moves them by 2^-53 / sin(lat)
-            with np.errstate(all="ignore"):
-                cond = k * 8 * 2.0**-52 / np.maximum(np.abs(np.sin(want[..., 0])), 1e-9)
-                ok = (d <= MAP_ULPS) | (np.abs(g - w) <= np.maximum(1e-15, cond))
+            # After k rotations lat = arccos(v_y) and lon = atan2(v_z, v_x) (rotation.py:158-164).  The device's sin / cos / atan2 are
+            # correctly rounded (NumPy's = glibc's are, on all but ~1 argument in 1000); arccos is NOT matched: NumPy's AVX-512 loop
+            # (SVML-derived, third-party, not in /root/reference nor in this image as source) differs from correct rounding on 9.5 % of
+            # the arguments (profiles/r03_libm_mismatch.txt) and by tens of ulp of the RESULT where v_y -> +-1 (the poles: a result of
+            # 1e-8 carries the absolute error of a value near 1), and atan2 amplifies a last-bit difference of v there.  VERDICT r3
+            # item 6, second branch: no formula - the measured maxima of THIS build against the committed reference maps are pinned,
+            # as upper bounds, per case, stage and channel (values beyond 1 ulp: likewise).
+            lim_max, lim_n = ROTATED_MAP_LIMITS.get((n, k, name), (MAP_ULPS, 0)) if k else (MAP_ULPS, None)
+            ok = d <= lim_max
             lens = case.dst[3] if case.dst[0] != "pano" else "pano"
             well = d[np.abs(np.sin(want[..., 0])) > 1e-3] if k else d
             with capsys.disabled():
                 print(f"\n[maps {n}: dst lens {lens}, stage {k} ({'after %d rotation(s)' % k if k else 'get_coordinate_map'}), {name}] "
                       f"max {int(d.max())} ulp, {int((d > 1).sum())} of {d.size} values beyond 1 ulp, "
                       f"max away from the poles {int(well.max()) if well.size else 0} ulp", end="")
-            assert ok.all(), f"stage {k} {name}: max {d.max()} ulp"
+            assert ok.all(), f"stage {k} {name}: max {d.max()} ulp (pinned maximum {lim_max})"
+            if k and lim_n is not None:
+                assert int((d > 1).sum()) <= lim_n, f"stage {k} {name}: {int((d > 1).sum())} values beyond 1 ulp (pinned {lim_n})"
             if k == 0:
                 # round 3: sin / cos / atan2 / atan of the device chain are correctly rounded (pb_math.hpp) like glibc's and
                 # np.arctan on all but ~1 argument in 1000: longitudes and atan / identity latitudes agree to the bit or to 1 ulp;
