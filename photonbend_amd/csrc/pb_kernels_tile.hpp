@@ -1084,11 +1084,21 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_window_kernel(const PbP
     e->flags |= masked ? (PB_TILE_DIRECT | PB_TILE_MASKED) : (stageable ? PB_TILE_LEAN : PB_TILE_DIRECT);
 }
 
+// Plan creation, after certification: how many tiles ended in each class.  counters: [4] LEAN, [5] BLACK, [6] DIRECT.
+__global__ void pb_count_flags_kernel(const PbTileEntry* __restrict__ table, unsigned n_tiles, unsigned* __restrict__ counters) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const int f = table[t].flags;
+    if (f & PB_TILE_LEAN) atomicAdd(&counters[4], 1u);
+    if (f & PB_TILE_BLACK) atomicAdd(&counters[5], 1u);
+    if (f & PB_TILE_DIRECT) atomicAdd(&counters[6], 1u);
+}
+
 // One wave per tile: compares the hot path's index with the faithful one for every pixel of the
 // tile; differing pixels go to the fix list, tiles with more than PB_TILE_FAIL_LIMIT of them (or
 // without a model) are marked failed.  A LEAN tile whose pixels do not all satisfy the lean
 // invariants (non-negative offsets inside the window) loses the flag.  counters: [0] fix pixels,
-// [1] failed tiles, [2] pixels differing in total (statistics), [3] tiles with a model, [4] LEAN tiles.
+// [1] failed tiles, [2] pixels differing in total (statistics).
 // Plan creation, unrotated panorama destinations: an output pixel's longitude depends on its column alone (projection.py:502-512), so the
 // correctly rounded sine / cosine the source stage takes of it (np.exp(lon * 1j), projection.py:252) is evaluated once per COLUMN -
 // col_sc[2 j] = cos, col_sc[2 j + 1] = sin, the very bits a per-pixel evaluation returns - and certification looks them up (round 4:
@@ -1106,6 +1116,9 @@ __global__ void pb_col_sincos_kernel(const PbParams P, double* __restrict__ col_
 #ifndef PB_CERTIFY_UNROLL
 #define PB_CERTIFY_UNROLL 0
 #endif
+#ifndef PB_CERT_ABL  // timing experiments only (experiments/r4/build_f64.sh): 1 = no faithful chain, 2 = no column-first evaluation, 4 = no coarse measure
+#define PB_CERT_ABL 0
+#endif
 template <int SRC_KIND>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify_kernel(const PbParams P, PbTileEntry* __restrict__ table,
                                                                          int32_t* __restrict__ fail_tiles,
@@ -1116,15 +1129,21 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify
     if (!pb_tile_of_wave(P, wave, tx, ty)) return;
     const int tile = ty * pb_tiles_x(P) + tx;
     PbTileEntry* e = table + tile;
+    // the tile's entry as the kernel found it, in scalar registers: the model is evaluated from THIS copy.  (Read through `e` - memory
+    // this kernel also writes - the 50 coefficients were fetched again for every one of a lane's 16 pixels: 79 scalar loads per wave,
+    // each a dependent round trip; 74 % of the kernel's wave cycles were waits: experiments/r4/pmc_plan.sh.)
+    PbTileEntry L;
+    pb_load_entry(e, L);
+    const PbTileEntry* __restrict__ ec = &L;
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
     const int y = lane & 31, xh = (lane >> 5) * 16;
     const int i = Y0 + y;
-    bool failed = (e->flags & PB_TILE_FAILED) != 0;
-    const bool lean = (e->flags & (PB_TILE_LEAN | PB_TILE_DIRECT)) != 0;
+    bool failed = (ec->flags & PB_TILE_FAILED) != 0;
+    const bool lean = (ec->flags & (PB_TILE_LEAN | PB_TILE_DIRECT)) != 0;
     unsigned diff = 0;  // bit k: pixel xh + k of this lane's row differs
     if (!failed) {
         PbRowModel R;
-        pb_model_row(P, e, X0, Y0, y, xh, R);
+        pb_model_row(P, ec, X0, Y0, y, xh, R);
         bool lean_ok = true;
         double coarse = 0.0;  // largest |model - faithful| pre-truncation coordinate over this lane's sampled pixels, px
 #if PB_CERTIFY_UNROLL
@@ -1134,12 +1153,17 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify
             const int j = X0 + xh + k;
             if (i < P.dst.height && j < P.dst.width) {
                 const int fast = pb_model_px<SRC_KIND>(P, R, xh, k);
-                PbCoord cc = pb_dst_coord(P, i, j);
-                for (int r = 0; r < P.n_rot; ++r) cc = pb_rotate(P.R[r], cc);
+                PbCoord cc = {0.0, 0.0, false};
+                if (!(PB_CERT_ABL & 1)) {
+                    cc = pb_dst_coord(P, i, j);
+                    for (int r = 0; r < P.n_rot; ++r) cc = pb_rotate(P.R[r], cc);
+                }
                 // the faithful index and the faithful pre-truncation coordinate from ONE evaluation of the longitude's sine / cosine
                 int exact;
                 double f0 = 0.0, f1 = 0.0;
-                if (SRC_KIND == PB_KIND_PANO) {
+                if (PB_CERT_ABL & 1) {
+                    exact = fast;
+                } else if (SRC_KIND == PB_KIND_PANO) {
                     exact = pb_src_pano_index(P, cc);
                     if (exact >= 0) pb_src_pretrunc<PB_KIND_PANO>(P, cc, f0, f1);
                 } else {
@@ -1154,7 +1178,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify
                     pb_src_pretrunc_sc<SRC_KIND>(P, cc, sl, cl, f0, f1);
                 }
                 diff |= (unsigned)(fast != exact) << k;
-                if (exact >= 0) {  // (what the bilinear mode needs to know: PB_TILE_COARSE)
+                if (exact >= 0 && !(PB_CERT_ABL & 4)) {  // (what the bilinear mode needs to know: PB_TILE_COARSE)
                     int mr, mc;
                     pb_f2 mf;
                     pb_model_px_raw(R, xh, k, mr, mc, mf);
@@ -1168,31 +1192,31 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify
                 }
                 if (lean && !pb_row_px_invalid(R, k)) {  // (a MASKED tile's invalid pixels are never sampled: the hot path masks them)
                     const pb_f2 f = pb_eval_row(R.a, pb_tile_coord(xh + k));
-                    lean_ok = lean_ok && f.x >= 0.0f && f.y >= 0.0f && (int)f.x < e->win_rows && (int)f.y < e->win_cols;
+                    lean_ok = lean_ok && f.x >= 0.0f && f.y >= 0.0f && (int)f.x < ec->win_rows && (int)f.y < ec->win_cols;
                     // plain tiles may also be evaluated column-first by the hot kernel (a DIRECT tile whose gathers run
                     // down the columns collapses the model along u once per lane): same polynomial, another rounding
                     // order - certified as well, a pixel either order gets wrong goes on the fix list
                     pb_f2 bcol[5];
-                    pb_collapse_col(e, xh + k, bcol);
+                    if (PB_CERT_ABL & 2) continue;
+                    pb_collapse_col(ec, xh + k, bcol);
                     const pb_f2 g = pb_eval_row(bcol, pb_tile_coord(y));
-                    lean_ok = lean_ok && g.x >= 0.0f && g.y >= 0.0f && (int)g.x < e->win_rows && (int)g.y < e->win_cols;
-                    const int fast_col = (e->anchor_r + (int)g.x) * P.src.width + e->anchor_c + (int)g.y;
+                    lean_ok = lean_ok && g.x >= 0.0f && g.y >= 0.0f && (int)g.x < ec->win_rows && (int)g.y < ec->win_cols;
+                    const int fast_col = (ec->anchor_r + (int)g.x) * P.src.width + ec->anchor_c + (int)g.y;
                     diff |= (unsigned)(fast_col != exact) << k;
                 }
             }
         }
         if (lean && __builtin_amdgcn_ballot_w64(!lean_ok) != 0) {
             if (lane == 0) e->flags &= ~(PB_TILE_LEAN | PB_TILE_DIRECT);
-        } else if (lean && lane == 0) {
-            atomicAdd(&counters[(e->flags & PB_TILE_LEAN) ? 4 : 6], 1u);
         }
-        if (lane == 0 && (e->flags & PB_TILE_BLACK)) atomicAdd(&counters[5], 1u);
         if (__builtin_amdgcn_ballot_w64(coarse > PB_COARSE_PX) != 0 && lane == 0) e->flags |= PB_TILE_COARSE;
         unsigned total = (unsigned)pb_wave_sum((int)__popc(diff));
-        if (lane == 0) {
-            atomicAdd(&counters[2], total);
-            atomicAdd(&counters[3], 1u);
-        }
+        // NO per-tile bookkeeping atomics here (round 4): every wave used to add to the same three or four words - LEAN / DIRECT / BLACK
+        // tile counts, pixel totals - and 32 768 waves x 3.5 device-scope atomics on one cache line WERE the kernel: 1.14 ms for c5 whatever
+        // was computed in between (experiments/r4/plan_kernels.sh: the float64 chain, the second evaluation order and the coordinate
+        // measure removed, one at a time: +-0).  The class counts come from pb_count_flags_kernel afterwards (one thread per tile, the
+        // compiler's wave-level reduction in front of each atomic); the pixel total is added where it is not zero.
+        if (lane == 0 && total) atomicAdd(&counters[2], total);
         if (total > PB_TILE_FAIL_LIMIT) failed = true;
         if (!failed && total) {
             unsigned base = 0;

@@ -299,6 +299,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r);
             hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r, pl->fail_tiles, pl->fix_px, cap, counters, col_sc);
+            hipLaunchKernelGGL(pb_count_flags_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, 0, pl->table, ntiles, counters);
+            hipLaunchKernelGGL(pb_count_flags_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, 0, pl->table_r, ntiles, counters);
             const unsigned lat_capacity = ntiles < 65536u ? ntiles : 65536u;  // <= 512 MiB of latitudes
             hipLaunchKernelGGL(pb_double_pair_kernel, grid, block, 0, 0, P, pl->table, pl->table_r, pl->sep_ready ? pl->sep_rows : nullptr,
                                pl->fail_tiles, counters, lat_capacity);
@@ -360,6 +362,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                 (void)hipFree(col_sc);
             }
         }
+        hipLaunchKernelGGL(pb_count_flags_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, 0, pl->table, ntiles, counters);
         unsigned res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
         pl->n_lean_tiles = res[4];
