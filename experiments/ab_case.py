@@ -10,6 +10,7 @@ import numpy as np, torch
 import bench
 from photonbend_amd import _native as nat
 L = nat.load()
+REMAP = L.pb_remap_bilinear_u8 if os.environ.get('PB_AB_BILINEAR') == '1' else L.pb_remap_u8  # PB_AB_BILINEAR=1: the opt-in bilinear mode
 dev = torch.device('cuda', 0)
 for spec in sys.argv[2:]:
     budget = 0
@@ -28,7 +29,7 @@ for spec in sys.argv[2:]:
     st = nat.current_stream()
     def step(k):
         i = (k % (pool // batch)) * batch
-        rc = L.pb_remap_u8(plan.handle, srcs.data_ptr() + i * sb, dsts.data_ptr() + i * db, batch, sb, db, st)
+        rc = REMAP(plan.handle, srcs.data_ptr() + i * sb, dsts.data_ptr() + i * db, batch, sb, db, st)
         if rc: nat.check(rc)
     for k in range(20): step(k)
     torch.cuda.synchronize()

@@ -183,22 +183,26 @@ __device__ __forceinline__ unsigned pb_umad24(unsigned a, unsigned b, unsigned c
 // tap on (an unaligned ds_read_b64 is legal here but measured three times slower: experiments/r4/exp_isa.hip).  Four pixels per call:
 // their 24 LDS reads are in flight together and their arithmetic interleaves - one pixel at a time left a wave waiting for LDS sixteen
 // times per tile, with a wait state after every dependent v_pk_fma of the coordinate polynomial (c5: a wave lived 19 us).
-__device__ __forceinline__ void pb_bil_lds4(const unsigned* win, const pb_f2 sv[4], unsigned pitch, unsigned a0, unsigned out[4]) {
+// a0w: the byte offset of the window's first sample from the START OF LDS (the wave's window offset folded in: a multiple of 16, so
+// the byte phase of an address is the sample's) - an address is two multiply-adds and one AND.
+typedef const __attribute__((address_space(3))) unsigned* pb_lds_cptr;
+__device__ __forceinline__ void pb_bil_lds4(const pb_f2 sv[4], unsigned pitch, unsigned a0w, unsigned out[4]) {
     unsigned l0[4], w[4][6];
     float tx[4], ty[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         ty[k] = __builtin_amdgcn_fractf(sv[k].x);
         tx[k] = __builtin_amdgcn_fractf(sv[k].y);
-        l0[k] = pb_umad24((unsigned)(int)sv[k].x, pitch, pb_umad24((unsigned)(int)sv[k].y, 3u, a0));
-        if (PB_BIL_ABL & 2) l0[k] = (l0[k] & 3u) + 64u;  // every lane reads the same dwords: no bank conflicts
-        const unsigned i0 = l0[k] >> 2, i1 = (l0[k] + pitch) >> 2;  // (the pitch is a multiple of 16: both rows share the byte phase)
-        w[k][0] = win[i0];
-        w[k][1] = win[i0 + 1];
-        w[k][2] = win[i0 + 2];
-        w[k][3] = win[i1];
-        w[k][4] = win[i1 + 1];
-        w[k][5] = win[i1 + 2];
+        l0[k] = pb_umad24((unsigned)(int)sv[k].x, pitch, pb_umad24((unsigned)(int)sv[k].y, 3u, a0w));
+        if (PB_BIL_ABL & 2) l0[k] = (l0[k] & 3u) + (a0w & ~15u) + 64u;  // every lane reads the same dwords: no bank conflicts
+        const unsigned b0 = l0[k] & ~3u;  // (the pitch is a multiple of 16: both rows share the byte phase)
+        const pb_lds_cptr r0 = (pb_lds_cptr)(uintptr_t)b0, r1 = (pb_lds_cptr)(uintptr_t)(b0 + pitch);
+        w[k][0] = r0[0];
+        w[k][1] = r0[1];
+        w[k][2] = r0[2];
+        w[k][3] = r1[0];
+        w[k][4] = r1[1];
+        w[k][5] = r1[2];
     }
 #pragma unroll
     for (int k = 0; k < 4; k += 2) {
@@ -439,6 +443,7 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pb_wave_sync();
         const pb_f2 half = {0.5f, 0.5f};
+        const unsigned a0w = a0 + (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)win;  // (LDS addresses are 32-bit offsets)
         if (along_x) {
             PB_MARK("window_colfirst");
 #pragma unroll
@@ -449,7 +454,7 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
                 b[0] = b[0] - half;  // s = f - 0.5, folded into the constant term (window path and direct path alike)
 #pragma unroll
                 for (int jr = 0; jr < 4; ++jr) sv[jr] = pb_eval_row(b, pb_tile_coord(yb + 8 * jr));
-                pb_bil_lds4(win, sv, pitch, a0, o);
+                pb_bil_lds4(sv, pitch, a0w, o);
 #pragma unroll
                 for (int jr = 0; jr < 4; ++jr) v[jr * 4 + k] = o[jr];
             }
@@ -462,7 +467,7 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
                 a[0] = a[0] - half;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sv[k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
-                pb_bil_lds4(win, sv, pitch, a0, &v[jr * 4]);
+                pb_bil_lds4(sv, pitch, a0w, &v[jr * 4]);
             }
         }
         PB_MARK("end");
