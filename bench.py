@@ -328,6 +328,7 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
                "algorithmic_bytes_per_frame": alg4, "must_move_bytes_per_frame": must,
                "frac": round(alg4 / (per_frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                "frac_note": "4-tap algorithmic bytes (3 B written per output pixel + 4 x 3 B read per in-bounds sample) / kernel time / 8 TB/s; the bytes that must cross HBM are the nearest mode's",
+               "traffic_bytes_per_frame": traffic_for(name + "_bilinear", info)[0],
                "bilinear_float64_tiles": info["bilinear_float64_tiles"], "tiles": info["tiles"],
                "nearest_over_bilinear_note": "one launch per call: tile models where certified to 1/1024 px, the plan's exact coordinate table elsewhere; no float64 per frame"}
         del srcs, dsts, plan
