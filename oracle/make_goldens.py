@@ -442,6 +442,32 @@ def gen_full_bilinear():
     print("full_bilinear.npz written; full.json updated (bilinear counts)")
 
 
+def gen_npmath():
+    """NumPy's own arcsin / arccos / arctan / tan (the functions the reference calls: rotation.py:158, lens.py:71-307) on the arguments of
+    tests/npmath_args.py: the RESULT BITS of this container's NumPy - the NumPy that produced every other golden - which
+    photonbend_amd/csrc/pb_math_np.hpp restates.  Scalars go through the same kernels as arrays (checked here), so one table per
+    function pins both uses."""
+    from tests import npmath_args
+
+    try:
+        from numpy._core._multiarray_umath import __cpu_features__ as feats
+    except ImportError:
+        from numpy.core._multiarray_umath import __cpu_features__ as feats
+    arrays = {}
+    for fn in npmath_args.FUNCTIONS:
+        x = npmath_args.arguments(fn)
+        with np.errstate(all="ignore"):
+            y = getattr(np, fn)(x)
+            for i in range(0, x.size, 997):  # scalar calls, strided views and short arrays take the same kernel
+                assert np.float64(getattr(np, fn)(float(x[i]))).tobytes() == y[i].tobytes()
+            assert getattr(np, fn)(x[::3]).tobytes() == y[::3].tobytes() and getattr(np, fn)(x[5:8]).tobytes() == y[5:8].tobytes()
+        arrays[fn] = y.view(np.uint64)
+    meta = {"numpy": np.__version__, "AVX512_SKX": bool(feats.get("AVX512_SKX")), "arguments": "tests/npmath_args.py", "n": int(npmath_args.N_PER_FUNCTION)}
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "npmath.npz"), **arrays)
+    print("npmath.npz written:", meta)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--lens", action="store_true")
@@ -454,8 +480,9 @@ if __name__ == "__main__":
     ap.add_argument("--real", action="store_true")
     ap.add_argument("--mid", action="store_true")
     ap.add_argument("--generic", action="store_true")
+    ap.add_argument("--npmath", action="store_true", help="NumPy's arcsin / arccos / arctan / tan result bits (tests/golden/npmath.npz)")
     a = ap.parse_args()
-    everything = not (a.full_bilinear or a.full_raw or a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic)
+    everything = not (a.full_bilinear or a.full_raw or a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic or a.npmath)
     os.makedirs(GOLD, exist_ok=True)
     if a.lens or everything:
         gen_lens()
@@ -477,3 +504,5 @@ if __name__ == "__main__":
         gen_cli()
     if a.real or everything:
         gen_real()
+    if a.npmath or everything:
+        gen_npmath()

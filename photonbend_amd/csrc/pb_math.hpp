@@ -334,3 +334,5 @@ PB_MATH_FN double pb_atan2_cr(double y, double x) {
     }
     return pb_atan2_slow(y, x, num, den, swap);
 }
+
+#include "pb_math_np.hpp"  // NumPy's own (SVML) arcsin / arccos / arctan / tan, bit for bit

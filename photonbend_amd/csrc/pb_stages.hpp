@@ -2,11 +2,11 @@
 // functions for ONE output pixel, in "faithful" float64: every IEEE-exact
 // operation (add, mul, div, sqrt, fma) is replayed in the reference's order with
 // contraction disabled (-ffp-contract=off), and the NumPy cast quirks are spelled out.
-// Transcendentals: sin / cos / atan2 - glibc's in the reference (np.sin, np.cos, np.exp(1j x), np.log(complex).imag) - are the
-// correctly rounded functions of pb_math.hpp (99.9 % bit-equal with glibc 2.35, which is itself correctly rounded on all but
-// ~1 argument in 1000), and so is atan (np.arctan: NumPy's SIMD path, correctly rounded on all but 7 arguments in 10 000);
-// asin / acos / tan stay with the device libm: NumPy's versions on the reference's host (SIMD asin / acos, glibc tan) are
-// 8-17 % away from correct rounding, so exactness would take THEIR algorithms, which are not the reference's to give.
+// Transcendentals, each the function the reference's NumPy actually runs (primitive table):
+//   sin / cos / atan2 - glibc's (np.sin, np.cos, np.exp(1j x), np.log(complex).imag): the correctly rounded functions of pb_math.hpp
+//     (99.9 % bit-equal with glibc 2.35, which is itself correctly rounded on all but ~1 argument in 1000);
+//   asin / acos / atan / tan - NumPy's own AVX-512 kernels (np.arcsin, np.arccos, np.arctan, np.tan), 8-17 % away from correct
+//     rounding: restated operation for operation in pb_math_np.hpp, bit-equal with NumPy on every argument tested.
 //
 //   stage A  dst_coord()      pixel (i, j) -> (lat, lon, invalid)
 //            CameraImage._compute_latitude_longitude  projection.py:171-194
@@ -49,15 +49,16 @@ __device__ __forceinline__ int pb_floor_mod(long long a, int n) {
 }
 
 // ---- a-1 lens functions (array semantics of core/lens.py) --------------------
+// np.tan / np.arcsin / np.arctan are NumPy's own SIMD kernels, restated bit for bit in pb_math_np.hpp; np.sin is glibc's (pb_math.hpp).
 __device__ __forceinline__ double pb_lens_forward(int lens, double theta, double rect_max) {
     switch (lens) {
         case PB_LENS_EQUIDISTANT: return theta;                          // lens.py:187
         case PB_LENS_EQUISOLID: return 2.0 * pb_sin_cr(theta / 2.0);     // lens.py:240-243
-        case PB_LENS_STEREOGRAPHIC: return 2.0 * tan(theta / 2.0);       // lens.py:142-145
+        case PB_LENS_STEREOGRAPHIC: return 2.0 * pb_tan_np(theta / 2.0); // lens.py:142-145
         case PB_LENS_ORTHOGRAPHIC: return pb_sin_cr(theta);              // lens.py:285
         case PB_LENS_THOBY: return 1.47 * pb_sin_cr(0.713 * theta);      // lens.py:332-335
         default: {                                                       // lens.py:97-103
-            double t = tan(theta);
+            double t = pb_tan_np(theta);
             return (theta < 0.0 || theta > rect_max) ? __builtin_nan("") : t;
         }
     }
@@ -66,13 +67,13 @@ __device__ __forceinline__ double pb_lens_inverse(int lens, double r) {
     switch (lens) {
         case PB_LENS_EQUIDISTANT: return r;                              // lens.py:165
         case PB_LENS_EQUISOLID: {                                        // lens.py:206-220
-            double t = 2.0 * asin(r / 2.0);
+            double t = 2.0 * pb_asin_np(r / 2.0);
             return (t != t) ? 0.0 : t;
         }
-        case PB_LENS_STEREOGRAPHIC: return 2.0 * pb_atan_cr(r / 2.0);    // lens.py:121-124
-        case PB_LENS_ORTHOGRAPHIC: return asin(r);                       // lens.py:261
-        case PB_LENS_THOBY: return asin(r / 1.47) / 0.713;               // lens.py:305
-        default: return pb_atan_cr(r);                                   // lens.py:71
+        case PB_LENS_STEREOGRAPHIC: return 2.0 * pb_atan_np(r / 2.0);    // lens.py:121-124
+        case PB_LENS_ORTHOGRAPHIC: return pb_asin_np(r);                 // lens.py:261
+        case PB_LENS_THOBY: return pb_asin_np(r / 1.47) / 0.713;         // lens.py:305
+        default: return pb_atan_np(r);                                   // lens.py:71
     }
 }
 
@@ -204,12 +205,12 @@ __device__ __forceinline__ bool pb_dst_inv_pred(const PbParams& P, long long n4,
     bool nan_region = false;
     switch (P.dst.lens) {
         case PB_LENS_EQUISOLID: {
-            const double t = 2.0 * asin(dist / 2.0);
+            const double t = 2.0 * pb_asin_np(dist / 2.0);
             nan_region = (t != t);
             lat = nan_region ? 0.0 : t;
         } break;
-        case PB_LENS_ORTHOGRAPHIC: lat = asin(dist); nan_region = (lat != lat); break;
-        case PB_LENS_THOBY: lat = asin(dist / 1.47) / 0.713; nan_region = (lat != lat); break;
+        case PB_LENS_ORTHOGRAPHIC: lat = pb_asin_np(dist); nan_region = (lat != lat); break;
+        case PB_LENS_THOBY: lat = pb_asin_np(dist / 1.47) / 0.713; nan_region = (lat != lat); break;
         default: lat = pb_lens_inverse(P.dst.lens, dist);
     }
     if (outside_domain) *outside_domain = nan_region;
@@ -235,7 +236,7 @@ __device__ __forceinline__ PbCoord pb_rotate(const double* __restrict__ R, PbCoo
     const double vx = fma(R[2], z, fma(R[0], x, R[1] * yy));
     const double vy = fma(R[5], z, fma(R[3], x, R[4] * yy));
     const double vz = fma(R[8], z, fma(R[6], x, R[7] * yy));
-    c.lat = acos(vy);         // rotation.py:158
+    c.lat = pb_acos_np(vy);   // rotation.py:158 (NumPy's SIMD arccos, bit for bit: pb_math_np.hpp)
     c.lon = pb_atan2(vz, vx); // rotation.py:159-164
     return c;
 }

@@ -76,3 +76,29 @@ def test_device_math_bits_equal_the_host_build(fn, tmp_path):
     assert dev.size == host.size == (2 * n if fn == 0 else n)
     bad = int((dev != host).sum())
     assert bad == 0, f"{bad} of {dev.size} results differ between the gfx950 build and the host build of pb_math.hpp"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["arcsin", "arccos", "arctan", "tan"])
+def test_device_build_of_the_numpy_functions_returns_numpys_bits(name, tmp_path):
+    """csrc/pb_math_np.hpp as the faithful chain runs it - the gfx950 build, instruction tables in device memory - against the result
+    bits of the NumPy that produced the goldens (tests/golden/npmath.npz): np.arcsin / np.arccos / np.arctan / np.tan are what
+    rotation.py:158 and lens.py:71-307 call.  Every bit of 40 000 results per function; NaN for NaN."""
+    from photonbend_amd.build import DIAG_LIB_PATH
+    from tests import npmath_args
+
+    if not os.path.exists(DIAG_LIB_PATH):
+        pytest.skip("needs the diagnostic build (python -m photonbend_amd.build --diag)")
+    fn = 3 + npmath_args.FUNCTIONS.index(name)
+    x = npmath_args.arguments(name)
+    src, dev_out = str(tmp_path / "in.bin"), str(tmp_path / "dev.bin")
+    x.tofile(src)
+    env = dict(os.environ, PB_LIB_PATH=DIAG_LIB_PATH)
+    res = subprocess.run([sys.executable, "-c", _SCRIPT, str(fn), src, dev_out], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    got = np.fromfile(dev_out, dtype=np.uint64)
+    want = np.load(os.path.join(ROOT, "tests", "golden", "npmath.npz"))[name]
+    assert got.size == want.size == x.size
+    both_nan = np.isnan(got.view(np.float64)) & np.isnan(want.view(np.float64))
+    bad = np.flatnonzero((got != want) & ~both_nan)
+    assert bad.size == 0, f"{name}: {bad.size} of {x.size} device results differ from NumPy, first at x = {x[bad[0]].hex()}: {got[bad[0]]:#018x} vs {want[bad[0]]:#018x}"

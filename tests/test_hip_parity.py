@@ -81,23 +81,26 @@ def ulp_diff(a, b):
 # (case, stage, channel) -> (largest ulp distance, values beyond 1 ulp) of the rotated float64 maps against the reference's, measured on
 # MI355X with this build (GPUTEST r4); everything not listed: <= MAP_ULPS and nothing beyond 1 ulp
 ROTATED_MAP_LIMITS = {
-    ("C_alter_eqd_eqs_rot", 1, "lat"): (24, 23),
-    ("C_alter_eqd_eqs_rot", 1, "lon"): (159, 27),
-    ("D_photo_rot", 1, "lat"): (1, 0),
+    ("C_alter_eqd_eqs_rot", 1, "lat"): (0, 0),
+    ("C_alter_eqd_eqs_rot", 1, "lon"): (1, 0),
+    ("D_photo_rot", 1, "lat"): (0, 0),
     ("D_photo_rot", 1, "lon"): (1, 0),
-    ("D_pano_chain", 1, "lat"): (5, 7),
+    ("D_pano_chain", 1, "lat"): (5, 8),
     ("D_pano_chain", 1, "lon"): (1, 0),
-    ("D_pano_chain", 2, "lat"): (7, 37),
-    ("D_pano_chain", 2, "lon"): (68, 179),
+    ("D_pano_chain", 2, "lat"): (2, 1),
+    ("D_pano_chain", 2, "lon"): (2, 2),
 }
 
 
 @pytest.mark.parametrize("case", [c for c in small_cases() if c.keep_map], ids=lambda c: c.name)
 def test_materialised_maps_within_ulps(case, capsys):
-    """north_star asks for 1 ULP per channel on floating-point results.  get_coordinate_map (stage 0) meets it but for the asin-based
-    lenses (NumPy's SIMD asin is itself not correctly rounded: thoby 2 ulp); after a rotation the maps are held to the PINNED measured
-    maxima of ROTATED_MAP_LIMITS (f-1 stays "partial": NumPy's SIMD arccos cannot be restated from what this image holds).  The
-    measured maximum per stage is printed."""
+    """north_star asks for 1 ULP per channel on floating-point results.  Round 4: asin / acos / atan / tan of the device chain are
+    NumPy's own SIMD kernels restated bit for bit (csrc/pb_math_np.hpp), sin / cos / atan2 the correctly rounded functions that glibc's
+    are on all but ~1 argument in 1000.  get_coordinate_map (stage 0): every latitude equals the reference's bits for every lens,
+    longitudes to 1 ulp at most.  After a rotation the only differences left come from glibc's own misrounded sin / cos of a latitude
+    or longitude (1 ulp of v, which arccos / atan2 may amplify): the maps are held to the PINNED measured maxima of
+    ROTATED_MAP_LIMITS - C_alter_eqd_eqs_rot 0 / 1 ulp (round 3: 24 / 159), D_pano_chain 5 ulp on 8 of 3 200 latitudes after one
+    rotation, 2 / 2 after two (round 3: 7 / 68).  The measured maximum per stage is printed."""
     import photonbend_amd as pb
 
     n = case.name
@@ -114,13 +117,11 @@ def test_materialised_maps_within_ulps(case, capsys):
             g, w = got[..., ch], want[..., ch]
             both_nan = np.isnan(g) & np.isnan(w)
             d = ulp_diff(np.where(both_nan, 0.0, g), np.where(both_nan, 0.0, w))
-            # After k rotations lat = arccos(v_y) and lon = atan2(v_z, v_x) (rotation.py:158-164).  The device's sin / cos / atan2 are
-            # correctly rounded (NumPy's = glibc's are, on all but ~1 argument in 1000); arccos is NOT matched: NumPy's AVX-512 loop
-            # (SVML-derived, third-party, not in /root/reference nor in this image as source) differs from correct rounding on 9.5 % of
-            # the arguments (profiles/r03_libm_mismatch.txt) and by tens of ulp of the RESULT where v_y -> +-1 (the poles: a result of
-            # 1e-8 carries the absolute error of a value near 1), and atan2 amplifies a last-bit difference of v there.  VERDICT r3
-            # item 6, second branch: no formula - the measured maxima of THIS build against the committed reference maps are pinned,
-            # as upper bounds, per case, stage and channel (values beyond 1 ulp: likewise).
+            # After k rotations lat = arccos(v_y) and lon = atan2(v_z, v_x) (rotation.py:158-164).  arccos is NumPy's own kernel, bit
+            # for bit; v differs from the reference's by one ulp where glibc's sin / cos is not the correctly rounded value (~0.1 % of
+            # the arguments; with NumPy's sin / cos fed in, the whole D_pano_chain map is bit-identical - experiments/README.md,
+            # round 4).  No formula: the measured maxima of THIS build against the committed reference maps are pinned, as upper
+            # bounds, per case, stage and channel (values beyond 1 ulp: likewise).
             lim_max, lim_n = ROTATED_MAP_LIMITS.get((n, k, name), (MAP_ULPS, 0)) if k else (MAP_ULPS, None)
             ok = d <= lim_max
             lens = case.dst[3] if case.dst[0] != "pano" else "pano"
@@ -133,13 +134,11 @@ def test_materialised_maps_within_ulps(case, capsys):
             if k and lim_n is not None:
                 assert int((d > 1).sum()) <= lim_n, f"stage {k} {name}: {int((d > 1).sum())} values beyond 1 ulp (pinned {lim_n})"
             if k == 0:
-                # round 3: sin / cos / atan2 / atan of the device chain are correctly rounded (pb_math.hpp) like glibc's and
-                # np.arctan on all but ~1 argument in 1000: longitudes and atan / identity latitudes agree to the bit or to 1 ulp;
-                # asin-based lenses (equisolid, orthographic: 1 ulp; thoby: asin(r / 1.47) / 0.713, 2 ulp) meet NumPy's SIMD asin,
-                # which is itself 8 % away from correct rounding
-                limit = 0 if name == "lon" and lens == "pano" else (1 if name == "lon" or lens in ("equidistant", "stereographic", "rectilinear", "pano") else 2)
+                # latitudes: pixel arithmetic (IEEE-exact) and NumPy's arcsin / arctan, restated bit for bit -> the reference's bits;
+                # longitudes: atan2, correctly rounded here, glibc's in the reference (itself correctly rounded on all but ~1 in 1000)
+                limit = 0 if name == "lat" or lens == "pano" else 1
                 assert int(d.max()) <= limit, f"stage 0 {name} ({lens}): {int(d.max())} ulp > {limit}"
-                assert int((d > 0).sum()) <= max(2, d.size // 100) or lens in ("equisolid", "orthographic", "thoby"), f"stage 0 {name}: {int((d > 0).sum())} values differ"
+                assert int((d > 0).sum()) <= max(2, d.size // 200), f"stage 0 {name}: {int((d > 0).sum())} values differ"
 
 
 @pytest.mark.parametrize("case", [c for c in small_cases() if c.keep_map], ids=lambda c: c.name)

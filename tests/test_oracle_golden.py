@@ -166,3 +166,51 @@ def test_device_math_agrees_with_glibc(tmp_path):
         assert int(undecided) <= int(calls) // 2000, out
         if err:
             assert float(err) <= float(thr) - 2.0, out
+
+
+@pytest.mark.parametrize("fn", ["arcsin", "arccos", "arctan", "tan"])
+def test_numpy_simd_functions_are_restated_bit_for_bit(fn, tmp_path):
+    """photonbend_amd/csrc/pb_math_np.hpp (host build) against the RESULT BITS of the NumPy that made the goldens
+    (tests/golden/npmath.npz: np.arcsin / np.arccos / np.arctan / np.tan on an AVX512_SKX machine - what rotation.py:158 and
+    lens.py:71-307 run there), on 40 000 arguments per function.  Not a tolerance: every bit, NaN for NaN."""
+    import shutil
+    import subprocess
+
+    from tests import npmath_args
+
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_math")
+    res = subprocess.run([gxx, "-O2", "-ffp-contract=off", "-mfma", "-o", exe, os.path.join(root, "oracle", "check_math.cpp"), "-lquadmath"],
+                         capture_output=True, text=True)
+    if res.returncode != 0 and "quadmath" in res.stderr:
+        pytest.skip("libquadmath missing")
+    assert res.returncode == 0, res.stderr
+    gold = np.load(os.path.join(root, "tests", "golden", "npmath.npz"))
+    x = npmath_args.arguments(fn)
+    src, dst = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    x.tofile(src)
+    code = 3 + npmath_args.FUNCTIONS.index(fn)
+    assert subprocess.run([exe, "--eval", str(code), src, dst], timeout=120).returncode == 0
+    got, want = np.fromfile(dst, dtype=np.uint64), gold[fn]
+    assert got.size == want.size == x.size
+    both_nan = np.isnan(got.view(np.float64)) & np.isnan(want.view(np.float64))
+    bad = np.flatnonzero((got != want) & ~both_nan)
+    assert bad.size == 0, f"{fn}: {bad.size} of {x.size} differ from NumPy, first at x = {x[bad[0]].hex()}: {got[bad[0]]:#018x} vs {want[bad[0]]:#018x}"
+    if fn == "tan":
+        return
+    # ... and where NumPy here IS that NumPy, a million fresh arguments (skipped on machines whose NumPy takes another code path)
+    try:
+        from numpy._core._multiarray_umath import __cpu_features__ as feats
+    except ImportError:
+        from numpy.core._multiarray_umath import __cpu_features__ as feats
+    with np.errstate(all="ignore"):
+        if not feats.get("AVX512_SKX") or getattr(np, fn)(x).view(np.uint64)[~both_nan].tobytes() != want[~both_nan].tobytes():
+            return
+    rng = np.random.default_rng(7)
+    y = (2.0 * rng.random(1_000_000) - 1.0) * (8.0 if fn == "arctan" else 1.0)
+    y.tofile(src)
+    assert subprocess.run([exe, "--eval", str(code), src, dst], timeout=120).returncode == 0
+    assert np.fromfile(dst, dtype=np.uint64).tobytes() == getattr(np, fn)(y).view(np.uint64).tobytes()
