@@ -27,7 +27,8 @@ static double uni() { return (double)(rnd() >> 11) * 0x1p-53; }
 static bool same(double a, double b) { return memcmp(&a, &b, 8) == 0 || (a != a && b != b); }
 
 // --eval <fn> <in> <out>: evaluates the header's functions on the doubles of a binary file (fn 0: sin, cos of each value, interleaved;
-// 1: atan2 of consecutive (y, x) pairs; 2: atan; 3..6: pb_math_np.hpp's asin, acos, atan, tan - NumPy's own) - the host half of tests/test_hip_math.py, which compares the gfx950 build of the
+// 1: atan2 of consecutive (y, x) pairs; 2: atan; 3..6: pb_math_np.hpp's asin, acos, atan, tan - NumPy's own;
+// 7, 8: pb_math_glibc.hpp's np.sin, np.cos; 9: np.exp(1j x) as (imag, real) interleaved; 10: np.log(x + 1j y).imag of (y, x) pairs) - the host half of tests/test_hip_math.py, which compares the gfx950 build of the
 // same header with this one bit for bit.
 static int eval_file(int fn, const char* in, const char* out) {
     FILE* f = fopen(in, "rb");
@@ -49,7 +50,11 @@ static int eval_file(int fn, const char* in, const char* out) {
         else if (fn == 3) r[0] = pb_asin_np(x[i]);
         else if (fn == 4) r[0] = pb_acos_np(x[i]);
         else if (fn == 5) r[0] = pb_atan_np(x[i]);
-        else r[0] = pb_tan_np(x[i]);
+        else if (fn == 6) r[0] = pb_tan_np(x[i]);
+        else if (fn == 7) r[0] = pb_sin_np(x[i]);
+        else if (fn == 8) r[0] = pb_cos_np(x[i]);
+        else if (fn == 9) { pb_expi_np(x[i], &r[0], &r[1]); k = 2; }
+        else { if (i & 1) continue; r[0] = (i + 1 < n) ? pb_arg_np(x[i], x[i + 1]) : 0.0; }
         fwrite(r, 8, k, g);
     }
     fclose(g);

@@ -104,7 +104,7 @@ __device__ __forceinline__ PbBilCoord pb_bil_coord_of(const PbParams& P, const P
         const double cx = (SRC_KIND == PB_KIND_EYE_R) ? P.src_cx_r : P.src_cx;
         const double dist = pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
         double sl, cl;
-        pb_sincos_cr(c.lon, &sl, &cl);  // np.exp(lon * 1j)
+        pb_expi_np(c.lon, &sl, &cl);  // np.exp(lon * 1j)
         f0 = ((sl * dist) * -1.0) + P.src_cy;
         f1 = (cl * dist) + cx;
         live = f0 == f0 && f1 == f1 && fabs(f0) < 1.0e9 && fabs(f1) < 1.0e9 && f0 >= 0.0 && f0 < (double)P.src.height && f1 >= 0.0 && f1 < (double)we;
@@ -639,7 +639,7 @@ __device__ __forceinline__ unsigned pb_bilinear_eye(const PbParams& P, const uin
     const int h = P.src.height, w = P.src.width;
     const double dist = pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
     double sl, cl;
-    pb_sincos_cr(lon, &sl, &cl);  // np.exp(lon * 1j)
+    pb_expi_np(lon, &sl, &cl);  // np.exp(lon * 1j)
     const double f0 = ((sl * dist) * -1.0) + P.src_cy, f1 = (cl * dist) + cx;
     const bool live = f0 == f0 && f1 == f1 && fabs(f0) < 1.0e9 && fabs(f1) < 1.0e9 && f0 >= 0.0 && f0 < (double)h && f1 >= 0.0 && f1 < (double)we;
     if (!live) return 0u;

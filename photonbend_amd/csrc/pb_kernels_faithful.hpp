@@ -231,7 +231,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_sample_map_kernel(const PbParams 
 // HOST for a Lens made of Python callables (lens.py:48-64); they replace the built-in forward lens.
 __device__ __forceinline__ bool pb_src_camera_pos_d(double dist, double lon, int h, int w, double cy, double cx, int& py, int& px) {
     double sl, cl;
-    pb_sincos_cr(lon, &sl, &cl);  // np.exp(lon * 1j)
+    pb_expi_np(lon, &sl, &cl);  // np.exp(lon * 1j)
     const double re = cl * dist, im = sl * dist;
     const long long y = pb_cvt_i64((im * -1.0) + cy);
     const long long x = pb_cvt_i64(re + cx);

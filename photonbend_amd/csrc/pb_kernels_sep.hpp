@@ -36,7 +36,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_sep_tables_kernel(const PbParams 
     if (j >= 0 && j < P.dst.width) {
         const PbCoord c = pb_dst_coord(P, 0, j);
         PbSepCol q;
-        pb_sincos_cr(c.lon, &q.sl, &q.cl);
+        pb_expi_np(c.lon, &q.sl, &q.cl);
         cols[j] = q;
     }
 }

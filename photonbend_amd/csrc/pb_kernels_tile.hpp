@@ -1107,7 +1107,7 @@ __global__ void pb_col_sincos_kernel(const PbParams P, double* __restrict__ col_
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.dst.width) return;
     const PbCoord c = pb_dst_coord(P, 0, j);
-    pb_sincos_cr(c.lon, &col_sc[2 * j + 1], &col_sc[2 * j]);
+    pb_expi_np(c.lon, &col_sc[2 * j + 1], &col_sc[2 * j]);
 }
 
 #ifndef PB_CERTIFY_WPE
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify
                         cl = col_sc[2 * j];
                         sl = col_sc[2 * j + 1];
                     } else {
-                        pb_sincos_cr(cc.lon, &sl, &cl);
+                        pb_expi_np(cc.lon, &sl, &cl);
                     }
                     exact = pb_src_index_sc<SRC_KIND>(P, cc, sl, cl);
                     pb_src_pretrunc_sc<SRC_KIND>(P, cc, sl, cl, f0, f1);

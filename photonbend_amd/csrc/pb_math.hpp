@@ -336,3 +336,4 @@ PB_MATH_FN double pb_atan2_cr(double y, double x) {
 }
 
 #include "pb_math_np.hpp"  // NumPy's own (SVML) arcsin / arccos / arctan / tan, bit for bit
+#include "pb_math_glibc.hpp"  // glibc 2.35's sin / cos / sincos / atan2 as NumPy reaches them, bit for bit

@@ -2,11 +2,13 @@
 // functions for ONE output pixel, in "faithful" float64: every IEEE-exact
 // operation (add, mul, div, sqrt, fma) is replayed in the reference's order with
 // contraction disabled (-ffp-contract=off), and the NumPy cast quirks are spelled out.
-// Transcendentals, each the function the reference's NumPy actually runs (primitive table):
-//   sin / cos / atan2 - glibc's (np.sin, np.cos, np.exp(1j x), np.log(complex).imag): the correctly rounded functions of pb_math.hpp
-//     (99.9 % bit-equal with glibc 2.35, which is itself correctly rounded on all but ~1 argument in 1000);
-//   asin / acos / atan / tan - NumPy's own AVX-512 kernels (np.arcsin, np.arccos, np.arctan, np.tan), 8-17 % away from correct
-//     rounding: restated operation for operation in pb_math_np.hpp, bit-equal with NumPy on every argument tested.
+// Transcendentals, each the very function the reference's NumPy runs on the machine that made the goldens (x86-64, FMA, AVX512_SKX,
+// glibc 2.35, NumPy 2.2.6; SURVEY 2, primitive table), restated operation for operation and bit-equal on every argument tested:
+//   np.sin, np.cos             glibc's sin / cos, `_fma` build                      pb_sin_np, pb_cos_np        (pb_math_glibc.hpp)
+//   np.exp(lon * 1j)           glibc's internal sincos, plain build                 pb_expi_np
+//   np.log(complex).imag       glibc's atan2, `_fma` build                          pb_arg_np
+//   np.arcsin / arccos / arctan / tan   NumPy's own AVX-512 kernels (Intel SVML)    pb_asin_np ... pb_tan_np    (pb_math_np.hpp)
+// None of these is correctly rounded (0.1 % to 17 % of their results are not), so nothing but their own algorithms returns their bits.
 //
 //   stage A  dst_coord()      pixel (i, j) -> (lat, lon, invalid)
 //            CameraImage._compute_latitude_longitude  projection.py:171-194
@@ -53,10 +55,10 @@ __device__ __forceinline__ int pb_floor_mod(long long a, int n) {
 __device__ __forceinline__ double pb_lens_forward(int lens, double theta, double rect_max) {
     switch (lens) {
         case PB_LENS_EQUIDISTANT: return theta;                          // lens.py:187
-        case PB_LENS_EQUISOLID: return 2.0 * pb_sin_cr(theta / 2.0);     // lens.py:240-243
+        case PB_LENS_EQUISOLID: return 2.0 * pb_sin_np(theta / 2.0);     // lens.py:240-243
         case PB_LENS_STEREOGRAPHIC: return 2.0 * pb_tan_np(theta / 2.0); // lens.py:142-145
-        case PB_LENS_ORTHOGRAPHIC: return pb_sin_cr(theta);              // lens.py:285
-        case PB_LENS_THOBY: return 1.47 * pb_sin_cr(0.713 * theta);      // lens.py:332-335
+        case PB_LENS_ORTHOGRAPHIC: return pb_sin_np(theta);              // lens.py:285
+        case PB_LENS_THOBY: return 1.47 * pb_sin_np(0.713 * theta);      // lens.py:332-335
         default: {                                                       // lens.py:97-103
             double t = pb_tan_np(theta);
             return (theta < 0.0 || theta > rect_max) ? __builtin_nan("") : t;
@@ -77,19 +79,9 @@ __device__ __forceinline__ double pb_lens_inverse(int lens, double r) {
     }
 }
 
-// atan2 as np.log(complex).imag gives it (glibc atan2): correctly rounded (pb_math.hpp).  That covers the
-// octant lines |x| == |y| and the axes, where the pre-truncation longitude coordinate of a pano source is an exact integer
-// (SURVEY 7 hard part 2) - they keep their shortcut only for speed.
-__device__ __forceinline__ double pb_atan2(double y, double x) {
-    const double ax = fabs(x), ay = fabs(y);
-    if (ax == ay && ax != 0.0 && ax < __builtin_inf()) {
-        const double q = 0.7853981633974483;   // pi/4 rounded
-        const double q3 = 2.356194490192345;   // 3*pi/4 rounded
-        double r = (x > 0.0) ? q : q3;
-        return (y < 0.0) ? -r : r;
-    }
-    return pb_atan2_cr(y, x);
-}
+// atan2 as np.log(complex).imag gives it (glibc's atan2), bit for bit (pb_math_glibc.hpp) - including the octant lines
+// |x| == |y| and the axes, where the pre-truncation longitude coordinate of a pano source is an exact integer (SURVEY 7 hard part 2).
+__device__ __forceinline__ double pb_atan2(double y, double x) { return pb_arg_np(y, x); }
 
 // ---- stage A ---------------------------------------------------------------------
 __device__ __forceinline__ PbCoord pb_dst_coord(const PbParams& P, int i, int j) {
@@ -229,8 +221,9 @@ __device__ __forceinline__ PbCoord pb_rotate(const double* __restrict__ R, PbCoo
         return c;
     }
     double s, yy, sl, cl;
-    pb_sincos_cr(c.lat, &s, &yy);   // np.cos(lat), np.sin(lat)   rotation.py:129-131
-    pb_sincos_cr(c.lon, &sl, &cl);  // np.exp(lon * 1j)
+    s = pb_sin_np(c.lat);           // np.sin(lat), np.cos(lat): two calls in the reference, two functions in libm   rotation.py:129-131
+    yy = pb_cos_np(c.lat);
+    pb_expi_np(c.lon, &sl, &cl);  // np.exp(lon * 1j)
     const double x = cl * s, z = sl * s;  // rotation.py:130-132
     // accumulation order of the BLAS behind np.matmul (probe)
     const double vx = fma(R[2], z, fma(R[0], x, R[1] * yy));
@@ -267,7 +260,7 @@ __device__ __forceinline__ bool pb_src_camera_pos(const PbParams& P, double lat,
                                                   double cx, int& py, int& px) {
     const double dist = pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
     double sl, cl;
-    pb_sincos_cr(lon, &sl, &cl);  // np.exp(lon * 1j)   projection.py:252
+    pb_expi_np(lon, &sl, &cl);  // np.exp(lon * 1j)   projection.py:252
     return pb_src_camera_pos_sc(dist, sl, cl, h, w, cy, cx, py, px);
 }
 
@@ -325,7 +318,7 @@ __device__ __forceinline__ PbDoubleTap pb_src_double_taps(const PbParams& P, con
     PbDoubleTap t;
     const double lat_r = (c.lat * -1.0) + PB_PI;  // projection.py:426-427
     double sl, cl;
-    pb_sincos_cr(c.lon, &sl, &cl);  // np.exp(lon * 1j): ONE evaluation serves both eyes (same argument, same bits)
+    pb_expi_np(c.lon, &sl, &cl);  // np.exp(lon * 1j): ONE evaluation serves both eyes (same argument, same bits)
     t.il = pb_src_index_sc<PB_KIND_EYE_L>(P, c, sl, cl);
     t.ir = pb_src_index_sc<PB_KIND_EYE_R>(P, c, sl, cl);
     t.fl = pb_merge_factor(P, c.lat);

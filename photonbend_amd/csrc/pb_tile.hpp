@@ -102,7 +102,7 @@ template <int SRC_KIND>
 __device__ __forceinline__ int pb_exact_index_of(const PbParams& P, const PbCoord& c) {
     if (SRC_KIND == PB_KIND_PANO) return pb_src_pano_index(P, c);
     double sl, cl;
-    pb_sincos_cr(c.lon, &sl, &cl);
+    pb_expi_np(c.lon, &sl, &cl);
     return pb_src_index_sc<SRC_KIND>(P, c, sl, cl);  // (one eye of a double frame: that eye alone)
 }
 template <int SRC_KIND>
