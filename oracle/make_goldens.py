@@ -443,26 +443,38 @@ def gen_full_bilinear():
 
 
 def gen_npmath():
-    """NumPy's own arcsin / arccos / arctan / tan (the functions the reference calls: rotation.py:158, lens.py:71-307) on the arguments of
-    tests/npmath_args.py: the RESULT BITS of this container's NumPy - the NumPy that produced every other golden - which
-    photonbend_amd/csrc/pb_math_np.hpp restates.  Scalars go through the same kernels as arrays (checked here), so one table per
-    function pins both uses."""
+    """The RESULT BITS of this container's NumPy - the NumPy that produced every other golden - for the transcendental calls the reference
+    makes (rotation.py:129-164, lens.py:71-335, projection.py:193, :252), on the arguments of tests/npmath_args.py: np.arcsin / arccos /
+    arctan / tan (NumPy's own AVX-512 kernels), np.sin / np.cos (glibc, `_fma` build), np.exp(x * 1j) (glibc's internal sincos, plain
+    build) and np.log(z).imag (glibc atan2).  photonbend_amd/csrc/pb_math_np.hpp and pb_math_glibc.hpp restate them.  Scalars, strided
+    views and short arrays go through the same kernels as whole arrays (checked here), so one table per function pins every use."""
     from tests import npmath_args
 
     try:
         from numpy._core._multiarray_umath import __cpu_features__ as feats
     except ImportError:
         from numpy.core._multiarray_umath import __cpu_features__ as feats
+    import ctypes
+
+    libc = ctypes.CDLL(None)
+    libc.gnu_get_libc_version.restype = ctypes.c_char_p
     arrays = {}
     for fn in npmath_args.FUNCTIONS:
         x = npmath_args.arguments(fn)
         with np.errstate(all="ignore"):
-            y = getattr(np, fn)(x)
-            for i in range(0, x.size, 997):  # scalar calls, strided views and short arrays take the same kernel
-                assert np.float64(getattr(np, fn)(float(x[i]))).tobytes() == y[i].tobytes()
-            assert getattr(np, fn)(x[::3]).tobytes() == y[::3].tobytes() and getattr(np, fn)(x[5:8]).tobytes() == y[5:8].tobytes()
-        arrays[fn] = y.view(np.uint64)
-    meta = {"numpy": np.__version__, "AVX512_SKX": bool(feats.get("AVX512_SKX")), "arguments": "tests/npmath_args.py", "n": int(npmath_args.N_PER_FUNCTION)}
+            y = npmath_args.reference(fn, x)
+            if fn not in ("expi", "arg"):
+                f = getattr(np, fn)
+                for i in range(0, x.size, 997):
+                    assert np.float64(f(float(x[i]))).tobytes() == y[i].tobytes()
+                assert f(x[::3]).tobytes() == y[::3].tobytes() and f(x[5:8]).tobytes() == y[5:8].tobytes()
+            elif fn == "expi":
+                assert npmath_args.reference(fn, x[7:10]).tobytes() == y[14:20].tobytes()
+            else:
+                assert npmath_args.reference(fn, x[14:20]).tobytes() == y[7:10].tobytes()
+        arrays[fn] = y
+    meta = {"numpy": np.__version__, "glibc": libc.gnu_get_libc_version().decode(), "AVX512_SKX": bool(feats.get("AVX512_SKX")),
+            "FMA3": bool(feats.get("FMA3")), "arguments": "tests/npmath_args.py", "n": int(npmath_args.N_PER_FUNCTION)}
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(GOLD, "npmath.npz"), **arrays)
     print("npmath.npz written:", meta)

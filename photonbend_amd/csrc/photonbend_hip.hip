@@ -1202,18 +1202,21 @@ int pb_index_map_i32(const pb_plan* plan, int32_t* idx_dev, double* weights_dev,
 __global__ void pb_debug_math_kernel(int fn, const double* __restrict__ in, double* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (fn == 0) pb_sincos_cr(in[i], &out[2 * i], &out[2 * i + 1]);
-    else if (fn == 1) out[i] = pb_atan2_cr(in[2 * i], in[2 * i + 1]);
-    else if (fn == 2) out[i] = pb_atan_cr(in[i]);
-    else if (fn == 3) out[i] = pb_asin_np(in[i]);
-    else if (fn == 4) out[i] = pb_acos_np(in[i]);
-    else if (fn == 5) out[i] = pb_atan_np(in[i]);
-    else out[i] = pb_tan_np(in[i]);
+    switch (fn) {
+        case 0: out[i] = pb_asin_np(in[i]); break;
+        case 1: out[i] = pb_acos_np(in[i]); break;
+        case 2: out[i] = pb_atan_np(in[i]); break;
+        case 3: out[i] = pb_tan_np(in[i]); break;
+        case 4: out[i] = pb_sin_np(in[i]); break;
+        case 5: out[i] = pb_cos_np(in[i]); break;
+        case 6: pb_expi_np(in[i], &out[2 * i], &out[2 * i + 1]); break;
+        default: out[i] = pb_arg_np(in[2 * i], in[2 * i + 1]);
+    }
 }
 extern "C" {
-// fn 0: n values -> (sin, cos) interleaved; 1: n (y, x) pairs -> atan2; 2: n values -> atan; 3..6: NumPy's asin, acos, atan, tan
+// fn (the order of tests/npmath_args.py FUNCTIONS): 0 arcsin, 1 arccos, 2 arctan, 3 tan, 4 sin, 5 cos of n values; 6: np.exp(x * 1j) -> (imag, real) interleaved; 7: n (y, x) pairs -> np.log(x + 1j y).imag
 __attribute__((visibility("default"))) int pb_debug_math(int fn, const double* in_dev, double* out_dev, size_t n, void* stream) {
-    if (!in_dev || !out_dev || fn < 0 || fn > 6) return pb_fail(PB_ERR_INVALID, "bad argument");
+    if (!in_dev || !out_dev || fn < 0 || fn > 7) return pb_fail(PB_ERR_INVALID, "bad argument");
     if (n) hipLaunchKernelGGL(pb_debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, in_dev, out_dev, n);
     PB_HIP(hipGetLastError());
     return PB_OK;

@@ -6,7 +6,8 @@ values, both signs, and the special values."""
 
 import numpy as np
 
-FUNCTIONS = ("arcsin", "arccos", "arctan", "tan")
+FUNCTIONS = ("arcsin", "arccos", "arctan", "tan", "sin", "cos", "expi", "arg")
+# "expi": np.exp(x * 1j) -> (imag, real) interleaved; "arg": np.log(x + 1j * y).imag of consecutive (y, x) pairs
 N_PER_FUNCTION = 40_000
 
 
@@ -60,6 +61,38 @@ def arguments(fn: str) -> np.ndarray:
             (2.0 * _unit(q, s + 6) - 1.0) * _pow2(q, s + 7, -300, 0),
             (1.0 + _unit(q, s + 8)) * _pow2(q, s + 9, 0, 300) * _signs(q, s + 10),      # large
         ]
+    elif fn in ("sin", "cos", "expi"):
+        # latitudes, longitudes and lens arguments; the branch points of glibc's sin / cos (2^-26, 0.126, 0.855469, 2.426265) and the
+        # multiples of pi / 2 its reduction lands next to; up to the end of its Cody-Waite range (105 414 350)
+        special = np.array([0.0, -0.0, 0.126, -0.126, 0.855469, 2.426265, np.pi, np.pi / 2, -np.pi / 2, 2 * np.pi, 2.0 ** -26, 2.0 ** -27, np.nextafter(2.0 ** -26, 0),
+                            5e-324, 1e-310, 105414349.0, -105414349.0, 1.0, -1.0, 100.0])
+        parts = [
+            (2.0 * _unit(4 * q, s + 1) - 1.0) * np.pi,
+            _unit(q, s + 2) * np.pi * 0.713,
+            (np.floor(_unit(q, s + 3) * 16.0) - 8.0) * (np.pi / 2) + (2.0 * _unit(q, s + 4) - 1.0) * _pow2(q, s + 5, -50, -2),
+            (2.0 * _unit(q, s + 6) - 1.0) * _pow2(q, s + 7, -300, 0),
+            (2.0 * _unit(q, s + 8) - 1.0) * _pow2(q, s + 9, 0, 26),
+        ]
+    elif fn == "arg":
+        # (y, x) pairs: the pixel-centre half-integers of a destination map, unit vectors after a rotation (any quadrant), extreme ratios
+        # (|y / x| beyond 2^+-57), the octant lines and axes, scaled-tiny and scaled-huge pairs, the special values
+        m = n // 2
+        q = m // 8
+        sp = [(0.0, 1.0), (-0.0, 1.0), (0.0, -1.0), (-0.0, -1.0), (0.0, 0.0), (-0.0, 0.0), (0.0, -0.0), (-0.0, -0.0), (1.0, 0.0), (-1.0, 0.0), (1.0, -0.0),
+              (np.inf, np.inf), (-np.inf, np.inf), (np.inf, -np.inf), (-np.inf, -np.inf), (1.0, np.inf), (-1.0, -np.inf), (np.inf, 1.0), (1.0, 1.0), (1.0, -1.0),
+              (-1.0, -1.0), (-1.0, 1.0), (0.0625, 1.0), (1.0, 0.0625), (1e-300, 1e-300), (1e300, -1e300), (1e-200, 1e200), (1e200, 1e-200), (-1e200, -1e-200), (np.nan, 1.0)]
+        half = lambda k, sd: np.floor(_unit(k, sd) * 8192.0) - 4096.0 + 0.5
+        ang_y, ang_x = 2.0 * _unit(2 * q, s + 3) - 1.0, 2.0 * _unit(2 * q, s + 4) - 1.0
+        ys = [half(3 * q, s + 1), ang_y * _unit(2 * q, s + 5), (2.0 * _unit(q, s + 6) - 1.0) * _pow2(q, s + 7, -70, 70), (2.0 * _unit(q, s + 9) - 1.0) * _pow2(q, s + 10, -1000, 1000),
+              np.floor(_unit(q, s + 13) * 64.0) - 32.0]
+        xs = [half(3 * q, s + 2), ang_x * _unit(2 * q, s + 5), 2.0 * _unit(q, s + 8) - 1.0, (2.0 * _unit(q, s + 11) - 1.0) * _pow2(q, s + 12, -1000, 1000),
+              np.floor(_unit(q, s + 14) * 64.0) - 32.0]
+        y, x = np.concatenate(ys), np.concatenate(xs)
+        sp = np.array(sp)
+        y = np.concatenate([y[: m - len(sp)], sp[:, 0]])
+        x = np.concatenate([x[: m - len(sp)], sp[:, 1]])
+        assert y.size == x.size == m
+        return np.ascontiguousarray(np.stack([y, x], axis=1).ravel(), dtype=np.float64)
     else:
         special = np.array([0.0, -0.0, np.pi / 2, -np.pi / 2, np.pi, np.pi / 4, np.pi / 32, 3 * np.pi / 32, 5e-324, 1e-310, 65536.0, -65536.0,
                             np.nextafter(np.pi / 2, 0), np.nextafter(np.pi / 2, 4), 1.0, -1.0, 0.5, 100.0, 3.0, np.nan])
@@ -74,3 +107,16 @@ def arguments(fn: str) -> np.ndarray:
     x = np.concatenate([x[: n - special.size], special])
     assert x.size == n
     return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def reference(fn: str, x: np.ndarray) -> np.ndarray:
+    """The result BITS (uint64) of the NumPy expression `fn` stands for, as the reference writes it."""
+    if fn == "expi":
+        e = np.exp(x * 1j)  # rotation.py:130, projection.py:252
+        return np.ascontiguousarray(np.stack([e.imag, e.real], axis=1).ravel()).view(np.uint64)
+    if fn == "arg":
+        yx = x.reshape(-1, 2)
+        z = np.empty(yx.shape[0], dtype=np.complex128)  # make_complex (utils/__init__.py): real and imaginary parts set apart
+        z.real, z.imag = yx[:, 1], yx[:, 0]
+        return np.ascontiguousarray(np.log(z).imag).view(np.uint64)
+    return np.ascontiguousarray(getattr(np, fn)(x)).view(np.uint64)

@@ -68,8 +68,6 @@ def test_cli_matches_reference_cli(case, tmp_path):
     assert got.shape == gold.shape and got.dtype == gold.dtype  # RGBA stays RGBA: nothing is converted
     d = np.abs(got.astype(np.int16) - gold.astype(np.int16))
     d = np.minimum(d, 256 - d)
-    if "double" in " ".join(opts) and cmd != "make-photo":
-        # double-fisheye SOURCE: float64 blend, last-bit latitude differences may move a channel by 1 LSB
-        assert int((d > 1).sum()) == 0 and int((d > 0).any(axis=2).sum()) <= max(2, d.shape[0] * d.shape[1] // 2000)
-    else:
-        assert int((d > 0).sum()) == 0, f"{int((d > 0).any(axis=2).sum())} pixels differ from the reference CLI"
+    # (round 4: the device chain runs the reference's own libm / NumPy kernels bit for bit, so the float64 blend of a double-fisheye
+    # source lands on the reference's bytes too - no 1-LSB allowance any more)
+    assert int((d > 0).sum()) == 0, f"{int((d > 0).any(axis=2).sum())} pixels differ from the reference CLI"

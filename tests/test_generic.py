@@ -63,15 +63,10 @@ def test_generic_case_matches_reference(name, case, layout):
     img = synth_image(h, w, layout, frame=3, circle_mask=case.mask)
     got = run_case(case, img)
     assert isinstance(got, np.ndarray) and got.shape == want.shape and got.dtype == want.dtype, (got.shape, got.dtype, want.shape, want.dtype)
-    if case.src[0] == "double":
-        # float64 blend: a last-bit latitude difference may move a channel by 1 LSB (wraps mod 256 like the reference's cast)
-        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
-        d = np.minimum(d, 256 - d)
-        px = d.reshape(d.shape[0], d.shape[1], -1)
-        assert int((d > 1).sum()) == 0 and int((px > 0).any(axis=2).sum()) <= max(2, d.shape[0] * d.shape[1] // 500), name
-    else:
-        bad = int((got != want).reshape(got.shape[0], got.shape[1], -1).any(axis=2).sum())
-        assert bad == 0, f"{name}: {bad} pixels differ from the reference"
+    # every case, double-fisheye sources and their float64 blend included: the reference's bytes (round 4: the chain's transcendentals
+    # are the reference's own, bit for bit)
+    bad = int((got != want).reshape(got.shape[0], got.shape[1], -1).any(axis=2).sum())
+    assert bad == 0, f"{name}: {bad} pixels differ from the reference"
     # the same image as a CUDA tensor stays on the device and gives the same pixels
     if layout in ("RGBA", "L", "RGB"):
         t = torch.from_numpy(img).cuda()
