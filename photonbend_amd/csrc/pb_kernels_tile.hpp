@@ -1110,8 +1110,8 @@ __global__ void pb_col_sincos_kernel(const PbParams P, double* __restrict__ col_
     pb_expi_np(c.lon, &col_sc[2 * j + 1], &col_sc[2 * j]);
 }
 
-#ifndef PB_CERTIFY_WPE
-#define PB_CERTIFY_WPE 1
+#ifndef PB_CERTIFY_WPE  // three waves per SIMD (168 VGPRs, 36-148 bytes of scratch) beat the compiler's free choice (216 VGPRs, two waves) by 9-20 %
+#define PB_CERTIFY_WPE 3  // on every config, and four (128 VGPRs, 170-280 bytes) on c2: experiments/README.md, round 4
 #endif
 #ifndef PB_CERTIFY_UNROLL
 #define PB_CERTIFY_UNROLL 0
