@@ -178,3 +178,29 @@ def test_numpy_and_glibc_functions_are_restated_bit_for_bit(fn, tmp_path):
     with np.errstate(all="ignore"):
         bad = differing(run(y), npmath_args.reference(fn, y))
     assert bad.size == 0, f"{fn}: {bad.size} of a million fresh results differ from this machine's NumPy"
+
+
+def test_this_hosts_numpy_against_the_goldens_numpy(capsys):
+    """Reports whether THIS host's NumPy / libm reproduce the result bits of golden/npmath.npz - i.e. whether live-oracle comparisons on
+    this host are bit-exact comparisons with the goldens' platform (tests/helpers.py).  Where the host matches the fixture's recorded
+    platform (NumPy version, glibc version, AVX512_SKX, FMA3) it MUST reproduce it; elsewhere the outcome is only reported."""
+    import ctypes
+    import json
+
+    try:
+        from numpy._core._multiarray_umath import __cpu_features__ as feats
+    except ImportError:
+        from numpy.core._multiarray_umath import __cpu_features__ as feats
+    meta = json.loads(bytes(np.load(os.path.join(H.GOLD, "npmath.npz"))["meta"]).decode())
+    libc = ctypes.CDLL(None)
+    try:
+        libc.gnu_get_libc_version.restype = ctypes.c_char_p
+        glibc = libc.gnu_get_libc_version().decode()
+    except AttributeError:
+        glibc = "?"
+    here = {"numpy": np.__version__, "glibc": glibc, "AVX512_SKX": bool(feats.get("AVX512_SKX")), "FMA3": bool(feats.get("FMA3"))}
+    same = H.live_numpy_is_the_goldens_numpy()
+    with capsys.disabled():
+        print(f"\n[npmath] this host {here}; fixture {({k: meta[k] for k in here})}; live NumPy reproduces the fixture: {same}", end="")
+    if all(here[k] == meta[k] for k in here):
+        assert same, "same NumPy, glibc and CPU features as the fixture's platform, but different result bits"
