@@ -16,8 +16,10 @@
 #include <cstdlib>
 #include <ctime>
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -113,6 +115,66 @@ static int pb_fail(int code, const std::string& msg) {
             return pb_fail(PB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
     } while (0)
 
+// Small device buffers that live for a few launches of plan preparation (counters, per-unit costs, a column table): a hipFree costs ~35 us
+// on this stack (it synchronises the device) and a plan used to make nine - a third of a millisecond of a 1.3 ms preparation
+// (experiments/r4/plan_api.sh).  They come from a per-device cache instead: a freed block is kept (up to 32 MiB in blocks of up to 4 MiB)
+// and handed to the next request it fits.  Safe because every user works on the NULL stream, which orders a block's next kernel behind its
+// last one device-wide, and because each site releases its block only after a synchronising copy or hipDeviceSynchronize.
+namespace {
+struct PbTmpCache {
+    struct Block { int device; size_t bytes; void* ptr; };
+    std::mutex lock;
+    std::vector<Block> idle;
+    std::unordered_map<void*, std::pair<int, size_t>> live;
+    size_t held = 0;
+} g_tmp;
+}  // namespace
+static hipError_t pb_tmp_alloc(void** out, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> g(g_tmp.lock);
+        size_t best = g_tmp.idle.size();
+        for (size_t k = 0; k < g_tmp.idle.size(); ++k) {
+            const PbTmpCache::Block& b = g_tmp.idle[k];
+            if (b.device == device && b.bytes >= bytes && b.bytes <= 4 * bytes + 4096 && (best == g_tmp.idle.size() || b.bytes < g_tmp.idle[best].bytes)) best = k;
+        }
+        if (best != g_tmp.idle.size()) {
+            const PbTmpCache::Block b = g_tmp.idle[best];
+            g_tmp.idle.erase(g_tmp.idle.begin() + (long)best);
+            g_tmp.held -= b.bytes;
+            g_tmp.live[b.ptr] = {b.device, b.bytes};
+            *out = b.ptr;
+            return hipSuccess;
+        }
+    }
+    e = hipMalloc(out, bytes);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> g(g_tmp.lock);
+        g_tmp.live[*out] = {device, bytes};
+    }
+    return e;
+}
+static void pb_tmp_free(void* ptr) {
+    if (!ptr) return;
+    {
+        std::lock_guard<std::mutex> g(g_tmp.lock);
+        const auto it = g_tmp.live.find(ptr);
+        if (it != g_tmp.live.end()) {
+            const std::pair<int, size_t> info = it->second;
+            g_tmp.live.erase(it);
+            if (info.second <= ((size_t)4 << 20) && g_tmp.held + info.second <= ((size_t)32 << 20)) {
+                g_tmp.idle.push_back({info.first, info.second, ptr});
+                g_tmp.held += info.second;
+                return;
+            }
+        }
+    }
+    (void)hipFree(ptr);
+}
+
 // ----------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------
@@ -193,16 +255,18 @@ static int pb_build_bilinear_list(pb_plan* pl) {
     pl->bil_tiles = nullptr;
     pl->bil_xy = pl->bil_fix_xy = nullptr;
     pl->n_bil_tiles = pl->n_bil_slots = 0;
-    PB_HIP(hipMalloc((void**)&cnt, 2 * sizeof(unsigned)));
-    hipError_t e = hipMemset(cnt, 0, 2 * sizeof(unsigned));
+    PB_HIP(pb_tmp_alloc((void**)&cnt, 2 * sizeof(unsigned)));
+    hipError_t e = hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned), 0);
     if (e == hipSuccess) e = hipMalloc((void**)&pl->bil_tiles, (size_t)(pl->n_tiles ? pl->n_tiles : 1) * sizeof(int32_t));
     unsigned res[2] = {0u, 0u};
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pb_bilinear_tile_list_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->table_r, pl->n_tiles, P.src_eye_w,
                            P.src.width, pl->bil_tiles, cnt);
         e = hipMemcpy(res, cnt, sizeof(res), hipMemcpyDeviceToHost);
+    } else {
+        (void)hipDeviceSynchronize();
     }
-    (void)hipFree(cnt);
+    pb_tmp_free(cnt);
     const bool dbl = pl->table_r != nullptr;
     // the tables: sources the 1/4096-px fixed point holds, and at most 1 GiB of coordinates (a geometry the models mostly cannot
     // follow keeps the float64 pass)
@@ -253,7 +317,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
     PbParams& P = pl->P;
     long long* scratch = nullptr;
     PB_HIP(hipGetDevice(&pl->device));
-    PB_HIP(hipMalloc((void**)&scratch, 16 * sizeof(long long)));
+    PB_HIP(pb_tmp_alloc((void**)&scratch, 16 * sizeof(long long)));
     int rc = PB_OK;
     do {
         if (P.dst.kind != PB_KIND_PANO) {
@@ -352,14 +416,14 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters);
         } else {
             double* col_sc = nullptr;  // (unrotated panorama destination: one sine / cosine per column instead of one per pixel)
-            if (P.dst.kind == PB_KIND_PANO && P.n_rot == 0 && hipMalloc((void**)&col_sc, (size_t)P.dst.width * 2 * sizeof(double)) == hipSuccess)
+            if (P.dst.kind == PB_KIND_PANO && P.n_rot == 0 && pb_tmp_alloc((void**)&col_sc, (size_t)P.dst.width * 2 * sizeof(double)) == hipSuccess)
                 hipLaunchKernelGGL(pb_col_sincos_kernel, dim3((P.dst.width + 255) / 256), dim3(256), 0, 0, P, col_sc);
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters, (const double*)col_sc);
             if (col_sc) {
                 (void)hipDeviceSynchronize();
-                (void)hipFree(col_sc);
+                pb_tmp_free(col_sc);
             }
         }
         hipLaunchKernelGGL(pb_count_flags_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, 0, pl->table, ntiles, counters);
@@ -401,7 +465,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         pl->table_r = nullptr; pl->lat_tab = nullptr; pl->sep_ready = 0; pl->dbl_ready = 0;
         pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr; pl->sep_rows = nullptr; pl->sep_cols = nullptr;
     }
-    (void)hipFree(scratch);
+    (void)hipDeviceSynchronize();  // (preparation is synchronous; the scratch block goes back to the cache idle)
+    pb_tmp_free(scratch);
     return rc;
 }
 
@@ -529,7 +594,7 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
         if (walk != 1 && sgy >= 4 && (ns >= 128u || walk != 0)) {  // (fewer than 16 super-tiles per XCD: too coarse to reorder - a 3072x2048 output measured 3-4 % slower)
             std::vector<unsigned> fixed(ns, 0u);
             unsigned* cost_dev = nullptr;
-            if (hipMalloc((void**)&cost_dev, ns * sizeof(unsigned)) != hipSuccess) {
+            if (pb_tmp_alloc((void**)&cost_dev, ns * sizeof(unsigned)) != hipSuccess) {
                 (void)hipFree(out_table);  // (the old table may be classified under another budget)
                 out_table = nullptr;
                 out_groups = 0;
@@ -539,7 +604,8 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
             hipLaunchKernelGGL(pb_unit_cost_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->n_tiles, tiles_x, 2u * U, sgx, cost_dev,
                                pl->dbl_ready ? pl->table_r : nullptr, 2u * UY, bil ? 1 : 0);
             const hipError_t ce = hipMemcpy(fixed.data(), cost_dev, ns * sizeof(unsigned), hipMemcpyDeviceToHost);
-            (void)hipFree(cost_dev);
+            if (ce != hipSuccess) (void)hipDeviceSynchronize();
+            pb_tmp_free(cost_dev);
             if (ce != hipSuccess) {
                 (void)hipFree(out_table);
                 out_table = nullptr;
@@ -640,7 +706,7 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
     int* unit_dev = nullptr;
     hipError_t e = (!bil && pb_test_alloc_fails()) ? hipErrorOutOfMemory : hipMalloc((void**)&fresh, (size_t)n_slots * sizeof(PbTileEntry));  // (the test hook counts the nearest mode's tables)
     if (e == hipSuccess && units) {
-        e = hipMalloc((void**)&unit_dev, unit_of.size() * sizeof(int));
+        e = pb_tmp_alloc((void**)&unit_dev, unit_of.size() * sizeof(int));
         if (e == hipSuccess) e = hipMemcpy(unit_dev, unit_of.data(), unit_of.size() * sizeof(int), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) {
@@ -648,7 +714,7 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
                            pl->dbl_ready ? pl->table_r : nullptr, (int)UY);
         e = hipDeviceSynchronize();
     }
-    (void)hipFree(unit_dev);
+    pb_tmp_free(unit_dev);
     if (e != hipSuccess) {
         (void)hipFree(fresh);
         (void)hipGetLastError();
@@ -672,7 +738,7 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
         }
     }
     unsigned* counters = nullptr;
-    PB_HIP(hipMalloc((void**)&counters, 4 * sizeof(unsigned)));
+    PB_HIP(pb_tmp_alloc((void**)&counters, 4 * sizeof(unsigned)));
     (void)hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
     if (pl->dbl_ready)
         hipLaunchKernelGGL(pb_budget_double_kernel, g, b, 0, 0, pl->table, pl->table_r, pl->saved_l, pl->saved_r, nt, budget, counters);
@@ -680,7 +746,8 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
         hipLaunchKernelGGL(pb_budget_kernel, g, b, 0, 0, pl->table, pl->saved_l, nt, budget, counters);
     unsigned res[4] = {0, 0, 0, 0};
     const hipError_t e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
-    (void)hipFree(counters);
+    if (e != hipSuccess) (void)hipDeviceSynchronize();
+    pb_tmp_free(counters);
     PB_HIP(e);
     counts[0] = res[0];
     counts[1] = res[1];
