@@ -220,7 +220,10 @@ int pb_shard_range(int n_items, int n_ranks, int rank, int* first, int* count);
 int pb_remap_batch_sharded(const pb_comm* comm, const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames_total,
                            size_t src_frame_stride, size_t dst_frame_stride, int* first_out, int* count_out, void* stream);
 
-/* ---- materialised coordinate-map API (protocol compatibility) --------- */
+/* ---- materialised coordinate-map API (protocol compatibility) ---------
+ * The float64 values are the reference's BITS as computed on x86-64 with FMA and AVX512_SKX, glibc 2.35, NumPy 2.2.6 (the platform of
+ * tests/golden/): the device runs that platform's sin / cos / sincos / atan2 and NumPy's arcsin / arccos / arctan / tan restated bit
+ * for bit (csrc/pb_math_glibc.hpp, csrc/pb_math_np.hpp); the same functions define every index map and remap. */
 int pb_coordmap_f64(const pb_proj* dst, double* map_dev, void* stream);
 /* Zeroes lat/lon of invalid pixels IN map_in_dev (rotation.py:119-125), like the
  * reference; map_out_dev must not alias map_in_dev. */
