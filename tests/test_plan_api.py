@@ -204,6 +204,37 @@ def test_two_threads_remap_same_sized_images_without_sharing_staging():
     assert len(res) == 24 and all(res.values())
 
 
+@pytest.mark.gpu
+def test_threads_preparing_plans_at_once_share_the_scratch_cache_safely():
+    """Round 4: the short-lived device buffers of plan preparation (counters, per-unit costs, column tables) come from a per-device cache
+    shared by every thread.  Four threads prepare plans of four geometries over and over at the same time; every plan's index map must
+    equal the one a single thread built, and its certification statistics too."""
+    fov = pb.utils.to_radians(190)
+    geoms = []
+    for k, (h, w) in enumerate([(256, 256), (320, 288), (288, 352), (384, 384)]):
+        d = pb.CameraImage(np.zeros((h, w, 3), np.uint8), fov, pb.equidistant())._proj("dst")
+        s = nat.make_proj(nat.KIND_PANO, 256 + 32 * k, 512 + 64 * k)
+        rots = [] if k % 2 == 0 else [pb.Rotation(0.1 * k, -0.2, 0.05).rotation_matrix]
+        geoms.append((d, rots, s))
+    serial = []
+    for d, rots, s in geoms:
+        p = nat.Plan(d, rots, s)
+        serial.append((p.index_map().cpu().numpy(), p.info()["fix_pixels"], p.info()["lean_tiles"]))
+    ok = {}
+
+    def worker(k):
+        d, rots, s = geoms[k]
+        for rep in range(8):
+            p = nat.Plan(d, rots, s)
+            info = p.info()
+            ok[(k, rep)] = np.array_equal(p.index_map().cpu().numpy(), serial[k][0]) and (info["fix_pixels"], info["lean_tiles"]) == serial[k][1:]
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert len(ok) == 32 and all(ok.values()), [k for k, v in ok.items() if not v]
+
+
 _FAIL_SCRIPT = r"""
 import sys, numpy as np, torch
 from photonbend_amd import _native as nat
