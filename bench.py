@@ -269,11 +269,15 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
     batch = batch or cfg["batch"]
     d, rots, s = build_projs(cfg)
     budget = BENCH_BUDGET[name]
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    plan = nat.Plan(d, rots, s, budget=budget)
-    torch.cuda.synchronize(device)
-    plan_ms = (time.perf_counter() - t0) * 1e3
+    plan_times, plan = [], None
+    for _ in range(3):  # the first preparation of a geometry KIND in a process also pays its kernels' first launches; "warm" = the best of three
+        plan = None  # (the previous plan's ~20 hipFree calls stay outside the timed region)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        plan = nat.Plan(d, rots, s, budget=budget)
+        torch.cuda.synchronize(device)
+        plan_times.append((time.perf_counter() - t0) * 1e3)
+    plan_ms = min(plan_times)
     sh, sw, dh, dw = s.height, s.width, d.height, d.width
     sbytes, dbytes = 3 * sh * sw, 3 * dh * dw
     pool = max(2 * batch, (pool_bytes or POOL_BYTES_MIN) // (sbytes + dbytes) + 1)
@@ -362,6 +366,7 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
         "attainable_frac": round(alg / must, 4),
         "traffic_bytes_per_frame": traffic,
         "plan_create_warm_ms": round(plan_ms, 3),
+        "plan_create_first_ms": round(plan_times[0], 3),
         "tiles": {k: info[k] for k in ("tiles", "lean_tiles", "direct_tiles", "black_tiles", "fix_tiles")},
         "window_budget": info["window_budget"],
         "launches_timed": n_groups * every,
