@@ -333,7 +333,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             if (hipMalloc((void**)&pl->sep_rows, (size_t)P.dst.height * sizeof(PbSepRow)) != hipSuccess ||
                 hipMalloc((void**)&pl->sep_cols, (size_t)P.dst.width * sizeof(PbSepCol)) != hipSuccess) { rc = PB_ERR_HIP; break; }
             unsigned* bad = reinterpret_cast<unsigned*>(scratch + 4);
-            if (hipMemset(bad, 0, sizeof(unsigned)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            if (hipMemsetAsync(bad, 0, sizeof(unsigned), 0) != hipSuccess) { rc = PB_ERR_HIP; break; }
             hipLaunchKernelGGL(pb_sep_tables_kernel, dim3(pb_blocks((unsigned long long)P.dst.height + P.dst.width)), dim3(PB_BLOCK), 0, 0,
                                P, pl->sep_rows, pl->sep_cols);
             hipLaunchKernelGGL(pb_sep_check_kernel, dim3(pb_blocks((unsigned long long)P.dst.height * P.dst.width)), dim3(PB_BLOCK), 0,
@@ -353,7 +353,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                 hipMalloc((void**)&pl->fail_tiles, (size_t)2 * ntiles * sizeof(int32_t)) != hipSuccess ||
                 hipMalloc((void**)&pl->fix_px, (size_t)cap * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
             unsigned* counters = reinterpret_cast<unsigned*>(scratch + 4);
-            if (hipMemset(counters, 0, 12 * sizeof(unsigned)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            if (hipMemsetAsync(counters, 0, 12 * sizeof(unsigned), 0) != hipSuccess) { rc = PB_ERR_HIP; break; }
             const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
             // (unrotated panorama destination: the separable path's column table holds the sine / cosine of every column's longitude)
             const double* col_sc = (P.dst.kind == PB_KIND_PANO && P.n_rot == 0 && pl->sep_cols) ? reinterpret_cast<const double*>(pl->sep_cols) : nullptr;
@@ -408,7 +408,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             hipMalloc((void**)&pl->fail_tiles, (size_t)ntiles * sizeof(int32_t)) != hipSuccess ||
             hipMalloc((void**)&pl->fix_px, (size_t)cap * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
         unsigned* counters = reinterpret_cast<unsigned*>(scratch + 4);
-        if (hipMemset(counters, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+        if (hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), 0) != hipSuccess) { rc = PB_ERR_HIP; break; }
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
         if (P.src.kind == PB_KIND_PANO) {
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table);
