@@ -780,7 +780,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_do
                     wl = pb_merge_factor(P, t);
                     wr = pb_merge_factor(P, (t * -1.0) + PB_PI);
                 }
-                a[jr * 4 + k] = pb_sep_blend(al[jr * 4 + k], a[jr * 4 + k], wl, wr);
+                if (PB_BIL_ABL & 512) a[jr * 4 + k] ^= al[jr * 4 + k];  // no blend arithmetic
+                else a[jr * 4 + k] = pb_sep_blend(al[jr * 4 + k], a[jr * 4 + k], wl, wr);
             }
         }
     }
