@@ -204,3 +204,24 @@ def test_this_hosts_numpy_against_the_goldens_numpy(capsys):
         print(f"\n[npmath] this host {here}; fixture {({k: meta[k] for k in here})}; live NumPy reproduces the fixture: {same}", end="")
     if all(here[k] == meta[k] for k in here):
         assert same, "same NumPy, glibc and CPU features as the fixture's platform, but different result bits"
+
+
+@pytest.mark.parametrize("gen,out", [("gen_np_tables.py", "pb_np_tables.hpp"), ("gen_glibc_tables.py", "pb_glibc_tables.hpp")])
+def test_generated_math_tables_are_what_their_generators_write(gen, out):
+    """csrc/pb_np_tables.hpp (VRSQRT14PD / VRCP14PD as sampled from the CPU) and csrc/pb_glibc_tables.hpp (glibc 2.35's __sincostab and
+    cij, read out of libm.so.6 and checked entry by entry against 60-digit arithmetic) are committed generator output: on a machine that can
+    run the generator (AVX-512F; glibc 2.35) it must write the committed file byte for byte - on this CPU as on the one that wrote it."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "photonbend_amd", "csrc")
+    res = subprocess.run([sys.executable, os.path.join(csrc, gen)], capture_output=True, text=True, timeout=120)
+    if res.returncode != 0:
+        pytest.skip(f"{gen} cannot run here: {(res.stderr or res.stdout).strip().splitlines()[-1][:160]}")
+    want = open(os.path.join(csrc, out)).read()
+    got = res.stdout
+    if gen == "gen_np_tables.py":  # (the header names the CPU it was sampled on)
+        strip = lambda t: "\n".join(l for l in t.splitlines() if not l.startswith("// VRSQRT14PD / VRCP14PD sampled on"))
+        got, want = strip(got), strip(want)
+    assert got.strip() == want.strip(), f"{out} differs from what {gen} writes on this machine"
