@@ -725,7 +725,8 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
     return PB_OK;
 }
 
-// keeps the certified flags (once) and writes the flags under `budget` into the tile tables; counts = {LEAN, DIRECT} tiles.  Synchronous.
+// keeps the certified flags (once) and writes the flags under `budget` into the tile tables; counts = {LEAN, DIRECT} tiles (nullptr: not
+// wanted - then the call does not wait for the device).
 static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2]) {
     const unsigned nt = pl->n_tiles;
     const dim3 g((nt + 255) / 256), b(256);
@@ -744,6 +745,11 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
         hipLaunchKernelGGL(pb_budget_double_kernel, g, b, 0, 0, pl->table, pl->table_r, pl->saved_l, pl->saved_r, nt, budget, counters);
     else
         hipLaunchKernelGGL(pb_budget_kernel, g, b, 0, 0, pl->table, pl->saved_l, nt, budget, counters);
+    if (!counts) {  // (nobody reads the class counts of this pass: no round trip - the block's next user is ordered behind the kernel by the stream)
+        pb_tmp_free(counters);
+        PB_HIP(hipGetLastError());
+        return PB_OK;
+    }
     unsigned res[4] = {0, 0, 0, 0};
     const hipError_t e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
     if (e != hipSuccess) (void)hipDeviceSynchronize();
@@ -767,8 +773,7 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     pl->ltable_bil = nullptr;
     pl->launch_groups_bil = 0;
     pl->bil_budget = pb_clamp_budget(PB_BIL_WIN_BUDGET);
-    unsigned counts[2];
-    int rc = pb_classify_under_budget(pl, pl->bil_budget, counts);
+    int rc = pb_classify_under_budget(pl, pl->bil_budget, nullptr);
     if (rc == PB_OK) rc = pb_build_launch_table(pl, true);
     return rc;
 }
