@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../.."
 while [ $# -gt 1 ]; do
   tag=$1; defs=$2; shift 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden $defs photonbend_amd/csrc/photonbend_hip.hip -o experiments/r4/libpb_f_$tag.so -Rpass-analysis=kernel-resource-usage 2> /tmp/res_$tag.txt &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -disable-machine-licm -fPIC -shared -fvisibility=hidden $defs photonbend_amd/csrc/photonbend_hip.hip -o experiments/r4/libpb_f_$tag.so -Rpass-analysis=kernel-resource-usage 2> /tmp/res_$tag.txt &
 done
 wait
 for f in /tmp/res_*.txt; do echo "== $f"; python3 - "$f" <<'PY'

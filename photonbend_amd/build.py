@@ -16,11 +16,17 @@ LIB_PATH = os.environ.get("PB_LIB_PATH") or os.path.join(HERE, LIB_NAME)
 
 # -ffp-contract=off: the reference rounds every multiply and add separately; the
 # kernels fuse only where they say fma() (see csrc/pb_stages.hpp).
+# -mllvm -disable-machine-licm: the float64 kernels evaluate five table-and-polynomial transcendental kernels per pixel inside loops (16
+# pixels per lane in certification); hoisting those kernels' hundred-odd float64 constants out of the loops made certification need 212
+# VGPRs (two waves per SIMD) where 94 suffice (five): plan preparation c3 1.15 -> 1.02 ms, c5 1.52 -> 1.31.  The hot kernels keep their
+# register counts and their times with or without it (experiments/README.md, round 4).
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
     "-std=c++17",
     "-ffp-contract=off",
+    "-mllvm",
+    "-disable-machine-licm",
     "-fPIC",
     "-shared",
     "-fvisibility=hidden",

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_fix_kernel(const PbParam
         if (i >= P.dst.height || j >= P.dst.width) return;
     }
     PbCoord c = pb_dst_coord(P, i, j);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    c = pb_rotate_all(P, c);
     double f0, f1;
     pb_src_pretrunc<SRC_KIND>(P, c, f0, f1);
     bool live = !c.inv && f0 == f0 && f1 == f1 && fabs(f0) < 1.0e9 && fabs(f1) < 1.0e9;
@@ -667,7 +667,7 @@ __device__ __forceinline__ unsigned pb_bilinear_eye(const PbParams& P, const uin
 // one output pixel of the double-fisheye bilinear mode from the float64 chain (the mode's definition on the device)
 __device__ __forceinline__ unsigned pb_bilinear_double_px(const PbParams& P, int i, int j, const uint8_t* __restrict__ s) {
     PbCoord c = pb_dst_coord(P, i, j);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    c = pb_rotate_all(P, c);
     if (c.inv) return 0u;
     const double lat_r = (c.lat * -1.0) + PB_PI;  // projection.py:426-427
     const double fl = pb_merge_factor(P, c.lat), fr = pb_merge_factor(P, lat_r);
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_coord_kernel(const PbPar
     const int local = (blockIdx.x & 3) * 256 + threadIdx.x;
     const int i = min(ty * PB_TILE + (local >> 5), P.dst.height - 1), j = min(tx * PB_TILE + (local & 31), P.dst.width - 1);
     PbCoord c = pb_dst_coord(P, i, j);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    c = pb_rotate_all(P, c);
     bil_xy[(size_t)slot * (PB_TILE * PB_TILE) + local] = pb_bil_coord_of<SRC_KIND>(P, c);
 }
 // ... and the fix list's: out[item * stride + offset]
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_fix_coord_kernel(const P
     const unsigned p = (unsigned)fix_px[item];
     const int i = (int)(p / (unsigned)P.dst.width), j = (int)(p - (unsigned)i * (unsigned)P.dst.width);
     PbCoord c = pb_dst_coord(P, i, j);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    c = pb_rotate_all(P, c);
     out[(size_t)item * stride + offset] = pb_bil_coord_of<SRC_KIND>(P, c);
 }
 

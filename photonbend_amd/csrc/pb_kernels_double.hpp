@@ -503,7 +503,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_double_tables_kernel(const PbPara
         out = px_fix + item;
     }
     PbCoord c = pb_dst_coord(P, i, j);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    c = pb_rotate_all(P, c);
     const PbDoubleTap t = pb_src_double_taps(P, c);
     PbDoubleFix r;
     r.il = t.il;  // both -1 for an invalid destination pixel: black (final_image[invalid_map] = 0, projection.py:460)
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_double_pair_kernel(cons
         const int j = X0 + xh + k;
         if (i >= P.dst.height || j >= P.dst.width) continue;
         PbCoord c = pb_dst_coord(P, i, j);
-        for (int r = 0; r < P.n_rot; ++r) c = pb_rotate(P.R[r], c);
+        c = pb_rotate_all(P, c);
         // the blend factors are functions of the latitude alone (projection.py:439-457): no taps, no sine / cosine here (round 4: this
         // kernel used to evaluate both eyes' whole source stage per pixel for the sake of two numbers)
         const double t_fl = pb_merge_factor(P, c.lat), t_fr = pb_merge_factor(P, (c.lat * -1.0) + PB_PI);
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_double_lat_kernel(const
     for (int k = 0; k < 16; ++k) {
         const int i = min(ty * PB_TILE + y, P.dst.height - 1), j = min(tx * PB_TILE + xh + k, P.dst.width - 1);
         PbCoord c = pb_dst_coord(P, i, j);
-        for (int r = 0; r < P.n_rot; ++r) c = pb_rotate(P.R[r], c);
+        c = pb_rotate_all(P, c);
         lt[y * PB_TILE + xh + k] = c.lat;
     }
 }

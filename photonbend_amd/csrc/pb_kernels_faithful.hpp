@@ -14,10 +14,9 @@
 // ----------------------------------------------------------------------------------
 // kernels
 // ----------------------------------------------------------------------------------
+template <int ROT = PB_ROT_ANY>
 __device__ __forceinline__ PbCoord pb_chain(const PbParams& P, int i, int j) {
-    PbCoord c = pb_dst_coord(P, i, j);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
-    return c;
+    return pb_rotate_all<ROT>(P, pb_dst_coord(P, i, j));
 }
 
 __device__ __forceinline__ unsigned pb_load_px(const uint8_t* __restrict__ src, int idx) {
@@ -60,7 +59,7 @@ __device__ __forceinline__ void pb_store_px4(uint8_t* __restrict__ out, unsigned
 #endif
 #define PB_PRAGMA(x) _Pragma(#x)
 #define PB_UNROLL(n) PB_PRAGMA(unroll n)
-template <int SRC_KIND>
+template <int SRC_KIND, int ROT>
 __global__ __launch_bounds__(PB_BLOCK, PB_FAITHFUL_WPE(SRC_KIND)) void pb_remap_kernel(const PbParams P, const uint8_t* __restrict__ src,
                                                             uint8_t* __restrict__ dst, int n_frames,
                                                             unsigned long long src_stride,
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(PB_BLOCK, PB_FAITHFUL_WPE(SRC_KIND)) void pb_remap_
         fl[k] = fr[k] = 1.0;
         inv[k] = true;
         if (k < count) {
-            const PbCoord c = pb_chain(P, (int)i, (int)j);
+            const PbCoord c = pb_chain<ROT>(P, (int)i, (int)j);
             if (SRC_KIND == PB_KIND_PANO) {
                 idx[k] = pb_src_pano_index(P, c);
             } else if (SRC_KIND == PB_KIND_CAMERA) {
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(PB_BLOCK, PB_FAITHFUL_WPE(SRC_KIND)) void pb_remap_
     }
 }
 
-template <int SRC_KIND>
+template <int SRC_KIND, int ROT>
 __global__ __launch_bounds__(PB_BLOCK) void pb_index_kernel(const PbParams P, int32_t* __restrict__ out,
                                                             double* __restrict__ wout) {
     const unsigned total = (unsigned)P.dst.height * (unsigned)P.dst.width;
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_index_kernel(const PbParams P, in
     if (p >= total) return;
     const unsigned W = (unsigned)P.dst.width;
     const unsigned i = p / W, j = p - i * W;
-    const PbCoord c = pb_chain(P, (int)i, (int)j);
+    const PbCoord c = pb_chain<ROT>(P, (int)i, (int)j);
     if (SRC_KIND == PB_KIND_PANO) {
         out[p] = pb_src_pano_index(P, c);
     } else if (SRC_KIND == PB_KIND_CAMERA) {

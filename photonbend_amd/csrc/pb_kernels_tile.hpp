@@ -1110,8 +1110,8 @@ __global__ void pb_col_sincos_kernel(const PbParams P, double* __restrict__ col_
     pb_expi_np(c.lon, &col_sc[2 * j + 1], &col_sc[2 * j]);
 }
 
-#ifndef PB_CERTIFY_WPE  // three waves per SIMD (168 VGPRs, 36-148 bytes of scratch) beat the compiler's free choice (216 VGPRs, two waves) by 9-20 %
-#define PB_CERTIFY_WPE 3  // on every config, and four (128 VGPRs, 170-280 bytes) on c2: experiments/README.md, round 4
+#ifndef PB_CERTIFY_WPE  // (the compiler's free choice: 87-116 VGPRs, four or five waves per SIMD, now that the build keeps the math kernels'
+#define PB_CERTIFY_WPE 1  // constants out of long-lived registers - build.py; with them hoisted it was 212, and a forced 168 + scratch won 9-20 %)
 #endif
 #ifndef PB_CERTIFY_UNROLL
 #define PB_CERTIFY_UNROLL 0
@@ -1119,7 +1119,7 @@ __global__ void pb_col_sincos_kernel(const PbParams P, double* __restrict__ col_
 #ifndef PB_CERT_ABL  // timing experiments only (experiments/r4/build_f64.sh): 1 = no faithful chain, 2 = no column-first evaluation, 4 = no coarse measure
 #define PB_CERT_ABL 0
 #endif
-template <int SRC_KIND>
+template <int SRC_KIND, int ROT>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify_kernel(const PbParams P, PbTileEntry* __restrict__ table,
                                                                          int32_t* __restrict__ fail_tiles,
                                                                          int32_t* __restrict__ fix_px, unsigned fix_capacity,
@@ -1155,8 +1155,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify
                 const int fast = pb_model_px<SRC_KIND>(P, R, xh, k);
                 PbCoord cc = {0.0, 0.0, false};
                 if (!(PB_CERT_ABL & 1)) {
-                    cc = pb_dst_coord(P, i, j);
-                    for (int r = 0; r < P.n_rot; ++r) cc = pb_rotate(P.R[r], cc);
+                    cc = pb_rotate_all<ROT>(P, pb_dst_coord(P, i, j));
                 }
                 // the faithful index and the faithful pre-truncation coordinate from ONE evaluation of the longitude's sine / cosine
                 int exact;

@@ -93,7 +93,7 @@ __device__ __forceinline__ void pb_wave_sync() {
 template <int SRC_KIND>
 __device__ __forceinline__ void pb_chain_real(const PbParams& P, double fi, double fj, double& f0, double& f1) {
     PbCoord c = pb_dst_coord_real(P, fi, fj);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    c = pb_rotate_all(P, c);
     pb_src_pretrunc<SRC_KIND>(P, c, f0, f1);
 }
 
@@ -108,7 +108,7 @@ __device__ __forceinline__ int pb_exact_index_of(const PbParams& P, const PbCoor
 template <int SRC_KIND>
 __device__ __forceinline__ int pb_exact_index(const PbParams& P, int i, int j) {
     PbCoord c = pb_dst_coord(P, i, j);
-    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
+    c = pb_rotate_all(P, c);
     return pb_exact_index_of<SRC_KIND>(P, c);
 }
 

@@ -359,10 +359,10 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             const double* col_sc = (P.dst.kind == PB_KIND_PANO && P.n_rot == 0 && pl->sep_cols) ? reinterpret_cast<const double*>(pl->sep_cols) : nullptr;
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table);
-            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_EYE_L>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters, col_sc);
+            PB_LAUNCH_BY_ROT(P.n_rot, pb_certify_kernel, PB_KIND_EYE_L, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters, col_sc);
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r);
-            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_EYE_R>, grid, block, 0, 0, P, pl->table_r, pl->fail_tiles, pl->fix_px, cap, counters, col_sc);
+            PB_LAUNCH_BY_ROT(P.n_rot, pb_certify_kernel, PB_KIND_EYE_R, grid, block, 0, 0, P, pl->table_r, pl->fail_tiles, pl->fix_px, cap, counters, col_sc);
             hipLaunchKernelGGL(pb_count_flags_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, 0, pl->table, ntiles, counters);
             hipLaunchKernelGGL(pb_count_flags_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, 0, pl->table_r, ntiles, counters);
             const unsigned lat_capacity = ntiles < 65536u ? ntiles : 65536u;  // <= 512 MiB of latitudes
@@ -413,14 +413,14 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         if (P.src.kind == PB_KIND_PANO) {
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table);
-            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_PANO>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters);
+            PB_LAUNCH_BY_ROT(P.n_rot, pb_certify_kernel, PB_KIND_PANO, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters);
         } else {
             double* col_sc = nullptr;  // (unrotated panorama destination: one sine / cosine per column instead of one per pixel)
             if (P.dst.kind == PB_KIND_PANO && P.n_rot == 0 && pb_tmp_alloc((void**)&col_sc, (size_t)P.dst.width * 2 * sizeof(double)) == hipSuccess)
                 hipLaunchKernelGGL(pb_col_sincos_kernel, dim3((P.dst.width + 255) / 256), dim3(256), 0, 0, P, col_sc);
             hipLaunchKernelGGL(pb_model_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table);
             hipLaunchKernelGGL(pb_window_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table);
-            hipLaunchKernelGGL(pb_certify_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters, (const double*)col_sc);
+            PB_LAUNCH_BY_ROT(P.n_rot, pb_certify_kernel, PB_KIND_CAMERA, grid, block, 0, 0, P, pl->table, pl->fail_tiles, pl->fix_px, cap, counters, (const double*)col_sc);
             if (col_sc) {
                 (void)hipDeviceSynchronize();
                 pb_tmp_free(col_sc);
@@ -524,7 +524,7 @@ static void pb_launch_faithful_remap(const PbParams& P, const uint8_t* src, uint
                                      unsigned long long ds, hipStream_t st) {
     const unsigned long long npx = (unsigned long long)P.dst.height * P.dst.width;
     const int aligned = (((uintptr_t)dst | ds) & 3u) == 0;
-    hipLaunchKernelGGL(pb_remap_kernel<KIND>, dim3(pb_blocks((npx + PB_PX - 1) / PB_PX)), dim3(PB_BLOCK), 0, st, P, src, dst,
+    PB_LAUNCH_BY_ROT(P.n_rot, pb_remap_kernel, KIND, dim3(pb_blocks((npx + PB_PX - 1) / PB_PX)), dim3(PB_BLOCK), 0, st, P, src, dst,
                        n_frames, ss, ds, aligned);
 }
 
@@ -1259,11 +1259,11 @@ int pb_index_map_i32(const pb_plan* plan, int32_t* idx_dev, double* weights_dev,
     if (pb_use_fast(plan)) {
         pb_launch_fast<1>(plan, nullptr, nullptr, 0, 0, 0, idx_dev, st);
     } else if (P.src.kind == PB_KIND_PANO) {
-        hipLaunchKernelGGL(pb_index_kernel<PB_KIND_PANO>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, idx_dev, weights_dev);
+        PB_LAUNCH_BY_ROT(P.n_rot, pb_index_kernel, PB_KIND_PANO, dim3(blocks), dim3(PB_BLOCK), 0, st, P, idx_dev, weights_dev);
     } else if (P.src.kind == PB_KIND_CAMERA) {
-        hipLaunchKernelGGL(pb_index_kernel<PB_KIND_CAMERA>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, idx_dev, weights_dev);
+        PB_LAUNCH_BY_ROT(P.n_rot, pb_index_kernel, PB_KIND_CAMERA, dim3(blocks), dim3(PB_BLOCK), 0, st, P, idx_dev, weights_dev);
     } else {
-        hipLaunchKernelGGL(pb_index_kernel<PB_KIND_DOUBLE>, dim3(blocks), dim3(PB_BLOCK), 0, st, P, idx_dev, weights_dev);
+        PB_LAUNCH_BY_ROT(P.n_rot, pb_index_kernel, PB_KIND_DOUBLE, dim3(blocks), dim3(PB_BLOCK), 0, st, P, idx_dev, weights_dev);
     }
     PB_HIP(hipGetLastError());
     return PB_OK;
