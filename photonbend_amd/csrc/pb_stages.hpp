@@ -235,30 +235,17 @@ __device__ __forceinline__ PbCoord pb_rotate(const double* __restrict__ R, PbCoo
 }
 
 // The whole rotation chain of one pixel.  ROT = the number of rotations when the caller knows it at COMPILE time (0 or 1: what the
-// reference's CLI and nearly every caller use), PB_ROT_ANY otherwise.  Why the float64 kernels are instantiated per count: with the loop
-// `for (k < n_rot) c = pb_rotate(R[k], c)` inlined, the compiler hoists the loop body's invariants - the hundred-odd float64 constants of
-// five transcendental kernels - out of the loop and keeps them live across the caller: the float64 remap kernel needed 123 VGPRs (4 waves
-// per SIMD) where ~40 suffice and ran 20-25 % slower on EVERY geometry, rotated or not (round 4: c2 160 -> 130 us, c1 73 -> 55, c3 521 -> 429;
-// experiments/README.md).  PB_ROT_ANY inlines the first rotation and sends the second and later ones through a real call (82 VGPRs).
+// reference's CLI and nearly every caller use), PB_ROT_ANY otherwise.  History (round 4, experiments/README.md): the float64 remap kernel
+// needed 123 VGPRs (4 waves per SIMD) and ran 20-25 % slower on EVERY geometry, rotated or not, because the compiler's machine-level
+// loop-invariant code motion hoisted the hundred-odd float64 constants of the five transcendental kernels out of this loop (and out of
+// certification's pixel loop) and kept them live across the caller.  The build switches that pass off (build.py): 42-61 VGPRs with the
+// plain loop.  Instantiating the three float64 kernels per count on top of that is worth another 3-4 % on unrotated geometries.
 #define PB_ROT_ANY (-1)
-__device__ __attribute__((noinline)) void pb_rotate_link(double r0, double r1, double r2, double r3, double r4, double r5, double r6, double r7, double r8,
-                                                         double* lat, double* lon, bool inv) {
-    const double R[9] = {r0, r1, r2, r3, r4, r5, r6, r7, r8};
-    const PbCoord c = pb_rotate(R, PbCoord{*lat, *lon, inv});
-    *lat = c.lat;
-    *lon = c.lon;
-}
 template <int ROT = PB_ROT_ANY>
 __device__ __forceinline__ PbCoord pb_rotate_all(const PbParams& P, PbCoord c) {
     if (ROT == 0) return c;
     if (ROT == 1) return pb_rotate(P.R[0], c);
-    if (P.n_rot > 0) {
-        c = pb_rotate(P.R[0], c);
-        for (int k = 1; k < P.n_rot; ++k) {
-            const double* __restrict__ R = P.R[k];
-            pb_rotate_link(R[0], R[1], R[2], R[3], R[4], R[5], R[6], R[7], R[8], &c.lat, &c.lon, c.inv);
-        }
-    }
+    for (int k = 0; k < P.n_rot; ++k) c = pb_rotate(P.R[k], c);
     return c;
 }
 // launches kernel<KIND, ROT> for the plan's rotation count
