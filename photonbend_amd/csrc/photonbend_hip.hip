@@ -46,8 +46,12 @@ struct pb_plan {
     int32_t* fix_idx = nullptr;  // ... and of the fix list's pixels: looked up per frame instead of recomputed
     unsigned n_tiles = 0, n_fail_tiles = 0, n_fix_px = 0, n_lean_tiles = 0, n_black_tiles = 0, n_direct_tiles = 0;
     long long diff_pixels = -1;  // pixels (outside failed tiles) where model and faithful index differed
-    // separable path (double source, unrotated pano destination): row / column tables
+    // separable path (double source, unrotated pano destination): row / column tables.  sep_ready: the tables exist (their row weights
+    // are exact by construction and serve the tile kernels); sep_checked: the exhaustive check of their TAPS against the faithful ones -
+    // 0 not run yet, 1 passed, -1 failed.  The check (one float64 chain per pixel: 0.27 ms of c5's 1.3 ms preparation) is only needed by
+    // pb_sep_double_kernel, the fallback for frames the windowed two-eye kernel cannot take, and runs when that fallback is first asked for.
     int sep_ready = 0;
+    mutable int sep_checked = 0;
     PbSepRow* sep_rows = nullptr;
     PbSepCol* sep_cols = nullptr;
     // double-fisheye source: one certified tile table per eye (pb_kernels_double.hpp); `table` is the left eye's
@@ -329,19 +333,13 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         }
         P.thresholds_ready = 1;
         if (P.src.kind == PB_KIND_DOUBLE && P.dst.kind == PB_KIND_PANO && P.n_rot == 0) {
-            // separable path: tables + exhaustive check against the faithful taps
+            // separable path: the row / column tables (their taps are checked against the faithful ones when first needed: pb_sep_verified)
             if (hipMalloc((void**)&pl->sep_rows, (size_t)P.dst.height * sizeof(PbSepRow)) != hipSuccess ||
                 hipMalloc((void**)&pl->sep_cols, (size_t)P.dst.width * sizeof(PbSepCol)) != hipSuccess) { rc = PB_ERR_HIP; break; }
-            unsigned* bad = reinterpret_cast<unsigned*>(scratch + 4);
-            if (hipMemsetAsync(bad, 0, sizeof(unsigned), 0) != hipSuccess) { rc = PB_ERR_HIP; break; }
             hipLaunchKernelGGL(pb_sep_tables_kernel, dim3(pb_blocks((unsigned long long)P.dst.height + P.dst.width)), dim3(PB_BLOCK), 0, 0,
                                P, pl->sep_rows, pl->sep_cols);
-            hipLaunchKernelGGL(pb_sep_check_kernel, dim3(pb_blocks((unsigned long long)P.dst.height * P.dst.width)), dim3(PB_BLOCK), 0,
-                               0, P, pl->sep_rows, pl->sep_cols, bad);
-            unsigned nbad = 1;
-            if (hipMemcpy(&nbad, bad, sizeof(nbad), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
-            pl->sep_ready = nbad == 0;
-            pl->diff_pixels = nbad;
+            pl->sep_ready = 1;
+            pl->sep_checked = 0;
         }
         if (P.src.kind == PB_KIND_DOUBLE) {
             // two certified tile tables (one per eye) + the weight class of every tile
@@ -1109,6 +1107,33 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
 }
 }  // extern "C"
 
+// The separable tables' taps against the faithful chain, every pixel, once per plan and only when pb_sep_double_kernel is about to use
+// them (synchronous, default stream).  True when they may be used.
+static std::mutex g_sep_lock;
+static bool pb_sep_verified(const pb_plan* plan, hipStream_t st) {
+    if (!plan->sep_ready || !plan->sep_rows || !plan->sep_cols) return false;
+    std::lock_guard<std::mutex> g(g_sep_lock);
+    if (plan->sep_checked == 0) {
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;  // (a synchronous check has no place inside a stream capture: such a
+        if (st && hipStreamIsCapturing(st, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return false;  // launch takes the float64 kernel)
+        const PbParams& P = plan->P;
+        unsigned* bad = nullptr;
+        unsigned nbad = 1;
+        if (pb_tmp_alloc((void**)&bad, sizeof(unsigned)) == hipSuccess) {
+            (void)hipMemsetAsync(bad, 0, sizeof(unsigned), 0);
+            hipLaunchKernelGGL(pb_sep_check_kernel, dim3(pb_blocks((unsigned long long)P.dst.height * P.dst.width)), dim3(PB_BLOCK), 0, 0, P, plan->sep_rows,
+                               plan->sep_cols, bad);
+            if (hipMemcpy(&nbad, bad, sizeof(nbad), hipMemcpyDeviceToHost) != hipSuccess) {
+                nbad = 1;
+                (void)hipDeviceSynchronize();
+            }
+            pb_tmp_free(bad);
+        }
+        plan->sep_checked = nbad == 0 ? 1 : -1;
+    }
+    return plan->sep_checked == 1;
+}
+
 static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames, size_t src_frame_stride,
                            size_t dst_frame_stride, hipStream_t st) {
     const PbParams& P = plan->P;
@@ -1137,7 +1162,7 @@ static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t*
         else if (one) PB_LAUNCH_DOUBLE(0, true);
         else PB_LAUNCH_DOUBLE(0, false);
 #undef PB_LAUNCH_DOUBLE
-    } else if (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL) {
+    } else if (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL && pb_sep_verified(plan, st)) {
         hipLaunchKernelGGL(pb_sep_double_kernel, dim3(pb_hot_blocks(P)), dim3(64 * PB_TILE_WAVES), 0, st, P, plan->sep_rows, plan->sep_cols,
                            src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
     } else if (pb_use_fast(plan)) {
