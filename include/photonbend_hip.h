@@ -171,7 +171,10 @@ int pb_plan_matches(const pb_plan* plan, const pb_proj* dst, const double* rot3x
  * the frames of a batch are a dimension of the grid, so the launch ramp and drain are paid once per call
  * (measured on MI355X: 8 frames per call run 1.3x faster per frame than 8 calls).  Asynchronous on `stream`;
  * never allocates or synchronises (graph-capture safe).  A deferred plan (PB_PLAN_DEFER, not yet prepared) runs
- * the faithful float64 kernel. */
+ * the faithful float64 kernel.  (A double-fisheye -> unrotated panorama plan keeps a second, separable fast path for frames the windowed
+ * kernel cannot take - source pointer or stride not a multiple of 16 bytes, PB_MODE_FAST_DIRECT; its tables are verified against the
+ * float64 chain by a kernel the FIRST such launch enqueues on `stream`: that launch, launches inside a stream capture, and any launch
+ * issued before the verification has finished run the float64 kernel instead - same bytes, slower.) */
 int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames,
                 size_t src_frame_stride, size_t dst_frame_stride, void* stream);
 

@@ -48,10 +48,14 @@ struct pb_plan {
     long long diff_pixels = -1;  // pixels (outside failed tiles) where model and faithful index differed
     // separable path (double source, unrotated pano destination): row / column tables.  sep_ready: the tables exist (their row weights
     // are exact by construction and serve the tile kernels); sep_checked: the exhaustive check of their TAPS against the faithful ones -
-    // 0 not run yet, 1 passed, -1 failed.  The check (one float64 chain per pixel: 0.27 ms of c5's 1.3 ms preparation) is only needed by
-    // pb_sep_double_kernel, the fallback for frames the windowed two-eye kernel cannot take, and runs when that fallback is first asked for.
+    // 0 not started, 2 in flight, 1 passed, -1 failed.  The check (one float64 chain per pixel: 0.27 ms of c5's 1.3 ms preparation) is only
+    // needed by pb_sep_double_kernel, the fallback for frames the windowed two-eye kernel cannot take; the first launch that wants the
+    // fallback ENQUEUES it (pb_sep_usable: no allocation, no synchronisation - the launch functions' contract) and takes the float64 kernel,
+    // later launches take the fallback once the check has been seen to pass.
     int sep_ready = 0;
     mutable int sep_checked = 0;
+    int sep_slot = -1;               // this plan's word of the process's pinned result page (pb_sep_setup)
+    hipEvent_t sep_event = nullptr;  // recorded behind the check
     PbSepRow* sep_rows = nullptr;
     PbSepCol* sep_cols = nullptr;
     // double-fisheye source: one certified tile table per eye (pb_kernels_double.hpp); `table` is the left eye's
@@ -177,6 +181,73 @@ static void pb_tmp_free(void* ptr) {
         }
     }
     (void)hipFree(ptr);
+}
+
+static inline unsigned pb_blocks(unsigned long long items);
+// The separable tables' taps against the faithful chain, every pixel, once per plan: enqueued by the first launch that wants
+// pb_sep_double_kernel, its verdict read - without waiting - by the launches after it.  The verdict lands in a word of a page of pinned,
+// device-mapped host memory the process allocates once (the check kernel counts mismatches straight into it).
+namespace {
+struct PbSepPage {
+    std::mutex lock;
+    unsigned* host = nullptr;  // 1024 words
+    unsigned* dev = nullptr;
+    std::vector<int> idle;
+} g_sep;
+}  // namespace
+// plan preparation / deserialisation: a result word and an event for the plan (failure = the fallback stays unverified, i.e. unused)
+static void pb_sep_setup(pb_plan* pl) {
+    if (!pl->sep_ready || pl->sep_slot >= 0) return;
+    std::lock_guard<std::mutex> g(g_sep.lock);
+    if (!g_sep.host) {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 1024 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess) return;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            (void)hipHostFree(h);
+            return;
+        }
+        g_sep.host = (unsigned*)h;
+        g_sep.dev = (unsigned*)d;
+        for (int k = 1023; k >= 0; --k) g_sep.idle.push_back(k);
+    }
+    if (g_sep.idle.empty()) return;
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
+    pl->sep_slot = g_sep.idle.back();
+    g_sep.idle.pop_back();
+    pl->sep_event = ev;
+    pl->sep_checked = 0;
+}
+static void pb_sep_release(pb_plan* pl) {
+    std::lock_guard<std::mutex> g(g_sep.lock);
+    if (pl->sep_event) {
+        (void)hipEventSynchronize(pl->sep_event);  // (a check still in flight writes its word: the slot must not be handed on before)
+        (void)hipEventDestroy(pl->sep_event);
+    }
+    if (pl->sep_slot >= 0) g_sep.idle.push_back(pl->sep_slot);
+    pl->sep_event = nullptr;
+    pl->sep_slot = -1;
+}
+// launch path: may pb_sep_double_kernel run?  Never waits, never allocates.
+static bool pb_sep_usable(const pb_plan* plan, hipStream_t st) {
+    if (!plan->sep_ready || plan->sep_slot < 0 || !plan->sep_event || !plan->sep_rows || !plan->sep_cols) return false;
+    std::lock_guard<std::mutex> g(g_sep.lock);
+    if (plan->sep_checked == 1) return true;
+    if (plan->sep_checked == -1) return false;
+    if (plan->sep_checked == 2) {
+        if (hipEventQuery(plan->sep_event) != hipSuccess) return false;  // still running (or the query failed): not yet
+        plan->sep_checked = g_sep.host[plan->sep_slot] == 0u ? 1 : -1;
+        return plan->sep_checked == 1;
+    }
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;  // (an event recorded inside a capture could not be queried afterwards)
+    if (st && hipStreamIsCapturing(st, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return false;
+    const PbParams& P = plan->P;
+    g_sep.host[plan->sep_slot] = 0u;
+    hipLaunchKernelGGL(pb_sep_check_kernel, dim3(pb_blocks((unsigned long long)P.dst.height * P.dst.width)), dim3(PB_BLOCK), 0, st, P, plan->sep_rows,
+                       plan->sep_cols, g_sep.dev + plan->sep_slot);
+    if (hipEventRecord(plan->sep_event, st) == hipSuccess) plan->sep_checked = 2;
+    return false;
 }
 
 // ----------------------------------------------------------------------------------
@@ -340,6 +411,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                                P, pl->sep_rows, pl->sep_cols);
             pl->sep_ready = 1;
             pl->sep_checked = 0;
+            pb_sep_setup(pl);
         }
         if (P.src.kind == PB_KIND_DOUBLE) {
             // two certified tile tables (one per eye) + the weight class of every tile
@@ -460,6 +532,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         (void)hipFree(pl->dbl_tile_fix); (void)hipFree(pl->dbl_px_fix); (void)hipFree(pl->bil_tiles); (void)hipFree(pl->bil_xy); (void)hipFree(pl->bil_fix_xy);
         pl->dbl_tile_fix = nullptr; pl->dbl_px_fix = nullptr; pl->bil_tiles = nullptr; pl->n_bil_tiles = 0;
         pl->bil_xy = pl->bil_fix_xy = nullptr; pl->n_bil_slots = 0;
+        pb_sep_release(pl);
         pl->table_r = nullptr; pl->lat_tab = nullptr; pl->sep_ready = 0; pl->dbl_ready = 0;
         pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr; pl->sep_rows = nullptr; pl->sep_cols = nullptr;
     }
@@ -1048,6 +1121,7 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->fix_px);
     (void)hipFree(plan->idx_tab);
     (void)hipFree(plan->fix_idx);
+    pb_sep_release(plan);
     (void)hipFree(plan->sep_rows);
     (void)hipFree(plan->sep_cols);
     (void)hipFree(plan->table_r);
@@ -1107,33 +1181,6 @@ int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, i
 }
 }  // extern "C"
 
-// The separable tables' taps against the faithful chain, every pixel, once per plan and only when pb_sep_double_kernel is about to use
-// them (synchronous, default stream).  True when they may be used.
-static std::mutex g_sep_lock;
-static bool pb_sep_verified(const pb_plan* plan, hipStream_t st) {
-    if (!plan->sep_ready || !plan->sep_rows || !plan->sep_cols) return false;
-    std::lock_guard<std::mutex> g(g_sep_lock);
-    if (plan->sep_checked == 0) {
-        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;  // (a synchronous check has no place inside a stream capture: such a
-        if (st && hipStreamIsCapturing(st, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return false;  // launch takes the float64 kernel)
-        const PbParams& P = plan->P;
-        unsigned* bad = nullptr;
-        unsigned nbad = 1;
-        if (pb_tmp_alloc((void**)&bad, sizeof(unsigned)) == hipSuccess) {
-            (void)hipMemsetAsync(bad, 0, sizeof(unsigned), 0);
-            hipLaunchKernelGGL(pb_sep_check_kernel, dim3(pb_blocks((unsigned long long)P.dst.height * P.dst.width)), dim3(PB_BLOCK), 0, 0, P, plan->sep_rows,
-                               plan->sep_cols, bad);
-            if (hipMemcpy(&nbad, bad, sizeof(nbad), hipMemcpyDeviceToHost) != hipSuccess) {
-                nbad = 1;
-                (void)hipDeviceSynchronize();
-            }
-            pb_tmp_free(bad);
-        }
-        plan->sep_checked = nbad == 0 ? 1 : -1;
-    }
-    return plan->sep_checked == 1;
-}
-
 static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames, size_t src_frame_stride,
                            size_t dst_frame_stride, hipStream_t st) {
     const PbParams& P = plan->P;
@@ -1162,7 +1209,7 @@ static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t*
         else if (one) PB_LAUNCH_DOUBLE(0, true);
         else PB_LAUNCH_DOUBLE(0, false);
 #undef PB_LAUNCH_DOUBLE
-    } else if (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL && pb_sep_verified(plan, st)) {
+    } else if (plan->sep_ready && plan->mode != PB_MODE_FAITHFUL && pb_sep_usable(plan, st)) {
         hipLaunchKernelGGL(pb_sep_double_kernel, dim3(pb_hot_blocks(P)), dim3(64 * PB_TILE_WAVES), 0, st, P, plan->sep_rows, plan->sep_cols,
                            src_dev, dst_dev, n_frames, src_frame_stride, dst_frame_stride);
     } else if (pb_use_fast(plan)) {
@@ -1642,6 +1689,7 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
     if (!pl) return pb_fail(PB_ERR_INVALID, "out of host memory");
     memcpy(&pl->P, in + sizeof(PbBlobHeader), sizeof(PbParams));
     pl->fast_ready = h.fast_ready; pl->sep_ready = h.sep_ready; pl->dbl_ready = h.dbl_ready;
+    pb_sep_setup(pl);
     pl->walk = (h.reserved >= 0 && h.reserved <= 3) ? h.reserved : 0;
     pl->n_tiles = h.n_tiles; pl->n_fail_tiles = h.n_fail_tiles; pl->n_fix_px = h.n_fix_px; pl->n_lean_tiles = h.n_lean_tiles;
     pl->n_black_tiles = h.n_black_tiles; pl->n_direct_tiles = h.n_direct_tiles; pl->n_row_weight_tiles = h.n_row_weight_tiles;

@@ -184,3 +184,42 @@ def test_taps_of_the_hot_double_kernel_mid_size(case):
         pytest.skip("the windowed kernel needs 16-byte aligned frames")
     n_checked, _ = _check_taps(plan, h, w)
     assert n_checked > 0
+
+
+def test_separable_fallback_is_verified_behind_the_first_launch_and_launches_capture_into_a_graph():
+    """Round 4: the exhaustive check of a stitch plan's separable tables no longer runs at plan creation.  The first launch that wants the
+    separable kernel (here: PB_MODE_FAST_DIRECT) enqueues the check and runs the float64 kernel; once the check has passed, later
+    launches take the separable kernel - every launch returns the same bytes.  No launch allocates or synchronises, so launches capture
+    into a graph: inside a capture an unverified plan simply takes the float64 kernel."""
+    case = Case("stitch_195_lazy", pano(256, 512), dbl(240, 480, "equidistant", 195), mask=2)
+    frames = _frames(case, 2)
+    ref_plan = H.pb_plan(case)
+    ref_plan.set_mode(nat.MODE_FAITHFUL)
+    want = ref_plan.remap(frames).clone()
+    # (a) a fresh plan, captured before anything verified its tables: the graph holds the float64 kernel
+    plan = H.pb_plan(case)
+    plan.set_mode(nat.MODE_FAST_DIRECT)
+    out = torch.zeros_like(want)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        plan.remap(frames, out)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    # (b) eager launches: the first enqueues the check, the ones after a synchronisation run the separable kernel
+    for rep in range(3):
+        got = plan.remap(frames)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), rep
+    # (c) the default mode, captured and replayed: the windowed two-eye kernel
+    plan.set_mode(nat.MODE_AUTO)
+    out.zero_()
+    graph2 = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(graph2, stream=side):
+        plan.remap(frames, out)
+    graph2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
