@@ -2,7 +2,7 @@
 # round-4 profiles: rocprofv3 kernel stats + FETCH_SIZE / WRITE_SIZE passes (separate, kernel-trace only) per config at the budget bench.py
 # pins for it - the nearest (reference) sampler AND the opt-in bilinear mode.  Summaries land in gpurun_out/prof_r4/;
 # experiments/make_traffic_r4.py turns them into profiles/r04_* and profiles/traffic_<config>_<budget>.json.
-# usage: profile_r4.sh [nearest|bilinear|both]
+# usage: profile_r4.sh [nearest|bilinear|both] [config ...]
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r4; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 run() {  # tag, bench args...
@@ -16,10 +16,11 @@ run() {  # tag, bench args...
   echo "== $tag"; head -3 $O/${tag}_kernel_stats.csv | cut -c1-150
   rm -rf $O/raw_${tag}_*
 }
-what=${1:-both}
+what=${1:-both}; shift
+near=${@:-c2 c1 c3 c5 c4shard c5shard}; bil=${@:-c2 c1 c3 c5}   # optional: the configs to run
 if [ $what != bilinear ]; then
-  for c in c2 c1 c3 c5 c4shard c5shard; do run $c --config $c || exit 1; done
+  for c in $near; do run $c --config $c || exit 1; done
 fi
 if [ $what != nearest ]; then
-  for c in c2 c1 c3 c5; do run ${c}_bilinear --config $c --sampling bilinear || exit 1; done
+  for c in $bil; do run ${c}_bilinear --config $c --sampling bilinear || exit 1; done
 fi
