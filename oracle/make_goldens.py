@@ -480,6 +480,32 @@ def gen_npmath():
     print("npmath.npz written:", meta)
 
 
+def canonical_map_sha(m):
+    """SHA-256 of a float64 coordinate map's bits with every NaN replaced by the one canonical quiet NaN (payloads and signs of NaNs are
+    not part of any contract; signed zeros and everything else are)."""
+    a = np.ascontiguousarray(m, dtype=np.float64).copy()
+    a[np.isnan(a)] = np.float64("nan")
+    return sha(a.view(np.uint64))
+
+
+def gen_map_pins():
+    """f-1 at the sizes that matter: the SHA-256 of the reference's float64 coordinate map after get_coordinate_map and after every rotation
+    (latitude, longitude and invalid-flag planes, NaNs canonicalised), for the 13 mid cases (every lens, both directions, rotations, 0.5-2 K)
+    and the five BASELINE geometries at full size (16.8-33.5 M pixels each) - added to mid.json / full.json under "map_sha256"."""
+    for fname, cases in (("mid.json", mid_cases()), ("full.json", full_cases())):
+        path = os.path.join(GOLD, fname)
+        pins = json.load(open(path))
+        for case in cases:
+            _, _, stages, _ = ref_map(case)
+            pins[case.name]["map_sha256"] = [canonical_map_sha(st) for st in stages]
+            pins[case.name]["map_shape"] = list(stages[0].shape)
+            print(f"  {case.name}: {len(stages)} stage(s) of {stages[0].shape}")
+            del stages
+        with open(path, "w") as f:
+            json.dump(pins, f, indent=1)
+    print("mid.json / full.json updated (map_sha256)")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--lens", action="store_true")
@@ -493,8 +519,9 @@ if __name__ == "__main__":
     ap.add_argument("--mid", action="store_true")
     ap.add_argument("--generic", action="store_true")
     ap.add_argument("--npmath", action="store_true", help="NumPy's arcsin / arccos / arctan / tan result bits (tests/golden/npmath.npz)")
+    ap.add_argument("--maps", action="store_true", help="only add the float64 map hashes of the mid and full cases to mid.json / full.json")
     a = ap.parse_args()
-    everything = not (a.full_bilinear or a.full_raw or a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic or a.npmath)
+    everything = not (a.full_bilinear or a.full_raw or a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic or a.npmath or a.maps)
     os.makedirs(GOLD, exist_ok=True)
     if a.lens or everything:
         gen_lens()
@@ -518,3 +545,5 @@ if __name__ == "__main__":
         gen_real()
     if a.npmath or everything:
         gen_npmath()
+    if a.maps or a.mid or a.full or everything:
+        gen_map_pins()

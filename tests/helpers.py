@@ -41,6 +41,27 @@ def live_numpy_is_the_goldens_numpy() -> bool:
     return _LIVE_IS_GOLDEN
 
 
+def canonical_map_sha(m) -> str:
+    """SHA-256 of a float64 coordinate map's bits with every NaN replaced by the canonical quiet NaN (oracle/make_goldens.py does the same
+    to the reference's maps): signed zeros, flags and every finite bit count, NaN payloads do not."""
+    import hashlib
+
+    a = np.ascontiguousarray(m, dtype=np.float64).copy()
+    a[np.isnan(a)] = np.float64("nan")
+    return hashlib.sha256(a.view(np.uint64).tobytes()).hexdigest()
+
+
+def pb_map_stages(case: Case):
+    """The package's materialised float64 maps of a case: after get_coordinate_map and after each rotation (host copies, one at a time)."""
+    import photonbend_amd as pb
+
+    cmap = pb_obj(case.dst).get_coordinate_map()
+    yield np.array(np.asarray(cmap))
+    for rot in case.rotations:
+        cmap = pb.Rotation(*map(pb.utils.to_radians, rot)).rotate_coordinate_map(cmap)
+        yield np.array(np.asarray(cmap))
+
+
 def load_small():
     return np.load(os.path.join(GOLD, "small.npz"))
 

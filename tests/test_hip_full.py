@@ -98,3 +98,17 @@ def test_full_size_identity_pano_roundtrip():
     out = plan.remap(frame).reshape(-1, 3)
     assert int((idx < 0).sum()) == 0
     assert torch.equal(out, frame.reshape(-1, 3)[idx])
+
+
+@pytest.mark.parametrize("name", sorted(FULL))
+def test_materialised_maps_are_the_references_bits_at_full_size(name):
+    """f-1 at the BASELINE sizes: pb_coordmap_f64 / pb_rotate_f64 over 8.4-33.5 M pixels - latitude, longitude and invalid-flag planes - hash
+    to the reference's maps (full.json: map_sha256; NaNs canonicalised), stage by stage."""
+    case = next(c for c in full_cases() if c.name == name)
+    want = FULL[name]["map_sha256"]
+    k = -1
+    for k, m in enumerate(H.pb_map_stages(case)):
+        assert list(m.shape) == FULL[name]["map_shape"]
+        assert H.canonical_map_sha(m) == want[k], f"{name}: the float64 map of stage {k} differs from the reference's"
+        del m
+    assert k + 1 == len(want)

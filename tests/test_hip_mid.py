@@ -122,3 +122,15 @@ def test_identity_and_near_identity_differ_only_inside_the_fragile_set(case, cap
         a, b = got_map[diff].astype(np.int64), want[diff].astype(np.int64)
         ok = (a < 0) | (b < 0) | (np.abs(a // ws - b // ws) <= 1) & ((np.abs(a % ws - b % ws) <= 1) | (np.abs(a % ws - b % ws) == ws - 1))
         assert bool(ok.all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", mid_cases(), ids=lambda c: c.name)
+def test_materialised_maps_are_the_references_bits_at_mid_size(case):
+    """f-1 at 0.5-2 K sizes, every lens, both directions, with rotations: the float64 coordinate map after get_coordinate_map and after
+    every rotation hashes to the reference's (mid.json: map_sha256, captured from the real reference; NaNs canonicalised)."""
+    want = MID[case.name]["map_sha256"]
+    got = [H.canonical_map_sha(m) for m in H.pb_map_stages(case)]
+    assert len(got) == len(want)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g == w, f"{case.name}: the float64 map of stage {k} differs from the reference's"
