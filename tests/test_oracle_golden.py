@@ -225,3 +225,34 @@ def test_generated_math_tables_are_what_their_generators_write(gen, out):
         strip = lambda t: "\n".join(l for l in t.splitlines() if not l.startswith("// VRSQRT14PD / VRCP14PD sampled on"))
         got, want = strip(got), strip(want)
     assert got.strip() == want.strip(), f"{out} differs from what {gen} writes on this machine"
+
+
+def test_restated_math_is_clean_under_the_sanitizers(tmp_path):
+    """The host build of csrc/pb_math.hpp under AddressSanitizer + UndefinedBehaviorSanitizer (GPU sanitizers are not available on this pool:
+    the CPU build is where table indices, shifts and conversions get checked): the whole fixture plus infinities, huge, tiny and
+    out-of-domain arguments through all eight functions, no finding, same bits as the plain build."""
+    import shutil
+    import subprocess
+
+    from tests import npmath_args
+
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_math_san")
+    res = subprocess.run([gxx, "-O1", "-g", "-ffp-contract=off", "-mfma", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+                          os.path.join(root, "oracle", "check_math.cpp")], capture_output=True, text=True)
+    if res.returncode != 0:
+        pytest.skip("no sanitizer runtime here: " + res.stderr.strip()[-160:])
+    gold = np.load(os.path.join(root, "tests", "golden", "npmath.npz"))
+    wild = np.array([np.inf, -np.inf, 1e308, -1e308, 1.7e308, 5e-324, -5e-324, 2.0 ** 1023, 1e9, 65537.0, 1.05e8, np.nan, 0.0, -0.0])
+    src, dst = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    for code, fn in enumerate(npmath_args.FUNCTIONS):
+        x = np.concatenate([npmath_args.arguments(fn), wild])
+        x.tofile(src)
+        run = subprocess.run([exe, str(code), src, dst], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0 and not run.stderr.strip(), f"{fn}: {run.stderr[-600:]}"
+        got, want = np.fromfile(dst, dtype=np.uint64)[: gold[fn].size], gold[fn]
+        both_nan = np.isnan(got.view(np.float64)) & np.isnan(want.view(np.float64))
+        assert bool(((got == want) | both_nan).all()), fn
