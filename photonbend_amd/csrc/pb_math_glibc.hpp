@@ -1,4 +1,5 @@
 // pb_math_glibc.hpp - the sin, cos, sincos and atan2 the reference's NumPy reaches in glibc 2.35, bit for bit, for the FAITHFUL chain.
+// SPDX-License-Identifier: LGPL-2.1-or-later  (restates GNU C Library code: IBM Accurate Mathematical Library; see NOTICE)
 //
 // Which call reaches what (checked against NumPy 2.2.6 itself on 10^7 arguments each, oracle/make_goldens.py --npmath):
 //   np.sin(x), np.cos(x)        libm's sin / cos through their ifunc: on a machine with FMA the `_fma` build of

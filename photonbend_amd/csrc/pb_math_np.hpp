@@ -1,4 +1,5 @@
 // pb_math_np.hpp - NumPy's float64 arcsin, arccos, arctan and tan, bit for bit, for the FAITHFUL float64 chain.
+// SPDX-License-Identifier: BSD-3-Clause  (restates Intel SVML kernels as vendored by NumPy; see NOTICE)
 //
 // Why: the reference calls np.arccos (rotation.py:158), np.arcsin (lens.py:210, :261, :307), np.arctan (lens.py:71, :122) and np.tan
 // (lens.py:95, :101, :143).  On an AVX512_SKX machine NumPy 2.2.6 does not reach libm for these: its loops
