@@ -36,7 +36,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define PB_ABI_VERSION 4
+#define PB_ABI_VERSION 5
 #define PB_MAX_ROTATIONS 8
 
 typedef enum pb_status {
@@ -177,6 +177,15 @@ int pb_plan_matches(const pb_plan* plan, const pb_proj* dst, const double* rot3x
  * issued before the verification has finished run the float64 kernel instead - same bytes, slower.) */
 int pb_remap_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames,
                 size_t src_frame_stride, size_t dst_frame_stride, void* stream);
+
+/* The same batch launch for frames that are NOT at a uniform stride - a ring of separately allocated buffers (ABI 5).
+ * src_dev / dst_dev are HOST arrays of n_frames DEVICE pointers (tightly packed frames); frame f is read at src_dev[f] and
+ * written at dst_dev[f].  ONE kernel launch per 64 frames on `stream`: the pointers travel in the kernel-argument segment
+ * (read at launch: the arrays may be reused when the call returns), so the call stays allocation- and synchronisation-free
+ * (graph-capture safe) like pb_remap_u8, whose bytes it reproduces.  Frames the windowed kernels cannot take (a source
+ * pointer not 16-byte aligned), deferred plans and PB_MODE_FAITHFUL / PB_MODE_FAST_DIRECT run as n_frames single launches.
+ * Replaces: a host loop over process_coordinate_map() (core/__init__.py:66-92) on separately allocated arrays. */
+int pb_remap_u8v(const pb_plan* plan, const uint8_t* const* src_dev, uint8_t* const* dst_dev, int n_frames, void* stream);
 
 /* OPT-IN extension with no reference counterpart (the reference samples nearest-by-truncation only):
  * bilinear interpolation at the reference's pre-truncation coordinate (pixel k covers [k, k+1), centre

@@ -27,7 +27,7 @@ except ImportError:  # the NumPy workflow needs no torch
 from ._device import DeviceArray
 from .build import LIB_PATH
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PB_MAX_ROTATIONS = 8
 PLAN_DEFER, PLAN_TUNE = 1, 2
 MODE_AUTO, MODE_FAITHFUL, MODE_FAST, MODE_FAST_DIRECT = 0, 1, 2, 3
@@ -86,6 +86,7 @@ SIGNATURES = {
     "pb_plan_bilinear_float64_tiles": (C.c_int, [_VP]),
     "pb_plan_matches": (C.c_int, [_VP, C.POINTER(pb_proj), C.POINTER(C.c_double), C.c_int, C.POINTER(pb_proj)]),
     "pb_remap_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
+    "pb_remap_u8v": (C.c_int, [_VP, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, _VP]),
     "pb_remap_bilinear_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
     "pb_index_map_i32": (C.c_int, [_VP, _VP, _VP, _VP]),
     "pb_coordmap_f64": (C.c_int, [C.POINTER(pb_proj), _VP, _VP]),
@@ -394,6 +395,35 @@ class Plan:
         if out is not None:
             return out
         return o if batched else o[0]
+
+    def remap_each(self, srcs, outs=None, stream: int | None = None):
+        """A batch of SEPARATELY ALLOCATED frames (a ring of buffers) in one launch (``pb_remap_u8v``): srcs / outs are
+        sequences of uint8 device arrays (h, w, 3) / (H, W, 3); returns the list of outputs (allocated when ``outs`` is None).
+        Same bytes as one ``remap`` per frame, at the batch rate."""
+        require_gpu()
+        srcs = list(srcs)
+        n = len(srcs)
+        if n == 0:
+            return []
+        for s in srcs:
+            u8 = is_device_array(s) and ((s.dtype == torch.uint8) if is_tensor(s) else (s.dtype == np.uint8))
+            if not u8 or tuple(s.shape) != (self.src.height, self.src.width, 3) or (is_tensor(s) and not s.is_contiguous()):
+                raise PbError(f"source frames must be contiguous uint8 device arrays ({self.src.height}, {self.src.width}, 3)")
+        if outs is None:
+            outs = [empty((self.dst.height, self.dst.width, 3), np.uint8, like=srcs[0]) for _ in range(n)]
+        else:
+            outs = list(outs)
+            if len(outs) != n:
+                raise PbError("outs must hold one array per source frame")
+            for o in outs:
+                u8 = is_device_array(o) and ((o.dtype == torch.uint8) if is_tensor(o) else (o.dtype == np.uint8))
+                if not u8 or tuple(o.shape) != (self.dst.height, self.dst.width, 3) or (is_tensor(o) and not o.is_contiguous()):
+                    raise PbError(f"outputs must be contiguous uint8 device arrays ({self.dst.height}, {self.dst.width}, 3)")
+        sp = (C.c_void_p * n)(*[int(s.data_ptr()) for s in srcs])
+        dp = (C.c_void_p * n)(*[int(o.data_ptr()) for o in outs])
+        with _on(srcs[0]):
+            check(load().pb_remap_u8v(self._h, sp, dp, n, current_stream() if stream is None else stream))
+        return outs
 
     def index_map(self, weights: bool = False, device=None):
         """int32 (H, W) index map, or for a double source (2, H, W) [+ float64 (2, H, W) weights]."""

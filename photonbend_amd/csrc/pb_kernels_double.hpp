@@ -231,7 +231,8 @@ __device__ __forceinline__ unsigned pb_double_fix_px(const PbDoubleFix& t, const
 // WMODE 0: every tile is UNIT; 1: a row table exists (unrotated panorama destination); 2: a latitude table exists.
 // tile_fix: faithful taps of failed tiles (1024 per tile, slot = right-eye entry's aux_off); px_fix: of the fix list.
 // ONE: single-frame launch (the frame loop and everything that keeps its invariants alive disappear).
-template <int WMODE, bool ONE>
+// VEC (pb_remap_u8v, with ONE): chunk c of the grid is the frame (vtab.src[c], vtab.dst[c]).
+template <int WMODE, bool ONE, bool VEC = false>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
                                                                             const PbTileEntry* __restrict__ table_r,
                                                                             const PbTileEntry* __restrict__ ltable,
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
                                                                             const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                             int n_frames, unsigned long long src_stride,
                                                                             unsigned long long dst_stride, const unsigned groups_per_frame,
-                                                                            const int frames_per_wave) {
+                                                                            const int frames_per_wave, const typename PbFrameTabOf<VEC>::type vtab) {
     // A batch is cut into chunks of frames_per_wave frames; chunks are a grid dimension (chunk-major, a tile group keeps
     // its XCD residue): the launch ramp and drain are paid once per batch, and inside a chunk the wave reuses its two
     // entries, blend weights and per-pixel addresses across the frames (ONE: chunks of one frame, no frame loop).
@@ -253,7 +254,12 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_double_kernel(const
     asm volatile("" ::"s"(ltable), "s"(Hd.dst_w), "s"(Hd.dst_h), "s"(Hd.src_w), "s"(Hd.src_h), "s"(Hd.win_budget), "s"(groups_per_frame));
     unsigned group = blockIdx.x;
     int frames = ONE ? 1 : frames_per_wave;
-    if (group >= groups_per_frame) {
+    if (VEC) {
+        const unsigned chunk = group / groups_per_frame;
+        group -= chunk * groups_per_frame;
+        src = pb_frame_src(vtab, chunk, src);
+        dst = pb_frame_dst(vtab, chunk, dst);
+    } else if (group >= groups_per_frame) {
         const unsigned chunk = group / groups_per_frame;
         group -= chunk * groups_per_frame;
         src += (unsigned long long)chunk * (unsigned)frames_per_wave * src_stride;

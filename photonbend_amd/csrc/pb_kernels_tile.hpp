@@ -190,6 +190,24 @@ struct PbHot {
 };
 __device__ __forceinline__ PbHot pb_hot_of(const PbParams& P) { return {P.dst.width, P.dst.height, P.src.width, P.src.height, P.win_budget}; }
 static inline PbHot pb_hot_of_host(const PbParams& P) { return {P.dst.width, P.dst.height, P.src.width, P.src.height, P.win_budget}; }
+// pb_remap_u8v: a batch whose frames are NOT at a uniform stride (a ring of separately allocated buffers).  The frame pointers travel
+// BY VALUE in the kernel-argument segment of the VEC instantiations of the hot kernels - a wave reads its frame's pair with one scalar
+// load at a uniform offset, in the same round trip as its tile entry; no device-side table to allocate, fill or guard, so the launch
+// stays allocation- and synchronisation-free (graph-capture safe) like pb_remap_u8.  The non-VEC instantiations carry 4 bytes.
+#define PB_MAX_VFRAMES 64
+struct PbFrameTab {
+    const uint8_t* src[PB_MAX_VFRAMES];
+    uint8_t* dst[PB_MAX_VFRAMES];
+};
+struct PbNoFrameTab {
+    int unused;
+};
+template <bool VEC> struct PbFrameTabOf { typedef PbNoFrameTab type; };
+template <> struct PbFrameTabOf<true> { typedef PbFrameTab type; };
+__device__ __forceinline__ const uint8_t* pb_frame_src(const PbFrameTab& t, unsigned f, const uint8_t*) { return t.src[f]; }
+__device__ __forceinline__ uint8_t* pb_frame_dst(const PbFrameTab& t, unsigned f, uint8_t*) { return t.dst[f]; }
+__device__ __forceinline__ const uint8_t* pb_frame_src(const PbNoFrameTab&, unsigned, const uint8_t* s) { return s; }
+__device__ __forceinline__ uint8_t* pb_frame_dst(const PbNoFrameTab&, unsigned, uint8_t* d) { return d; }
 static inline size_t pb_window_lds_bytes(const PbParams& P, int pad_dwords = 4) {
     return (size_t)PB_TILE_WAVES * ((size_t)P.win_budget + 4u * pad_dwords);
 }
@@ -656,7 +674,8 @@ __device__ __forceinline__ void pb_failed_tile(const PbHot& Hd, const PbTileEntr
 // 1216): measured on MI355X (round 3, experiments/session_r3_g.sh, three alternating pairs of processes) c2 40.6-41.2 -> 39.8-40.2 us,
 // c1 13.9-14.7 -> 13.7-13.9, c3 +-0, the all-tiles-skipped launch of 4096 workgroups 5.9-7.1 -> 5.9-6.7.  The double-fisheye kernel
 // keeps the block by value: by pointer measured 1.4 % SLOWER there (58.4-58.9 -> 59.5-59.8 us).
-template <int SRC_KIND>
+// VEC (pb_remap_u8v): frame f of the batch is (vtab.src[f], vtab.dst[f]) instead of src / dst + f * stride.
+template <int SRC_KIND, bool VEC = false>
 __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const PbParams* __restrict__ Pp, const PbHot Hd, const PbTileEntry* __restrict__ table,
                                                                          const uint8_t* __restrict__ src,
                                                                          uint8_t* __restrict__ dst, const unsigned groups_per_frame,
@@ -665,7 +684,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
                                                                          const int32_t* __restrict__ idx_tab,
                                                                          const int32_t* __restrict__ fix_px,
                                                                          const int32_t* __restrict__ fix_idx, const unsigned n_frames,
-                                                                         const unsigned ilv) {
+                                                                         const unsigned ilv, const typename PbFrameTabOf<VEC>::type vtab) {
     const PbParams& P = *Pp;
     // every kernel argument the tile prologue needs, in one scalar round trip (the compiler would otherwise fetch
     // the table pointer only after the tile index is known: a second dependent trip per wave)
@@ -690,7 +709,12 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
         dst += (unsigned long long)f * dst_stride;
     } else
 #endif
-    if (wg >= wgs_per_frame) {  // a batch: which frame
+    if (VEC) {  // a batch of separately allocated frames: the frame's pointers from the kernel-argument table
+        const unsigned f = wg / wgs_per_frame;
+        wg -= f * wgs_per_frame;
+        src = pb_frame_src(vtab, f, src);
+        dst = pb_frame_dst(vtab, f, dst);
+    } else if (wg >= wgs_per_frame) {  // a batch: which frame
         const unsigned f = wg / wgs_per_frame;
         wg -= f * wgs_per_frame;
         src += (unsigned long long)f * src_stride;

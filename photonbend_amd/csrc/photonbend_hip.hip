@@ -573,7 +573,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
             uint8_t* df = dst + (unsigned long long)f0 * ds;
 #define PB_LAUNCH_WIN(KIND)                                                                                                   \
     hipLaunchKernelGGL((pb_hot_win_kernel<KIND>), bgrid, wblock, lds, st, (const PbParams*)pl->P_dev, pb_hot_of_host(P), pl->ltable, sf, df, gpf, ss, ds, pl->idx_tab, \
-                       pl->fix_px, pl->fix_idx, (unsigned)nf, ilv)
+                       pl->fix_px, pl->fix_idx, (unsigned)nf, ilv, PbNoFrameTab{0})
             if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_WIN(PB_KIND_PANO);
             else PB_LAUNCH_WIN(PB_KIND_CAMERA);
         }
@@ -1200,7 +1200,7 @@ static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t*
 #define PB_LAUNCH_DOUBLE(WMODE, ONE)                                                                                              \
     hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, ONE>), bgrid, block, pb_window_lds_bytes(P, 8) + (size_t)pb_knob("PB_LDS_PAD", 0), st, P, plan->table, plan->table_r, plan->ltable, rows, plan->lat_tab, \
                        plan->fix_px, plan->dbl_px_fix, plan->dbl_tile_fix, src_dev, dst_dev, n_frames, src_frame_stride,           \
-                       dst_frame_stride, gpf, fpw)
+                       dst_frame_stride, gpf, fpw, PbNoFrameTab{0})
         const bool one = n_frames == 1 || fpw == 1;
         if (rows && one) PB_LAUNCH_DOUBLE(1, true);
         else if (rows) PB_LAUNCH_DOUBLE(1, false);
@@ -1225,7 +1225,72 @@ static int pb_remap_launch(const pb_plan* plan, const uint8_t* src_dev, uint8_t*
     return PB_OK;
 }
 
+// pb_remap_u8v: can the plan's hot kernel take a table of frame pointers?  (The windowed single-source kernel or the windowed
+// double-fisheye kernel, as pb_remap_launch would choose them for 16-byte aligned frames.)
+static bool pb_vec_launchable(const pb_plan* plan) {
+    const PbParams& P = plan->P;
+    if (plan->mode == PB_MODE_FAITHFUL || plan->mode == PB_MODE_FAST_DIRECT || !plan->ltable || plan->launch_groups == 0) return false;
+    if (plan->dbl_ready) return true;
+    return pb_use_fast(plan) && plan->P_dev && P.src.width < 32768 && P.src.height < 32768;
+}
+
 extern "C" {
+
+int pb_remap_u8v(const pb_plan* plan, const uint8_t* const* src_dev, uint8_t* const* dst_dev, int n_frames, void* stream) {
+    if (!plan || (n_frames > 0 && (!src_dev || !dst_dev))) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (n_frames < 0) return pb_fail(PB_ERR_INVALID, "negative frame count");
+    if (n_frames == 0) return PB_OK;
+    if (plan->device >= 0) {
+        int dev = -1;
+        PB_HIP(hipGetDevice(&dev));
+        if (dev != plan->device) return pb_fail(PB_ERR_INVALID, "plan was prepared on another device; create one plan per device");
+    }
+    bool aligned = true;
+    for (int f = 0; f < n_frames; ++f) {
+        if (!src_dev[f] || !dst_dev[f]) return pb_fail(PB_ERR_INVALID, "null frame pointer");
+        aligned = aligned && (((uintptr_t)src_dev[f]) & 15u) == 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (!aligned || !pb_vec_launchable(plan)) {
+        // frames LDS-DMA cannot address, deferred plans, the float64 mode: the frames one by one (same bytes, n launches)
+        for (int f = 0; f < n_frames; ++f) {
+            const int rc = pb_remap_launch(plan, src_dev[f], dst_dev[f], 1, 0, 0, st);
+            if (rc != PB_OK) return rc;
+        }
+        return PB_OK;
+    }
+    const PbParams& P = plan->P;
+    const unsigned gpf = plan->launch_groups;
+    const dim3 block(64 * PB_TILE_WAVES);
+    for (int f0 = 0; f0 < n_frames; f0 += PB_MAX_VFRAMES) {
+        const int nf = n_frames - f0 < PB_MAX_VFRAMES ? n_frames - f0 : PB_MAX_VFRAMES;
+        PbFrameTab tab;
+        for (int f = 0; f < PB_MAX_VFRAMES; ++f) {
+            tab.src[f] = src_dev[f0 + (f < nf ? f : 0)];
+            tab.dst[f] = dst_dev[f0 + (f < nf ? f : 0)];
+        }
+        const dim3 grid(gpf * (unsigned)nf);
+        if (plan->dbl_ready) {
+            const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
+#define PB_LAUNCH_DOUBLE_V(WMODE)                                                                                                          \
+    hipLaunchKernelGGL((pb_hot_double_kernel<WMODE, true, true>), grid, block, pb_window_lds_bytes(P, 8), st, P, plan->table, plan->table_r, plan->ltable, \
+                       rows, plan->lat_tab, plan->fix_px, plan->dbl_px_fix, plan->dbl_tile_fix, tab.src[0], tab.dst[0], nf, 0ull, 0ull, gpf, 1, tab)
+            if (rows) PB_LAUNCH_DOUBLE_V(1);
+            else if (plan->n_lat_tiles) PB_LAUNCH_DOUBLE_V(2);
+            else PB_LAUNCH_DOUBLE_V(0);
+#undef PB_LAUNCH_DOUBLE_V
+        } else {
+#define PB_LAUNCH_WIN_V(KIND)                                                                                                              \
+    hipLaunchKernelGGL((pb_hot_win_kernel<KIND, true>), grid, block, pb_window_lds_bytes(P), st, (const PbParams*)plan->P_dev, pb_hot_of_host(P), plan->ltable, \
+                       tab.src[0], tab.dst[0], gpf, 0ull, 0ull, plan->idx_tab, plan->fix_px, plan->fix_idx, (unsigned)nf, 0u, tab)
+            if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_WIN_V(PB_KIND_PANO);
+            else PB_LAUNCH_WIN_V(PB_KIND_CAMERA);
+#undef PB_LAUNCH_WIN_V
+        }
+    }
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
 
 int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* dst_dev, int n_frames, size_t src_frame_stride,
                          size_t dst_frame_stride, void* stream) {

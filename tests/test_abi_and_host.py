@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
     assert sorted(nat.SIGNATURES) == names, "ctypes binding and header disagree"
-    assert nat.load().pb_abi_version() == nat.ABI_VERSION == 4
+    assert nat.load().pb_abi_version() == nat.ABI_VERSION == 5
 
 
 def test_abi_argument_validation_without_gpu():

@@ -267,3 +267,55 @@ def test_batches_are_a_grid_dimension_and_change_no_byte(case):
     for f in (5, 36):
         frame = src[f * s_stride : f * s_stride + sb].reshape(h, w, 3)
         assert torch.equal(plan.remap(frame), dst[f * d_stride : f * d_stride + db].reshape(Hd, Wd, 3))
+
+
+@pytest.mark.parametrize("case", BATCH_CASES, ids=[c.name for c in BATCH_CASES])
+def test_scattered_frames_in_one_launch_equal_single_launches(case):
+    """pb_remap_u8v: a ring of SEPARATELY ALLOCATED frames (pointer tables, no common stride) in one launch per 64 frames - 70 frames
+    (two launches: 64 + 6) land byte for byte where 70 single pb_remap_u8 calls put them; a deferred plan, the float64 mode and an
+    unaligned source pointer take the frame-by-frame path and give the same bytes; bad arguments are refused."""
+    import ctypes as C
+
+    n = 70
+    _, h, w, *_ = case.src
+    Hd, Wd = case.dst[1], case.dst[2]
+    # separately allocated, in a shuffled order, with decoys in between so that neighbouring frames are not at one stride
+    rng = np.random.default_rng(5)
+    order = rng.permutation(n)
+    srcs, decoys = [None] * n, []
+    for f in order:
+        srcs[f] = nat.synth_frame(h, w, frame=int(f), circle_mask=case.mask)
+        decoys.append(torch.empty(int(rng.integers(1, 5)) * 4096 + 16, dtype=torch.uint8, device="cuda"))
+    outs = [torch.full((Hd, Wd, 3), 0xAB, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    plan = H.pb_plan_private(case)
+    assert plan.info()["fast_path"]
+    got = plan.remap_each(srcs, outs)
+    assert all(g is o for g, o in zip(got, outs))
+    for f in range(n):
+        assert torch.equal(outs[f], plan.remap(srcs[f])), f
+    # fresh outputs when none are given
+    fresh = plan.remap_each(srcs[:3])
+    assert all(torch.equal(a, b) for a, b in zip(fresh, outs[:3]))
+    # the float64 mode and a deferred plan: frame by frame, same bytes
+    plan.set_mode(nat.MODE_FAITHFUL)
+    assert all(torch.equal(a, b) for a, b in zip(plan.remap_each(srcs[10:13]), outs[10:13]))
+    plan.set_mode(nat.MODE_AUTO)
+    lazy = H.pb_plan_private(case, defer=True)
+    assert all(torch.equal(a, b) for a, b in zip(lazy.remap_each(srcs[20:22]), outs[20:22]))
+    # an unaligned source pointer (LDS-DMA cannot address it): still the same bytes
+    sb = h * w * 3
+    raw = torch.empty(sb + 16, dtype=torch.uint8, device="cuda")
+    raw[1 : 1 + sb] = srcs[7].reshape(-1)
+    odd = raw[1 : 1 + sb].reshape(h, w, 3)
+    assert odd.data_ptr() % 16 != 0
+    mixed = plan.remap_each([srcs[6], odd, srcs[8]])
+    assert torch.equal(mixed[0], outs[6]) and torch.equal(mixed[1], outs[7]) and torch.equal(mixed[2], outs[8])
+    # argument checks
+    L = nat.load()
+    sp = (C.c_void_p * 2)(srcs[0].data_ptr(), 0)
+    dp = (C.c_void_p * 2)(outs[0].data_ptr(), outs[1].data_ptr())
+    assert L.pb_remap_u8v(plan.handle, sp, dp, 2, nat.current_stream()) == -1  # PB_ERR_INVALID
+    assert L.pb_remap_u8v(plan.handle, sp, dp, -1, nat.current_stream()) == -1  # PB_ERR_INVALID
+    assert L.pb_remap_u8v(plan.handle, None, None, 0, nat.current_stream()) == 0
+    torch.cuda.synchronize()
+    del decoys
