@@ -33,6 +33,9 @@
 #ifndef PB_BIL_ABL  // timing experiments only (experiments/r4/): bits skip parts of the bilinear tile code (wrong pixels); 0 in the product
 #define PB_BIL_ABL 0
 #endif
+#ifndef PB_BIL_PATHS  // register-pressure experiments only (experiments/r5/): which tile paths are compiled in - 1 window, 2 direct, 4 table; 7 in the product
+#define PB_BIL_PATHS 7
+#endif
 #ifdef PB_MARKS  // ISA reading aid (experiments/r4/isa_count.py): comment markers around the paths of the tile code; never in the product build
 #define PB_MARK(name) asm volatile("; PBMARK " name ::: "memory")
 #else
@@ -175,6 +178,23 @@ __device__ __forceinline__ unsigned pb_umad24(unsigned a, unsigned b, unsigned c
     unsigned d;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
+}
+
+// The tile model as the bilinear tile code evaluates it: TD3 = the terms of total degree <= 3 only (PB_TILE_TD3 tiles: certified within
+// PB_COARSE_PX of the faithful coordinate by themselves), 4.5 packed multiply-adds per pixel instead of 9.
+template <bool TD3>
+__device__ __forceinline__ void pb_bil_collapse(const PbTileEntry* __restrict__ e, const bool col, const int t, pb_f2 c[5]) {
+    if (TD3) {
+        if (col) pb_collapse_col_td3(e, t, c);
+        else pb_collapse_row_td3(e, t, c);
+    } else {
+        if (col) pb_collapse_col(e, t, c);
+        else pb_collapse_row(e, t, c);
+    }
+}
+template <bool TD3>
+__device__ __forceinline__ pb_f2 pb_bil_eval(const pb_f2 c[5], const float t) {
+    return TD3 ? pb_eval_row_td3(c, t) : pb_eval_row(c, t);
 }
 
 // Four pixels from the wave's LDS window: the four taps around s = f - 0.5 (WINDOW coordinates; LEAN tiles carry one texel of margin
@@ -345,7 +365,7 @@ __device__ __forceinline__ void pb_bil_table8(const uint8_t* __restrict__ s, con
 // The direct-gather path's loads and arithmetic for one lane: its 16 pixels q(n) = (2 n + q0) & 31 along the collapsed polynomial
 // cf, eight pixels' loads in flight together (WIDE: two 8-byte loads per pixel, else four dwords), each blended pixel parked in the
 // wave's LDS at park_p + q * park_q.
-template <bool WIDE>
+template <bool WIDE, bool TD3>
 __device__ __forceinline__ void pb_bil_direct_gather(const uint8_t* __restrict__ s, unsigned* win, const pb_f2 cf[5], const unsigned gbase,
                                                      const unsigned rowbytes, const int q0, const int park_p, const int park_q) {
 #pragma unroll
@@ -355,7 +375,7 @@ __device__ __forceinline__ void pb_bil_direct_gather(const uint8_t* __restrict__
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int q = (2 * (8 * grp + m) + q0) & 31;
-            const pb_f2 sv = pb_eval_row(cf, pb_tile_coord(q));
+            const pb_f2 sv = pb_bil_eval<TD3>(cf, pb_tile_coord(q));
             wy[m] = __builtin_amdgcn_fractf(sv.x);
             wx[m] = __builtin_amdgcn_fractf(sv.y);
             const unsigned g = gbase + (unsigned)(int)sv.x * rowbytes + __umul24((unsigned)(int)sv.y, 3u);  // (s >= 0.5: truncation is floor)
@@ -391,6 +411,80 @@ __device__ __forceinline__ void pb_bil_direct_gather(const uint8_t* __restrict__
     }
 }
 
+// The window and the direct-gather path of a plain tile (LEAN / DIRECT), on the full tile model or on its TD3 part.
+template <bool TD3>
+__device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileEntry* __restrict__ e, const int flags, const int lane, unsigned* win,
+                                                  const int windows, const uint8_t* __restrict__ s, unsigned v[16]) {
+    const int xg = lane & 7, yb = lane >> 3;
+    const unsigned rowbytes = 3u * (unsigned)Hd.src_w, frame_bytes = rowbytes * (unsigned)Hd.src_h, safe_len = frame_bytes & ~15u;
+    const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
+    const bool along_x = fabsf(e->c[1][0]) <= fabsf(e->c[5][0]);  // |d row / du| <= |d row / dv|
+    if (!(PB_BIL_PATHS & 1) && (flags & PB_TILE_LEAN) && windows) return;
+    if ((PB_BIL_PATHS & 1) && (flags & PB_TILE_LEAN) && windows) {
+        const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
+        if (!(PB_BIL_ABL & 4)) pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pb_wave_sync();
+        const pb_f2 half = {0.5f, 0.5f};
+        const unsigned a0w = a0 + (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)win;  // (LDS addresses are 32-bit offsets)
+        if (along_x) {
+            PB_MARK("window_colfirst");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pb_f2 b[5], sv[4];
+                unsigned o[4];
+                pb_bil_collapse<TD3>(e, true, 4 * xg + k, b);
+                b[0] = b[0] - half;  // s = f - 0.5, folded into the constant term (window path and direct path alike)
+#pragma unroll
+                for (int jr = 0; jr < 4; ++jr) sv[jr] = pb_bil_eval<TD3>(b, pb_tile_coord(yb + 8 * jr));
+                pb_bil_lds4(sv, pitch, a0w, o);
+#pragma unroll
+                for (int jr = 0; jr < 4; ++jr) v[jr * 4 + k] = o[jr];
+            }
+        } else {
+            PB_MARK("window_rowfirst");
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                pb_f2 a[5], sv[4];
+                pb_bil_collapse<TD3>(e, false, yb + 8 * jr, a);
+                a[0] = a[0] - half;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[k] = pb_bil_eval<TD3>(a, pb_tile_coord(4 * xg + k));
+                pb_bil_lds4(sv, pitch, a0w, &v[jr * 4]);
+            }
+        }
+        PB_MARK("end");
+        pb_wave_sync();  // every lane has read its taps: the window may be refilled (the other eye, the next path)
+        return;
+    }
+    if (!(PB_BIL_PATHS & 2)) return;
+    // direct gathers.  wide: an 8-byte load takes both taps of a row - allowed when even the box's last tap has 8 bytes of frame
+    // behind it.
+    const bool wide = gbase + (unsigned)(e->win_rows - 1) * rowbytes + 3u * (unsigned)(e->win_cols - 1) + 8u <= frame_bytes;
+    const int p = lane & 31, hh = lane >> 5;
+    PB_MARK("direct");
+    const float num = along_x ? e->c[1][0] : e->c[5][0], den = along_x ? e->c[5][0] : e->c[1][0];
+    const float slope = (den != 0.0f) ? -num / den : 0.0f;
+    const int shift = (int)rintf(slope * ((float)p - 15.5f));
+    pb_f2 cf[5];
+    pb_bil_collapse<TD3>(e, along_x, p, cf);
+    {
+        const pb_f2 half = {0.5f, 0.5f};
+        cf[0] = cf[0] - half;  // s = f - 0.5 (as in the window path)
+    }
+    const int park_p = along_x ? p : p * 33, park_q = along_x ? 33 : 1;  // the lane's pixel (p, q) or (q, p) parks at [y][x], 33-dword pitch
+    if (wide) pb_bil_direct_gather<true, TD3>(s, win, cf, gbase, rowbytes, hh + shift, park_p, park_q);
+    else pb_bil_direct_gather<false, TD3>(s, win, cf, gbase, rowbytes, hh + shift, park_p, park_q);
+    pb_wave_sync();
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[jr * 4 + k] = win[(yb + 8 * jr) * 33 + 4 * xg + k];
+    PB_MARK("end");
+    pb_wave_sync();
+}
+
+
 // ---- one source's (or eye's) values for a tile -----------------------------------------------------------------------------
 // v[jr * 4 + k] = the bilinear sample of pixel (4 xg + k, yb + 8 jr) of the tile (xg = lane & 7, yb = lane >> 3: the lane's four
 // 12-byte stores), packed RGB.  Which path:
@@ -412,11 +506,12 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
                                             const int cmax, unsigned v[16]) {
     const int xg = lane & 7, yb = lane >> 3;
     const int h = Hd.src_h, w = Hd.src_w;
-    const unsigned rowbytes = 3u * (unsigned)w, frame_bytes = rowbytes * (unsigned)h, safe_len = frame_bytes & ~15u;
+    const unsigned frame_bytes = 3u * (unsigned)w * (unsigned)h;
     if ((PB_BIL_ABL & 32) && e->bil_off >= 0) return;                                                 // skip table tiles
     if ((PB_BIL_ABL & 64) && e->bil_off < 0 && (flags & PB_TILE_LEAN) && windows) return;            // skip window tiles
     if ((PB_BIL_ABL & 16) && e->bil_off < 0 && (flags & PB_TILE_DIRECT)) return;                     // skip direct-gather tiles
-    if (e->bil_off >= 0) {
+    if (!(PB_BIL_PATHS & 4) && e->bil_off >= 0) return;
+    if ((PB_BIL_PATHS & 4) && e->bil_off >= 0) {
         PB_MARK("table");
         const PbBilCoord* __restrict__ t = bil_xy + (size_t)e->bil_off * (PB_TILE * PB_TILE);
         int4 q[8];  // all sixteen coordinates first: one round trip
@@ -435,70 +530,12 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
         for (int n = 0; n < 16; ++n) v[n] = 0u;
         return;
     }
-    const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
-    const bool along_x = fabsf(e->c[1][0]) <= fabsf(e->c[5][0]);  // |d row / du| <= |d row / dv|
-    if ((flags & PB_TILE_LEAN) && windows) {
-        const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
-        if (!(PB_BIL_ABL & 4)) pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pb_wave_sync();
-        const pb_f2 half = {0.5f, 0.5f};
-        const unsigned a0w = a0 + (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)win;  // (LDS addresses are 32-bit offsets)
-        if (along_x) {
-            PB_MARK("window_colfirst");
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                pb_f2 b[5], sv[4];
-                unsigned o[4];
-                pb_collapse_col(e, 4 * xg + k, b);
-                b[0] = b[0] - half;  // s = f - 0.5, folded into the constant term (window path and direct path alike)
-#pragma unroll
-                for (int jr = 0; jr < 4; ++jr) sv[jr] = pb_eval_row(b, pb_tile_coord(yb + 8 * jr));
-                pb_bil_lds4(sv, pitch, a0w, o);
-#pragma unroll
-                for (int jr = 0; jr < 4; ++jr) v[jr * 4 + k] = o[jr];
-            }
-        } else {
-            PB_MARK("window_rowfirst");
-#pragma unroll
-            for (int jr = 0; jr < 4; ++jr) {
-                pb_f2 a[5], sv[4];
-                pb_collapse_row(e, yb + 8 * jr, a);
-                a[0] = a[0] - half;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sv[k] = pb_eval_row(a, pb_tile_coord(4 * xg + k));
-                pb_bil_lds4(sv, pitch, a0w, &v[jr * 4]);
-            }
-        }
-        PB_MARK("end");
-        pb_wave_sync();  // every lane has read its taps: the window may be refilled (the other eye, the next path)
-        return;
-    }
-    // direct gathers.  wide: an 8-byte load takes both taps of a row - allowed when even the box's last tap has 8 bytes of frame
-    // behind it.
-    const bool wide = gbase + (unsigned)(e->win_rows - 1) * rowbytes + 3u * (unsigned)(e->win_cols - 1) + 8u <= frame_bytes;
-    const int p = lane & 31, hh = lane >> 5;
-    PB_MARK("direct");
-    const float num = along_x ? e->c[1][0] : e->c[5][0], den = along_x ? e->c[5][0] : e->c[1][0];
-    const float slope = (den != 0.0f) ? -num / den : 0.0f;
-    const int shift = (int)rintf(slope * ((float)p - 15.5f));
-    pb_f2 cf[5];
-    if (along_x) pb_collapse_col(e, p, cf);
-    else pb_collapse_row(e, p, cf);
-    {
-        const pb_f2 half = {0.5f, 0.5f};
-        cf[0] = cf[0] - half;  // s = f - 0.5 (as in the window path)
-    }
-    const int park_p = along_x ? p : p * 33, park_q = along_x ? 33 : 1;  // the lane's pixel (p, q) or (q, p) parks at [y][x], 33-dword pitch
-    if (wide) pb_bil_direct_gather<true>(s, win, cf, gbase, rowbytes, hh + shift, park_p, park_q);
-    else pb_bil_direct_gather<false>(s, win, cf, gbase, rowbytes, hh + shift, park_p, park_q);
-    pb_wave_sync();
-#pragma unroll
-    for (int jr = 0; jr < 4; ++jr)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[jr * 4 + k] = win[(yb + 8 * jr) * 33 + 4 * xg + k];
-    PB_MARK("end");
-    pb_wave_sync();
+#ifdef PB_BIL_NO_TD3  // A/B builds only (experiments/r5/): the full tile model everywhere
+    if (false) pb_bil_model_vals<true>(Hd, e, flags, lane, win, windows, s, v);
+#else
+    if (flags & PB_TILE_TD3) pb_bil_model_vals<true>(Hd, e, flags, lane, win, windows, s, v);
+#endif
+    else pb_bil_model_vals<false>(Hd, e, flags, lane, win, windows, s, v);
 }
 
 // the lane's four 12-byte stores (4 consecutive pixels x 4 rows); tiles on the image's edge are clipped
@@ -833,6 +870,21 @@ __global__ void pb_bilinear_tile_list_kernel(PbTileEntry* __restrict__ table_l, 
     if (table_r) table_r[t].bil_off = need_r ? (int)atomicAdd(&counters[1], 1u) : -1;
     const bool failed = ((table_l[t].flags | (table_r ? table_r[t].flags : 0)) & PB_TILE_FAILED) != 0;
     if ((need_l || need_r) && !failed) list[atomicAdd(&counters[0], 1u)] = (int32_t)t;
+}
+
+// diagnostics (pb_plan_bilinear_tile_mix): how the bilinear mode serves the tiles of a table - counters: [0] window, [1] direct,
+// [2] exact coordinate table, [3] black, [4] plain tiles evaluated on their TD3 part, [5] entries seen
+__global__ void pb_bilinear_mix_kernel(const PbTileEntry* __restrict__ table, unsigned n, unsigned* __restrict__ counters) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int f = table[t].flags;
+    if (f & PB_TILE_SKIP) return;
+    atomicAdd(&counters[5], 1u);
+    if (table[t].bil_off >= 0) atomicAdd(&counters[2], 1u);
+    else if (f & PB_TILE_LEAN) atomicAdd(&counters[0], 1u);
+    else if (f & PB_TILE_DIRECT) atomicAdd(&counters[1], 1u);
+    else if (f & PB_TILE_BLACK) atomicAdd(&counters[3], 1u);
+    if (table[t].bil_off < 0 && (f & (PB_TILE_LEAN | PB_TILE_DIRECT)) && (f & PB_TILE_TD3)) atomicAdd(&counters[4], 1u);
 }
 
 // fills the coordinate table: 4 blocks per tile, every tile with a slot (pixels beyond the image repeat the edge: never stored)

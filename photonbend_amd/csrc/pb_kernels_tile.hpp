@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, 
         const bool solo_r = solo_ok && !solo_l && (fl & PB_TILE_BLACK) && (fr & plain);
         if (solo_l || solo_r) {
             if (solo_r) w = wr;
-            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK | PB_TILE_COARSE)) | PB_TILE_SOLO | (solo_r ? PB_TILE_EYE_R : 0);
+            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK | PB_TILE_COARSE | PB_TILE_TD3)) | PB_TILE_SOLO | (solo_r ? PB_TILE_EYE_R : 0);
         } else {
             w = 0;
         }
@@ -1170,6 +1170,9 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify
         pb_model_row(P, ec, X0, Y0, y, xh, R);
         bool lean_ok = true;
         double coarse = 0.0;  // largest |model - faithful| pre-truncation coordinate over this lane's sampled pixels, px
+        double coarse3 = 0.0;  // ... of the model's terms of total degree <= 3 alone (PB_TILE_TD3)
+        pb_f2 a3[4];
+        pb_collapse_row_td3(ec, y, a3);
 #if PB_CERTIFY_UNROLL
         PB_UNROLL(PB_CERTIFY_UNROLL)
 #endif
@@ -1212,6 +1215,14 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify
                     }
                     const double dm = fmax(d0, d1);
                     coarse = (dm == dm) ? fmax(coarse, dm) : 1.0;
+                    const pb_f2 tf = pb_eval_row_td3(a3, pb_tile_coord(xh + k));
+                    double e0 = fabs(((double)R.anchor_r + (double)tf.x) - f0), e1 = fabs(((double)R.anchor_c + (double)tf.y) - f1);
+                    if (SRC_KIND == PB_KIND_PANO) {
+                        e0 = fmin(e0, fabs(e0 - (double)P.src.height));
+                        e1 = fmin(e1, fabs(e1 - (double)P.src.width));
+                    }
+                    const double em = fmax(e0, e1);
+                    coarse3 = (em == em) ? fmax(coarse3, em) : 1.0;
                 }
                 if (lean && !pb_row_px_invalid(R, k)) {  // (a MASKED tile's invalid pixels are never sampled: the hot path masks them)
                     const pb_f2 f = pb_eval_row(R.a, pb_tile_coord(xh + k));
@@ -1233,6 +1244,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_CERTIFY_WPE) void pb_certify
             if (lane == 0) e->flags &= ~(PB_TILE_LEAN | PB_TILE_DIRECT);
         }
         if (__builtin_amdgcn_ballot_w64(coarse > PB_COARSE_PX) != 0 && lane == 0) e->flags |= PB_TILE_COARSE;
+        else if (lean && __builtin_amdgcn_ballot_w64(coarse3 > PB_COARSE_PX) == 0 && lane == 0) e->flags |= PB_TILE_TD3;
         unsigned total = (unsigned)pb_wave_sum((int)__popc(diff));
         // NO per-tile bookkeeping atomics here (round 4): every wave used to add to the same three or four words - LEAN / DIRECT / BLACK
         // tile counts, pixel totals - and 32 768 waves x 3.5 device-scope atomics on one cache line WERE the kernel: 1.14 ms for c5 whatever

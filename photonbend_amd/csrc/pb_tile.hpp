@@ -49,6 +49,14 @@
 // coordinate: it leaves such tiles to its float64 pass (pb_certify_kernel measures, the bilinear kernels obey).
 #define PB_TILE_COARSE 4096
 #define PB_COARSE_PX 0x1p-10  // 1/1024 px: at most half an LSB of a channel on the steepest possible content
+// TD3 (round 5; the bilinear mode only): the model's terms of TOTAL degree <= 3 (10 of the 25 coefficient pairs) alone stay within
+// PB_COARSE_PX of the faithful coordinate on every sampled pixel - measured by pb_certify_kernel like COARSE, against the float64 chain,
+// with the very evaluation the bilinear tile code then runs (pb_collapse_row_td3 / pb_eval_row_td3).  The coordinate field of a 32 x 32
+// tile is smooth on the scale of the whole image: its quartic terms are ~1e-6 px away from a projection's singular points, and the
+// coordinate costs 4.5 packed multiply-adds per pixel instead of 9 (experiments/r5/degree_study.py: every tile of c1 and c5, 83 % of
+// c2's, 62 % of c3's by the coefficient bound alone).  The nearest mode never looks at the flag: its exactness is certified for the
+// full model.
+#define PB_TILE_TD3 8192
 #define PB_TILE_W_UNIT_BIT 64  // == PB_TILE_W_UNIT (pb_kernels_double.hpp): blend factors exactly 1.0 for every pixel of the tile
 #define PB_LEAN_MAX_PASSES 24  // window rows / rows-per-load-instruction of a LEAN tile (register staging depth)
 
@@ -165,6 +173,40 @@ __device__ __forceinline__ pb_f2 pb_eval_row(const pb_f2 a[5], float u) {
     pb_f2 f = a[4];
 #pragma unroll
     for (int n = 3; n >= 0; --n) f = pb_fma2(f, u, a[n]);
+    return f;
+}
+
+// The same with the terms of total degree <= 3 only (PB_TILE_TD3 tiles, bilinear mode): c[m][n], m + n <= 3.
+__device__ __forceinline__ void pb_collapse_row_td3(const PbTileEntry* __restrict__ e, int y, pb_f2 a[4]) {
+    const float v = pb_tile_coord(y);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        pb_f2 s = {e->c[(3 - n) * 5 + n][0], e->c[(3 - n) * 5 + n][1]};
+#pragma unroll
+        for (int m = 2 - n; m >= 0; --m) {
+            const pb_f2 cm = {e->c[m * 5 + n][0], e->c[m * 5 + n][1]};
+            s = pb_fma2(s, v, cm);
+        }
+        a[n] = s;
+    }
+}
+__device__ __forceinline__ void pb_collapse_col_td3(const PbTileEntry* __restrict__ e, int x, pb_f2 b[4]) {
+    const float u = pb_tile_coord(x);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        pb_f2 s = {e->c[m * 5 + (3 - m)][0], e->c[m * 5 + (3 - m)][1]};
+#pragma unroll
+        for (int n = 2 - m; n >= 0; --n) {
+            const pb_f2 cn = {e->c[m * 5 + n][0], e->c[m * 5 + n][1]};
+            s = pb_fma2(s, u, cn);
+        }
+        b[m] = s;
+    }
+}
+__device__ __forceinline__ pb_f2 pb_eval_row_td3(const pb_f2 a[4], float u) {
+    pb_f2 f = a[3];
+#pragma unroll
+    for (int n = 2; n >= 0; --n) f = pb_fma2(f, u, a[n]);
     return f;
 }
 

@@ -1150,6 +1150,38 @@ int pb_plan_bilinear_float64_tiles(const pb_plan* plan) {
     if (plan->bil_xy) return 0;  // every tile the models cannot serve has its exact coordinates in the plan's table
     return (int)(plan->n_fail_tiles + (plan->bil_tiles ? plan->n_bil_tiles : 0u));
 }
+int pb_plan_bilinear_tile_mix(const pb_plan* plan, long long mix[6]) {
+    if (!plan || !mix) return pb_fail(PB_ERR_INVALID, "null argument");
+    for (int k = 0; k < 6; ++k) mix[k] = 0;
+    if (!(plan->fast_ready || plan->dbl_ready) || !plan->ltable_bil || plan->launch_groups_bil == 0) return PB_OK;
+    if (plan->device >= 0) {
+        int dev = -1;
+        PB_HIP(hipGetDevice(&dev));
+        if (dev != plan->device) return pb_fail(PB_ERR_INVALID, "plan was prepared on another device");
+    }
+    // the tables the bilinear launches read, classified under the mode's own budget: the launch-order table of a single source
+    // carries every tile's flags; a double-fisheye plan's two-eye slots only name their tile, so its eyes' tables are counted (their
+    // LEAN / DIRECT split is whatever budget was applied last)
+    unsigned* counters = nullptr;
+    PB_HIP(pb_tmp_alloc((void**)&counters, 8 * sizeof(unsigned)));
+    hipError_t e = hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), 0);
+    if (e == hipSuccess) {
+        if (plan->dbl_ready) {
+            hipLaunchKernelGGL(pb_bilinear_mix_kernel, dim3((plan->n_tiles + 255) / 256), dim3(256), 0, 0, plan->table, plan->n_tiles, counters);
+            hipLaunchKernelGGL(pb_bilinear_mix_kernel, dim3((plan->n_tiles + 255) / 256), dim3(256), 0, 0, plan->table_r, plan->n_tiles, counters);
+        } else {
+            const unsigned n_slots = 4u * plan->launch_groups_bil;
+            hipLaunchKernelGGL(pb_bilinear_mix_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, 0, plan->ltable_bil, n_slots, counters);
+        }
+        unsigned res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
+        for (int k = 0; k < 6; ++k) mix[k] = res[k];
+    }
+    if (e != hipSuccess) (void)hipDeviceSynchronize();
+    pb_tmp_free(counters);
+    PB_HIP(e);
+    return PB_OK;
+}
 int pb_plan_window_budget(const pb_plan* plan) {
     return (plan && (plan->fast_ready || plan->dbl_ready)) ? plan->P.win_budget : 0;
 }

@@ -303,3 +303,68 @@ def test_64_frame_c4_share_through_the_sharded_entry_point():
     assert (first, count) == (0, 64)
     assert bad == 0, f"{bad} of 64 frames differ from frame[idx]"
     assert distinct == 2
+
+
+def _c5_share_worker(q):
+    """One GPU's share of BASELINE config 5 (32 distinct 7776x3888 double-fisheye frames, 6.1 GB resident) through the C ABI's sharded
+    entry point; every frame against the blend of its two index-map gathers, frame 0 also against the reference's own bytes."""
+    import ctypes
+    import hashlib
+
+    from tests import helpers as H
+    from tests.cases import full_cases
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    lib = nat.load()
+    uid = ctypes.create_string_buffer(128)
+    nat.check(lib.pb_comm_unique_id(uid))
+    comm = ctypes.c_void_p()
+    nat.check(lib.pb_comm_init(1, 0, uid, ctypes.byref(comm)))
+    case = [c for c in full_cases() if c.name == "c5_180"][0]
+    plan = H.pb_plan_private(case)
+    n = 32
+    h, w, Hd, Wd = case.src[1], case.src[2], case.dst[1], case.dst[2]
+    frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
+    for f in range(n):
+        nat.synth_frame(h, w, frame=f, seed=0, circle_mask=case.mask, out=frames[f])
+    out = torch.empty((n, Hd, Wd, 3), dtype=torch.uint8, device="cuda")
+    out.fill_(0x5A)
+    first, count = ctypes.c_int(-1), ctypes.c_int(-1)
+    nat.check(lib.pb_remap_batch_sharded(comm, plan.handle, frames.data_ptr(), out.data_ptr(), n, 0, 0, ctypes.byref(first), ctypes.byref(count), nat.current_stream()))
+    torch.cuda.synchronize()
+    idx, wts = plan.index_map(weights=True)
+    sha_l = hashlib.sha256(idx[0].contiguous().cpu().numpy().tobytes()).hexdigest()
+    sha_r = hashlib.sha256(idx[1].contiguous().cpu().numpy().tobytes()).hexdigest()
+    bad = 0
+    for f in range(n):
+        want = nat.gather_blend(idx, wts, frames[f], 3, 1)
+        bad += int(not torch.equal(out[f].reshape(-1), want.reshape(-1)))
+        del want
+    sha0 = hashlib.sha256(out[0].contiguous().cpu().numpy().tobytes()).hexdigest()
+    distinct = int(not torch.equal(out[0], out[1])) + int(not torch.equal(out[30], out[31]))
+    nat.check(lib.pb_comm_destroy(comm))
+    q.put((sha_l, sha_r, sha0, bad, distinct, first.value, count.value))
+
+
+@pytest.mark.gpu
+def test_32_frame_c5_share_through_the_sharded_entry_point():
+    """north_star's c5 workload is 32 double-fisheye frames per GPU.  One rank's whole share (2.9 GB in + 3.2 GB out,
+    resident) goes through pb_remap_batch_sharded in ONE call; every output frame equals the reference's blend of the two eyes'
+    gathers through the plan's index maps and factors (pb_gather_blend_u8), both maps' SHA-256 are the reference's
+    (tests/golden/full.json: c5_180.idx_l_sha256 / idx_r_sha256), and frame 0's bytes hash to the reference's own output."""
+    from tests import helpers as H
+
+    pin = H.load_full()["c5_180"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_c5_share_worker, args=(q,))
+    p.start()
+    sha_l, sha_r, sha0, bad, distinct, first, count = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert (sha_l, sha_r) == (pin["idx_l_sha256"], pin["idx_r_sha256"]), "the plan's index maps are not the reference's"
+    assert sha0 == pin["u8_sha256"], "frame 0 of the share is not the reference's output"
+    assert (first, count) == (0, 32)
+    assert bad == 0, f"{bad} of 32 frames differ from the blend of their index-map gathers"
+    assert distinct == 2

@@ -279,3 +279,54 @@ def test_failed_launch_table_allocation_leaves_a_working_plan():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-c", _FAIL_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_plans_are_prepared_outside_the_cache_lock(monkeypatch):
+    """the cache lock guards the dictionary only.  While one thread prepares a geometry (held up inside _prepare),
+    another thread gets a DIFFERENT geometry's prepared plan without waiting; eager callers of the SAME geometry wait for the one
+    preparation and all receive its plan; a facade (non-eager) caller does not wait and gets the deferred plan; a failed preparation
+    reaches its eager waiters as an error and leaves the entry retryable."""
+    proj._PLAN_CACHE.clear()
+    (d1, r1, s1), (d2, r2, s2) = _projs(CASES[0]), _projs(CASES[1])
+    gate, entered = threading.Event(), threading.Event()
+    real_prepare = proj._prepare
+    calls = []
+
+    def slow_prepare(plan, key, rotations):
+        calls.append(key)
+        if plan.dst.key() == d1.key():
+            entered.set()
+            assert gate.wait(60)
+        return real_prepare(plan, key, rotations)
+
+    monkeypatch.setattr(proj, "_prepare", slow_prepare)
+    out = {}
+    t1 = threading.Thread(target=lambda: out.__setitem__("owner", proj._plan_for(d1, r1, s1, device="cuda:0")))
+    t1.start()
+    assert entered.wait(60)
+    # a different geometry: prepared while geometry 1 is still being prepared
+    other = proj._plan_for(d2, r2, s2, device="cuda:0")
+    assert other.info()["fast_path"]
+    # the same geometry: a facade caller gets the deferred plan at once, eager callers wait for the owner's plan
+    lazy = proj._plan_for(d1, r1, s1, device="cuda:0", eager=False)
+    assert not lazy.info()["fast_path"]
+    waiters = [threading.Thread(target=lambda k=k: out.__setitem__(k, proj._plan_for(d1, r1, s1, device="cuda:0"))) for k in range(3)]
+    [t.start() for t in waiters]
+    gate.set()
+    t1.join(60)
+    [t.join(60) for t in waiters]
+    assert out["owner"].info()["fast_path"] and all(out[k] is out["owner"] for k in range(3))
+    assert sum(1 for k in calls if k[1] == d1.key()) == 1, "one preparation per geometry"
+    # a failing preparation: the owner raises, the entry stays unprepared and can be retried
+    proj._PLAN_CACHE.clear()
+
+    def failing_prepare(plan, key, rotations):
+        raise nat.PbError("injected")
+
+    monkeypatch.setattr(proj, "_prepare", failing_prepare)
+    with pytest.raises(nat.PbError):
+        proj._plan_for(d1, r1, s1, device="cuda:0")
+    monkeypatch.setattr(proj, "_prepare", real_prepare)
+    assert proj._plan_for(d1, r1, s1, device="cuda:0").info()["fast_path"]
+    proj._PLAN_CACHE.clear()
