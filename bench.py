@@ -330,10 +330,12 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
                "kernel_ms_per_frame_p90": round(float(np.percentile(durs, 90)), 5),
                "mpx_per_s": round(dh * dw / 1e6 / (per_frame_ms * 1e-3), 1), "launches_timed": n_groups * every,
                "algorithmic_bytes_per_frame": alg4, "must_move_bytes_per_frame": must,
-               "frac": round(alg4 / (per_frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-               "frac_note": "4-tap algorithmic bytes (3 B written per output pixel + 4 x 3 B read per in-bounds sample) / kernel time / 8 TB/s; the bytes that must cross HBM are the nearest mode's",
+               "frac_must_move": round(must / (per_frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "frac_4tap": round(alg4 / (per_frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "frac_note": "frac_must_move = the bytes that MUST cross HBM (every 128-byte source line holding a sample, once, + the output: the nearest mode's) / kernel time / 8 TB/s - the roofline figure; "
+                            "frac_4tap prices four taps per sample (3 B written per output pixel + 4 x 3 B read per in-bounds sample): arithmetic riding on that traffic, not a roofline fraction",
                "traffic_bytes_per_frame": traffic_for(name + "_bilinear", info)[0],
-               "bilinear_float64_tiles": info["bilinear_float64_tiles"], "tiles": info["tiles"],
+               "bilinear_float64_tiles": info["bilinear_float64_tiles"], "tiles": info["tiles"], "tile_mix": plan.bilinear_tile_mix(),
                "nearest_over_bilinear_note": "one launch per call: tile models where certified to 1/1024 px, the plan's exact coordinate table elsewhere; no float64 per frame"}
         del srcs, dsts, plan
         torch.cuda.empty_cache()
@@ -454,6 +456,56 @@ def multi_stream_ms(fn, handle, sp0, dp0, sbytes, dbytes, n_pool, batch, device,
     go(launches)
     torch.cuda.synchronize(device)
     return (time.perf_counter() - t0) * 1e3 / (launches * batch)
+
+
+def scattered_batch(lib, nat, plan, cfg, s, d, device, stream, n=8, launches=24):
+    """a ring of SEPARATELY ALLOCATED frames (no common stride) through pb_remap_u8v - ONE launch per `n` frames on one
+    stream.  2 x n frame pairs (beyond the Infinity Cache for the headline config) with decoy allocations in between; kernel ms per frame
+    between HIP events, next to the same frames as n single pb_remap_u8 launches."""
+    import torch
+
+    pairs, decoys = [], []
+    for k in range(2 * n):
+        pairs.append((nat.synth_frame(s.height, s.width, frame=3000 + k, seed=0, circle_mask=cfg["mask"]),
+                      torch.empty((d.height, d.width, 3), dtype=torch.uint8, device=device)))
+        decoys.append(torch.empty(4096 * (1 + k % 3) + 16, dtype=torch.uint8, device=device))
+    tabs = []
+    for a in (0, n):
+        sp = (ctypes.c_void_p * n)(*[int(p[0].data_ptr()) for p in pairs[a : a + n]])
+        dp = (ctypes.c_void_p * n)(*[int(p[1].data_ptr()) for p in pairs[a : a + n]])
+        tabs.append((sp, dp))
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    nat.check(lib.pb_event_create(ctypes.byref(e0)))
+    nat.check(lib.pb_event_create(ctypes.byref(e1)))
+    ms = ctypes.c_float()
+
+    def timed(fn):
+        for k in range(4):
+            fn(k)
+        lib.pb_event_record(e0, stream)
+        for k in range(launches):
+            fn(k)
+        lib.pb_event_record(e1, stream)
+        nat.check(lib.pb_event_sync(e1))
+        nat.check(lib.pb_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+        return ms.value / (launches * n)
+
+    def vec(k):
+        sp, dp = tabs[k & 1]
+        nat.check(lib.pb_remap_u8v(plan.handle, sp, dp, n, stream))
+
+    def singles(k):
+        for p in pairs[(k & 1) * n : (k & 1) * n + n]:
+            nat.check(lib.pb_remap_u8(plan.handle, p[0].data_ptr(), p[1].data_ptr(), 1, 0, 0, stream))
+
+    out = {"frames_per_launch": n, "separately_allocated_frames": 2 * n, "u8v_ms_per_frame": round(timed(vec), 5),
+           "single_launches_ms_per_frame": round(timed(singles), 5),
+           "note": "pb_remap_u8v: frame pointers in the kernel-argument segment, one launch per 8 frames on one stream; byte-identical to the single launches (tests/test_hip_plan.py)"}
+    lib.pb_event_destroy(e0)
+    lib.pb_event_destroy(e1)
+    del pairs, decoys
+    torch.cuda.empty_cache()
+    return out
 
 
 def graph_replay_ms(lib, nat, plan, srcs, dsts, sbytes, dbytes, n_pool, device, launches=8, replays=25):
@@ -864,6 +916,10 @@ def main():
                 line["wall_ms_per_frame_by_streams_note"] = repr(exc)
             del srcs, dsts
             torch.cuda.empty_cache()
+            try:
+                line["scattered_batch"] = scattered_batch(lib, nat, plan, cfg, s, d, device, sts[0])
+            except Exception as exc:
+                line["scattered_batch"] = {"error": repr(exc)}
             single_ms, faithful_ms = headline_extras(lib, nat, d, rots, s, cfg, device, sts[0], budget)
             line["single_image_ms"] = single_ms
             line["single_image_note"] = "warm plan creation (thresholds, tile models, certification, launch table) + the first frame of a NEW geometry, device-resident input; a deferred plan instead runs faithful_kernel_ms with no preparation"

@@ -262,6 +262,19 @@ int pb_sample_map_u8(const pb_proj* src, double* map_dev, int height, int width,
  * it is given (projection.py:234-243, :545-546). */
 int pb_index_from_map_i32(const pb_proj* src, double* map_dev, int height, int width, const double* dist_l_dev,
                           const double* dist_r_dev, int32_t* idx_dev, double* weights_dev, void* stream);
+/* The opt-in bilinear mode on a MATERIALISED map and on ANY image (ABI 5): what process_coordinate_map(map, interpolation="bilinear")
+ * runs when the map is an array (looked at or edited between the stages; a destination Lens of user callables), when the image is not
+ * uint8 RGB (grey, RGBA, 16-bit samples) or when the source Lens is made of user callables (dist_l_dev / dist_r_dev as in
+ * pb_index_from_map_i32).  The definition of pb_remap_bilinear_u8, evaluated per pixel in float64 from the map's (lat, lon, invalid):
+ * taps floor(f - 0.5), + 1 clamped to the image (a panorama's columns wrap, an eye's taps stay in its half), round half to even,
+ * clamped to the sample range; PB_KIND_PANO zeroes invalid lat/lon in map_dev like the reference.  img_dev: (h, w, channels)
+ * samples of sample_bytes (1 or 2) bytes; out_dev: (height, width, channels) of the same sample type - a double-fisheye source
+ * returns uint8 like the reference's (left * fl + right * fr).astype(np.uint8) (projection.py:447-460).
+ * Replaces: nothing in the reference (it truncates: projection.py:254-259, :545); completes the ProjectionImage protocol
+ * (projection.py:40-66, :197-245, :515-547) for the opt-in mode.  pb_sample_map_bilinear_u8 = 3 channels of 1 byte. */
+int pb_sample_map_bilinear_px(const pb_proj* src, double* map_dev, int height, int width, const double* dist_l_dev, const double* dist_r_dev,
+                              const void* img_dev, void* out_dev, int channels, int sample_bytes, void* stream);
+int pb_sample_map_bilinear_u8(const pb_proj* src, double* map_dev, int height, int width, const uint8_t* src_dev, uint8_t* dst_dev, void* stream);
 /* dst[p] = idx[p] < 0 ? 0 : src[idx[p]], bytes_per_px bytes each (1..64). */
 int pb_gather_px(const int32_t* idx_dev, const void* src_dev, void* dst_dev, size_t n_px, int bytes_per_px, void* stream);
 /* The double-fisheye blend for `channels` interleaved samples of 1 or 2 bytes (unsigned): per channel

@@ -35,8 +35,11 @@ def to_radians(degrees: float) -> float:
 # --------------------------------------------------------------------------
 # a-1  lens functions (core/lens.py:68-335)
 # --------------------------------------------------------------------------
-def lens_forward(lens: str, theta):
-    """theta (rad) -> distance from the centre in focal-length units."""
+def lens_forward(lens, theta):
+    """theta (rad) -> distance from the centre in focal-length units.  `lens`: a built-in's name, or a (forward, reverse) pair of
+    callables - a Lens of user functions (lens.py:48-64)."""
+    if isinstance(lens, tuple):
+        return lens[0](theta)
     if lens == "equidistant":  # lens.py:169-187
         return theta
     if lens == "equisolid":  # lens.py:224-243
@@ -61,8 +64,10 @@ def lens_forward(lens: str, theta):
     raise KeyError(lens)
 
 
-def lens_inverse(lens: str, r):
+def lens_inverse(lens, r):
     """distance in focal-length units -> incidence angle (rad)."""
+    if isinstance(lens, tuple):
+        return lens[1](r)
     if lens == "equidistant":  # lens.py:148-165
         return r
     if lens == "equisolid":  # lens.py:191-220 (NaN -> 0.0)
@@ -449,12 +454,12 @@ def _bilinear_camera(p: Proj, h: int, w: int, image: np.ndarray, lat, lon, inval
         img = image.astype(np.float64)
         top = img[r0, c0] + tx * (img[r0, c1] - img[r0, c0])
         bot = img[r1, c0] + tx * (img[r1, c1] - img[r1, c0])
-        val = np.clip(np.rint(top + ty * (bot - top)), 0, 255).astype(np.uint8)
+        val = np.clip(np.rint(top + ty * (bot - top)), 0, np.iinfo(image.dtype).max).astype(image.dtype)
     val[~live] = 0
     return val, live
 
 
-def remap_bilinear(dst: Proj, src: Proj, image: np.ndarray, rotations=()) -> np.ndarray:
+def remap_bilinear(dst: Proj, src: Proj, image: np.ndarray, rotations=(), cmap: np.ndarray = None) -> np.ndarray:
     """OUR definition of the opt-in bilinear mode - the reference has no such behaviour, so this
     function is "parity unpinned": it pins the HIP kernels to a written-down definition, not to the reference.
 
@@ -462,10 +467,19 @@ def remap_bilinear(dst: Proj, src: Proj, image: np.ndarray, rotations=()) -> np.
     centre k + 0.5); s = f - 0.5, i0 = floor(s), t = s - i0; taps clamped to the image (panorama columns wrap),
     float64 weights, round half to even.  Black where the nearest mode is black.  A double-fisheye source is the
     reference's blend (projection.py:439-460) of the two eyes' bilinear uint8 samples, each eye sampled like a camera
-    source on its half of the frame (the right eye on the mirrored half)."""
-    cmap = coordinate_map(dst)
-    for rot in rotations:
-        cmap = rotate_map(rotation_matrix(*rot), cmap)
+    source on its half of the frame (the right eye on the mirrored half).
+
+    Round 5: `cmap` - a materialised (possibly edited) coordinate map used instead of dst's and the rotations; `image` any layout the
+    reference's fancy indexing accepts - (h, w) or (h, w, C), uint8 or uint16: values round half to even and clip to the sample type's
+    range; a double-fisheye source returns uint8 whatever the samples, like the reference's blend."""
+    if cmap is None:
+        cmap = coordinate_map(dst)
+        for rot in rotations:
+            cmap = rotate_map(rotation_matrix(*rot), cmap)
+    if image.ndim == 2:
+        if src.kind == "double":
+            raise ValueError("operands could not be broadcast together")
+        return remap_bilinear(dst, src, image[:, :, None], rotations, cmap)[:, :, 0]
     invalid = cmap[:, :, 2] != 0.0
     h, w = src.height, src.width
     if src.kind == "double":
@@ -498,6 +512,6 @@ def remap_bilinear(dst: Proj, src: Proj, image: np.ndarray, rotations=()) -> np.
         img = image.astype(np.float64)
         top = img[r0, c0] + tx * (img[r0, c1] - img[r0, c0])
         bot = img[r1, c0] + tx * (img[r1, c1] - img[r1, c0])
-        val = np.clip(np.rint(top + ty * (bot - top)), 0, 255).astype(np.uint8)
+        val = np.clip(np.rint(top + ty * (bot - top)), 0, np.iinfo(image.dtype).max).astype(image.dtype)
     val[~live] = 0
     return val

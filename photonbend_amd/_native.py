@@ -94,6 +94,8 @@ SIGNATURES = {
     "pb_rotate_f64": (C.c_int, [C.POINTER(C.c_double), _VP, _VP, C.c_int, C.c_int, _VP]),
     "pb_sample_map_u8": (C.c_int, [C.POINTER(pb_proj), _VP, C.c_int, C.c_int, _VP, _VP, _VP]),
     "pb_index_from_map_i32": (C.c_int, [C.POINTER(pb_proj), _VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, _VP]),
+    "pb_sample_map_bilinear_px": (C.c_int, [C.POINTER(pb_proj), _VP, C.c_int, C.c_int, _VP, _VP, _VP, _VP, C.c_int, C.c_int, _VP]),
+    "pb_sample_map_bilinear_u8": (C.c_int, [C.POINTER(pb_proj), _VP, C.c_int, C.c_int, _VP, _VP, _VP]),
     "pb_gather_px": (C.c_int, [_VP, _VP, _VP, C.c_size_t, C.c_int, _VP]),
     "pb_gather_blend_u8": (C.c_int, [_VP, _VP, _VP, _VP, C.c_size_t, C.c_int, C.c_int, _VP]),
     "pb_map_projection_u8": (C.c_int, [_VP, C.c_int, C.c_int, _VP, _VP, _VP]),
@@ -495,6 +497,21 @@ def index_from_map(src: pb_proj, cmap, dist_l=None, dist_r=None):
         check(load().pb_index_from_map_i32(C.byref(src), cmap.data_ptr(), H, W, dist_l.data_ptr() if dist_l is not None else None,
                                            dist_r.data_ptr() if dist_r is not None else None, idx.data_ptr(), w.data_ptr() if w is not None else None, current_stream()))
     return idx, w
+
+
+def sample_map_bilinear(src: pb_proj, cmap, img, channels: int, dt: np.dtype, dist_l=None, dist_r=None):
+    """The opt-in bilinear mode from a materialised float64 map (H, W, 3) on the device: img = the image's samples as a device array
+    (h, w, channels) of dtype dt (uint8 / uint16) -> (H, W, channels), uint8 for a double-fisheye source (pb_sample_map_bilinear_px)."""
+    require_gpu()
+    H, W = int(cmap.shape[0]), int(cmap.shape[1])
+    dt = np.dtype(dt)
+    out_dt = np.dtype(np.uint8) if src.kind == KIND_DOUBLE else dt
+    out = empty((H, W, channels), out_dt, like=cmap)
+    with _on(cmap):
+        check(load().pb_sample_map_bilinear_px(C.byref(src), cmap.data_ptr(), H, W, dist_l.data_ptr() if dist_l is not None else None,
+                                               dist_r.data_ptr() if dist_r is not None else None, img.data_ptr(), out.data_ptr(), int(channels),
+                                               dt.itemsize, current_stream()))
+    return out
 
 
 def gather_px(idx, img_bytes):

@@ -92,7 +92,10 @@ def _plan_for(dst: nat.pb_proj, rotations, src: nat.pb_proj, device=None, eager:
         dev_index = nat.current_device() if have_gpu else 0
     elif isinstance(device, int):
         dev_index = device
-    else:  # a torch.device (or its string form)
+    elif isinstance(device, str):  # "cuda" / "cuda:N"
+        tail = device.partition(":")[2]
+        dev_index = int(tail) if tail else (nat.current_device() if have_gpu else 0)
+    else:  # a torch.device
         idx = getattr(device, "index", None)
         dev_index = idx if idx is not None else (nat.current_device() if have_gpu else 0)
     eager = eager or os.environ.get("PB_PLAN_EAGER") == "1"
@@ -304,8 +307,8 @@ class _GpuProjection:
     def _source_distances(self, lat: np.ndarray):  # pragma: no cover - overridden by the camera classes
         raise NotImplementedError
 
-    def _index_from_map(self, src: nat.pb_proj, dev_map):
-        """int32 source indices (and float64 weights for a double source) of a materialised map on the device."""
+    def _distance_planes(self, src: nat.pb_proj, dev_map):
+        """forward_lens(latitude) * f_distance per pixel for a source Lens of user callables (None, None for a built-in lens)."""
         dl = dr = None
         if src.kind != nat.KIND_PANO and src.lens == nat.LENS_CUSTOM:
             # forward_function is host Python by definition: latitude plane down, distances up (projection.py:251)
@@ -315,6 +318,11 @@ class _GpuProjection:
             dl = _upload(np.ascontiguousarray(planes[0], dtype=np.float64), dev)
             if src.kind == nat.KIND_DOUBLE:
                 dr = _upload(np.ascontiguousarray(planes[1], dtype=np.float64), dev)
+        return dl, dr
+
+    def _index_from_map(self, src: nat.pb_proj, dev_map):
+        """int32 source indices (and float64 weights for a double source) of a materialised map on the device."""
+        dl, dr = self._distance_planes(src, dev_map)
         return nat.index_from_map(src, dev_map, dl, dr)
 
     def _gather(self, src: nat.pb_proj, idx, weights, img_bytes, tail, dt: np.dtype):
@@ -338,24 +346,29 @@ class _GpuProjection:
         image the reference accepts - grey (H, W), RGBA, 16-bit samples - and sources whose lens is made of user
         callables go through the integer index map and a gather (same indices, same bytes as the reference).
 
-        ``interpolation="bilinear"`` is an opt-in extension with no reference counterpart (the reference
-        truncates to the nearest pixel): lazy maps and uint8 RGB images only."""
+        ``interpolation="bilinear"`` is an opt-in extension with no reference counterpart (the reference truncates to the nearest
+        pixel).  A lazy map + a uint8 RGB image + built-in lenses take the tile kernels (one launch); a materialised or edited map, a
+        grey / RGBA / 16-bit image or a Lens of user callables take the mode's definition per pixel from the map
+        (pb_sample_map_bilinear_px) - same definition, float64 arithmetic."""
         src = self._proj("src")
         h, w, tail, dt = _image_info(self.image)
         rgb8 = tail == (3,) and dt == np.dtype(np.uint8)
         custom_src = src.kind != nat.KIND_PANO and src.lens == nat.LENS_CUSTOM
         lazy = isinstance(coordinate_map, CoordinateMap) and coordinate_map.is_lazy
-        if interpolation != "nearest":
+        bilinear = interpolation != "nearest"
+        if bilinear:
             if interpolation != "bilinear":
                 raise ValueError("interpolation must be 'nearest' or 'bilinear'")
-            if not lazy:
-                raise NotImplementedError("bilinear sampling needs a lazy coordinate map (a recipe), not a materialised array")
-            if not rgb8 or custom_src:
-                raise NotImplementedError("bilinear sampling takes uint8 (H, W, 3) images and built-in lenses")
+            if dt not in (np.dtype(np.uint8), np.dtype(np.uint16)):
+                raise NotImplementedError(f"bilinear sampling takes 8- or 16-bit unsigned samples, got {dt}")
+            if src.kind == nat.KIND_DOUBLE and len(tail) != 1:
+                # (the reference's blend cannot broadcast (H, W) samples against its (H, W, 1) factor maps either)
+                H_, W_ = tuple(coordinate_map.shape[:2])
+                raise ValueError(f"operands could not be broadcast together with shapes ({H_},{W_}) ({H_},{W_},1)")
         on_device = nat.is_device_array(self.image)  # the pixels live on the device: so does the result
         fused = rgb8 and not custom_src
         rotations = coordinate_map.rotations if lazy else ()
-        if interpolation == "bilinear" and len(rotations) > nat.PB_MAX_ROTATIONS:
+        if bilinear and lazy and len(rotations) > nat.PB_MAX_ROTATIONS:
             # The reference applies any number of -r rotations one after the other (scripts/commands/make_photo.py:128-131).  A chain
             # longer than one fused plan takes leaves the plan for the materialised-map kernels, which only truncate; in THIS mode
             # (our own definition, no reference bits to keep) the chain folds into one matrix product R_k ... R_1 instead.
@@ -376,7 +389,7 @@ class _GpuProjection:
             return out
         img = _device_image(self.image, h, w) if fused else _device_bytes(self.image)
         dev = img.device if nat.is_tensor(img) else None
-        if lazy and not too_many and not custom_src:
+        if lazy and not too_many and not custom_src and (fused or not bilinear):
             # bilinear taps come from the tile models: that mode needs the prepared plan from the first use on
             plan = _plan_for(coordinate_map.dst_proj, rotations, src, device=dev, eager=interpolation != "nearest")
             with nat.on_device(nat.device_index_of(img)):
@@ -404,7 +417,16 @@ class _GpuProjection:
                 if not (isinstance(host, np.ndarray) and host.dtype == np.float64 and host.ndim == 3 and host.shape[2] == 3):
                     raise TypeError("coordinate_map must be a float64 array of shape (H, W, 3)")
                 dmap = _upload(host, dev)
-            if fused:
+            if bilinear:
+                # the mode's definition per pixel from the map (pb_sample_map_bilinear_px): a materialised or edited map, any image
+                # layout, a source Lens of user callables - everything the tile kernels do not take
+                dl, dr = self._distance_planes(src, dmap)
+                channels = int(np.prod(tail, dtype=np.int64))
+                out = nat.sample_map_bilinear(src, dmap, img, channels, dt, dl, dr)
+                out_dt = np.dtype(np.uint8) if src.kind == nat.KIND_DOUBLE else dt
+                H_, W_ = int(dmap.shape[0]), int(dmap.shape[1])
+                out = out.reshape((H_, W_) + tuple(tail)) if nat.is_tensor(out) else out.view(out_dt, (H_, W_) + tuple(tail))
+            elif fused:
                 out = nat.sample_map(src, dmap, img)
             else:
                 idx, wts = self._index_from_map(src, dmap)

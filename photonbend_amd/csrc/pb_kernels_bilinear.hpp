@@ -78,6 +78,95 @@ __device__ __forceinline__ unsigned pb_bilinear_taps(const PbParams& P, const ui
     return out;
 }
 
+// ---- the mode on a MATERIALISED map, any image (round 5: f-4's API complete) ----------------------------------------------------
+// pb_sample_map_bilinear_px: the definition itself, per pixel, in float64 - the coordinate comes from the caller's (H, W, 3) map (a map
+// that was looked at or edited between the stages; a destination Lens of user callables), the source stage is the reference's
+// (projection.py:247-260, :533-545; a source Lens of user callables through the host-evaluated distance planes, like
+// pb_index_from_map_i32), the image any layout the reference's fancy indexing accepts: C channels of 8- or 16-bit samples.  The three
+// lerps are the oracle's float64 expressions with the build's -ffp-contract=off: on equal coordinates the bytes ARE
+// oracle.remap_bilinear's.  One work-item per output pixel; off the hot path (uint8 RGB + built-in lenses + a lazy map take the tile
+// kernels above).
+template <typename SAMPLE>
+__device__ __forceinline__ double pb_bil64_tap(const SAMPLE* __restrict__ img, long long r, long long c, int w, int channels, int ch) {
+    return (double)img[((unsigned long long)r * (unsigned)w + (unsigned long long)c) * (unsigned)channels + (unsigned)ch];
+}
+// one source's sample of channel ch at pre-truncation coordinate (fy, fx): taps clamped to rows [0, h) and columns [cmin, cmax) of a
+// frame `w` wide (`mirror`: the right eye's image is its half mirrored - projection.py:430-431 - eye column x = frame column
+// cmax - 1 - x); WRAP: a panorama's columns wrap first.  Rounded half to even and clamped to the sample type's range.
+template <typename SAMPLE, bool WRAP>
+__device__ __forceinline__ double pb_bil64_sample(const SAMPLE* __restrict__ img, double fy, double fx, int h, int w, int cmin, int cmax, bool mirror,
+                                                  int channels, int ch) {
+    const double sy = fy - 0.5, sx = fx - 0.5;
+    const double ry = floor(sy), rx = floor(sx);
+    const double ty = sy - ry, tx = sx - rx;
+    long long r0 = (long long)ry, c0 = (long long)rx;
+    long long r1 = r0 + 1, c1 = c0 + 1;
+    r0 = r0 < 0 ? 0 : (r0 > h - 1 ? h - 1 : r0);
+    r1 = r1 < 0 ? 0 : (r1 > h - 1 ? h - 1 : r1);
+    const long long we = cmax - cmin;
+    if (WRAP) {
+        c0 %= we; if (c0 < 0) c0 += we;
+        c1 %= we; if (c1 < 0) c1 += we;
+    }
+    c0 = c0 < 0 ? 0 : (c0 > we - 1 ? we - 1 : c0);
+    c1 = c1 < 0 ? 0 : (c1 > we - 1 ? we - 1 : c1);
+    const long long g0 = mirror ? (cmax - 1 - c0) : (cmin + c0), g1 = mirror ? (cmax - 1 - c1) : (cmin + c1);
+    const double a = pb_bil64_tap(img, r0, g0, w, channels, ch), b = pb_bil64_tap(img, r0, g1, w, channels, ch);
+    const double c = pb_bil64_tap(img, r1, g0, w, channels, ch), d = pb_bil64_tap(img, r1, g1, w, channels, ch);
+    const double top = a + tx * (b - a), bot = c + tx * (d - c);
+    const double v = rint(top + ty * (bot - top));
+    const double vmax = (double)(SAMPLE)~(SAMPLE)0;
+    return v < 0.0 ? 0.0 : (v > vmax ? vmax : v);
+}
+template <int SRC_KIND, typename SAMPLE>
+__global__ __launch_bounds__(PB_BLOCK) void pb_sample_map_bilinear_kernel(const PbParams P, double* __restrict__ map, unsigned total,
+                                                                          const double* __restrict__ dist_l, const double* __restrict__ dist_r,
+                                                                          const SAMPLE* __restrict__ img, void* __restrict__ out, int channels) {
+    const unsigned p = blockIdx.x * PB_BLOCK + threadIdx.x;
+    if (p >= total) return;
+    double* a = map + 3ull * p;
+    const bool inv = a[2] != 0.0;
+    if (SRC_KIND == PB_KIND_PANO && inv) {
+        a[0] = 0.0;  // polar_map[invalid_map] = 0 writes through the view, projection.py:534-536
+        a[1] = 0.0;
+    }
+    const double lat = a[0], lon = a[1];
+    const int h = P.src.height, w = P.src.width;
+    if (SRC_KIND == PB_KIND_PANO) {
+        const double fy = lat / P.src_hseg, fx = lon / P.src_wseg + P.src_half_w;
+        const bool live = !inv && fabs(fy) < 1.0e300 && fabs(fx) < 1.0e300 && fy == fy && fx == fx;
+        SAMPLE* o = static_cast<SAMPLE*>(out) + (unsigned long long)p * (unsigned)channels;
+        for (int ch = 0; ch < channels; ++ch) o[ch] = live ? (SAMPLE)pb_bil64_sample<SAMPLE, true>(img, fy, fx, h, w, 0, w, false, channels, ch) : (SAMPLE)0;
+        return;
+    }
+    double sl, cl;
+    pb_expi_np(lon, &sl, &cl);  // np.exp(lon * 1j), projection.py:252
+    if (SRC_KIND == PB_KIND_CAMERA) {
+        const double dist = dist_l ? dist_l[p] : pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
+        const double fy = ((sl * dist) * -1.0) + P.src_cy, fx = (cl * dist) + P.src_cx;
+        const bool live = !inv && fy == fy && fx == fx && fabs(fy) < 1.0e300 && fabs(fx) < 1.0e300 && fy >= 0.0 && fy < (double)h && fx >= 0.0 && fx < (double)w;
+        SAMPLE* o = static_cast<SAMPLE*>(out) + (unsigned long long)p * (unsigned)channels;
+        for (int ch = 0; ch < channels; ++ch) o[ch] = live ? (SAMPLE)pb_bil64_sample<SAMPLE, false>(img, fy, fx, h, w, 0, w, false, channels, ch) : (SAMPLE)0;
+        return;
+    }
+    // two eyes (projection.py:408-462): each sampled like a camera source on its half (the right one mirrored), then the reference's blend
+    const double lat_r = (lat * -1.0) + PB_PI;
+    const double dl = dist_l ? dist_l[p] : pb_lens_forward(P.src.lens, lat, P.rect_max) * P.src.f_distance;
+    const double dr = dist_r ? dist_r[p] : pb_lens_forward(P.src.lens, lat_r, P.rect_max) * P.src.f_distance;
+    const int wl = P.src_eye_w, wr = P.src_eye_w_right;
+    const double fyl = ((sl * dl) * -1.0) + P.src_cy, fxl = (cl * dl) + P.src_cx;
+    const double fyr = ((sl * dr) * -1.0) + P.src_cy, fxr = (cl * dr) + P.src_cx_r;
+    const bool live_l = !inv && fyl == fyl && fxl == fxl && fabs(fyl) < 1.0e300 && fabs(fxl) < 1.0e300 && fyl >= 0.0 && fyl < (double)h && fxl >= 0.0 && fxl < (double)wl;
+    const bool live_r = !inv && fyr == fyr && fxr == fxr && fabs(fyr) < 1.0e300 && fabs(fxr) < 1.0e300 && fyr >= 0.0 && fyr < (double)h && fxr >= 0.0 && fxr < (double)wr;
+    const double fl = pb_merge_factor(P, lat), fr = pb_merge_factor(P, lat_r);
+    uint8_t* o = static_cast<uint8_t*>(out) + (unsigned long long)p * (unsigned)channels;  // (left * fl + right * fr).astype(np.uint8): uint8 whatever the samples
+    for (int ch = 0; ch < channels; ++ch) {
+        const double l = live_l ? pb_bil64_sample<SAMPLE, false>(img, fyl, fxl, h, w, 0, wl, false, channels, ch) : 0.0;
+        const double r = live_r ? pb_bil64_sample<SAMPLE, false>(img, fyr, fxr, h, w, wl, wl + wr, true, channels, ch) : 0.0;
+        o[ch] = inv ? (uint8_t)0 : (uint8_t)pb_cvt_u8(l * fl + r * fr);
+    }
+}
+
 // ---- exact coordinate tables ------------------------------------------------------------------------------------------------
 // The faithful tap coordinate s = f - 0.5 of one pixel for one source (or eye), in 1/4096 px, in FRAME space: the right eye's
 // column runs over the mirrored half (w - 1 - s_eye: bilinear interpolation commutes with the mirror, the taps are the frame's
@@ -87,6 +176,13 @@ __device__ __forceinline__ unsigned pb_bilinear_taps(const PbParams& P, const ui
 struct PbBilCoord {
     int32_t y, x;
 };
+// PbTileEntry::bil_off of a tile with a slot: bits 0-19 the slot, bits 20-27 the walk's shear (signed, 1/64 pixel per pixel; the entry's
+// flag PB_TILE_TAB_Y says which way the walk runs); -1 = no slot
+#define PB_BIL_SLOT_MASK 0xFFFFF
+__host__ __device__ __forceinline__ int pb_bil_slot_shift(int bil_off, int p) {
+    const int q = (int)(signed char)((bil_off >> 20) & 0xFF);
+    return (int)rintf((float)q * (1.0f / 64.0f) * ((float)p - 15.5f));
+}
 #define PB_BIL_SHIFT 12
 #define PB_BIL_DEAD ((int32_t)0x80000000)
 #define PB_BIL_MAX_DIM (1 << 18)  // source sides the fixed point holds (the plan keeps the float64 pass beyond)
@@ -308,6 +404,7 @@ __device__ __forceinline__ PbBilTap pb_bil_table_tap(int qy, int qx, int h, int 
     c1 = min(max(c1, cmin), cmax - 1);
     t.o0 = 3u * ((unsigned)r0 * (unsigned)w + (unsigned)c0);
     t.o1 = 3u * ((unsigned)r1 * (unsigned)w + (unsigned)c0);
+    if (PB_BIL_ABL & 1024) t.o0 = t.o1 = 3u * (unsigned)(c0 & 15);  // every tap of a table tile in ONE line: what the scattered lines cost
     t.kind = dead ? -1 : (c1 == c0 + 1 ? 0 : (c1 == c0 ? 1 : 2));
     t.c1off = 3u * (unsigned)(c1 - c0);  // (kind 2: negative, as an unsigned wrap-around - added to o0 / o1)
     return t;
@@ -378,7 +475,8 @@ __device__ __forceinline__ void pb_bil_direct_gather(const uint8_t* __restrict__
             const pb_f2 sv = pb_bil_eval<TD3>(cf, pb_tile_coord(q));
             wy[m] = __builtin_amdgcn_fractf(sv.x);
             wx[m] = __builtin_amdgcn_fractf(sv.y);
-            const unsigned g = gbase + (unsigned)(int)sv.x * rowbytes + __umul24((unsigned)(int)sv.y, 3u);  // (s >= 0.5: truncation is floor)
+            unsigned g = gbase + (unsigned)(int)sv.x * rowbytes + __umul24((unsigned)(int)sv.y, 3u);  // (s >= 0.5: truncation is floor)
+            if (PB_BIL_ABL & 2048) g = gbase + 3u * ((unsigned)(int)sv.y & 15u);  // every tap of a direct tile in ONE line pair: what its scattered lines cost
             if (WIDE) {
                 unsigned long long t0, t1;
                 __builtin_memcpy(&t0, s + g, 8);
@@ -513,16 +611,42 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
     if (!(PB_BIL_PATHS & 4) && e->bil_off >= 0) return;
     if ((PB_BIL_PATHS & 4) && e->bil_off >= 0) {
         PB_MARK("table");
-        const PbBilCoord* __restrict__ t = bil_xy + (size_t)e->bil_off * (PB_TILE * PB_TILE);
-        int4 q[8];  // all sixteen coordinates first: one round trip
+        // Lane = one column (or, PB_TILE_TAB_Y, one row) of the tile, 16 pixels down the other direction, SHEARED along the line of
+        // constant source row like the direct-gather path: the 32 lanes of a half-wave take 32 neighbouring pixels along the direction
+        // in which the source position moves least.  Direction and shear are decided per slot at plan time by
+        // pb_bilinear_orient_kernel, which stores the slot in walk order: the lane's n-th coordinate is t[(2 n + hh) * 32 + p],
+        // 256 contiguous bytes per half-wave, and belongs to pixel (p, (2 n + hh + shift(p)) & 31) - or its transpose.  These are the tiles the models cannot follow - the rim of a
+        // fisheye destination, where one output pixel step along the radius is tens of source rows but a step along the rim almost
+        // none: with 4 x 4 pixels per lane every tap of a load instruction sat in a line of its own (64 lines per instruction, 32
+        // instructions per lane) and c3's 1 506 such tiles cost 10 of its 52 us in the CUs' L1 line rate alone (PB_BIL_ABL=1024).
+        // The blended pixels are regrouped for the 12-byte stores through the wave's LDS, like the direct-gather path's.
+        const PbBilCoord* __restrict__ t = bil_xy + (size_t)(e->bil_off & PB_BIL_SLOT_MASK) * (PB_TILE * PB_TILE);
+        const int p = lane & 31, hh = lane >> 5;
+        const bool by_rows = (flags & PB_TILE_TAB_Y) != 0;
+        const int shift = pb_bil_slot_shift(e->bil_off, p);
+        int2 c[16];  // all sixteen coordinates first: one round trip
 #pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            q[2 * jr] = *reinterpret_cast<const int4*>(t + (yb + 8 * jr) * PB_TILE + 4 * xg);
-            q[2 * jr + 1] = *reinterpret_cast<const int4*>(t + (yb + 8 * jr) * PB_TILE + 4 * xg + 2);
+        for (int n = 0; n < 16; ++n) c[n] = *reinterpret_cast<const int2*>(t + (2 * n + hh) * PB_TILE + p);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            int4 q[4];
+            unsigned o[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = make_int4(c[8 * half + 2 * i].x, c[8 * half + 2 * i].y, c[8 * half + 2 * i + 1].x, c[8 * half + 2 * i + 1].y);
+            pb_bil_table8<WRAP>(s, q, h, w, cmin, cmax, frame_bytes, o);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int a = (2 * (8 * half + m) + hh + shift) & 31;  // (the slot is stored in walk order: entry [2 n + hh][p] is this pixel's)
+                win[by_rows ? p * 33 + a : a * 33 + p] = o[m];  // parked at [y][x], 33-dword pitch
+            }
         }
-        pb_bil_table8<WRAP>(s, &q[0], h, w, cmin, cmax, frame_bytes, &v[0]);
-        pb_bil_table8<WRAP>(s, &q[4], h, w, cmin, cmax, frame_bytes, &v[8]);
+        pb_wave_sync();
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[jr * 4 + k] = win[(yb + 8 * jr) * 33 + 4 * xg + k];
         PB_MARK("end");
+        pb_wave_sync();
         return;
     }
     if (!(flags & (PB_TILE_LEAN | PB_TILE_DIRECT))) {  // BLACK (every other class has a table slot)
@@ -780,12 +904,21 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_do
         return;
     }
     const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
-    pb_load_entry(table_l + tile, entry);
-    const int fl0 = entry.flags, lat_slot = entry.aux_off, nl = entry.fix_cnt, off_l = entry.fix_off;
+    // Two eyes.  The RIGHT eye's entry is on its way into one vector register (lane i = dword i of the 256-byte entry: one coalesced
+    // load, issued before anything else) while the left eye is sampled; the LEFT eye's entry came with the slot (PB_TILE_TWO).  Round 4
+    // fetched both with dependent scalar loads, one before each eye: three serial round trips per two-eye wave before its first
+    // window load, where a one-eye wave makes one (c5's 4 448 two-eye tiles, 13.6 % of its tiles, cost 36 of 106 us).
+    const unsigned rlane = reinterpret_cast<const unsigned*>(table_r + tile)[lane];
+    if (!(entry.flags & PB_TILE_TWO)) pb_load_entry(table_l + tile, entry);
+    const int fl0 = entry.flags & ~PB_TILE_TWO, lat_slot = entry.aux_off, nl = entry.fix_cnt, off_l = entry.fix_off;
     if (entry.bil_off >= 0 && !bil_xy) return;
     unsigned al[16];
     pb_bil_vals<false>(Hd, &entry, fl0, lane, win, windows, src, bil_xy, 0, eye_w, al);
-    pb_load_entry(table_r + tile, entry);
+    {
+        int* w = reinterpret_cast<int*>(&entry);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) w[i] = __builtin_amdgcn_readlane((int)rlane, i);
+    }
     if (entry.bil_off >= 0 && !bil_xy) return;
     const int nr = entry.fix_cnt, off_r = entry.fix_off;
     pb_bil_vals<false>(Hd, &entry, entry.flags, lane, win, windows, src, bil_xy, eye_w, Hd.src_w, a);
@@ -900,6 +1033,63 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_coord_kernel(const PbPar
     c = pb_rotate_all(P, c);
     bil_xy[(size_t)slot * (PB_TILE * PB_TILE) + local] = pb_bil_coord_of<SRC_KIND>(P, c);
 }
+// How a table slot is walked (pb_bil_vals, table path): one block per tile with a slot.  From the slot's own coordinates: gx / gy = the
+// mean change of the source ROW per pixel step in x / in y (neighbour pairs that are both live and less than 64 rows apart: a
+// discontinuity inside the tile - the rim of the image circle - is not a gradient).  The walk runs along the direction with the smaller
+// change (along y: PB_TILE_TAB_Y) and is sheared by slope = -g_along / g_across so that a half-wave follows the line of constant
+// source row; the slot is rewritten in walk order, the shear goes into bil_off.  Speed only: the pixels do not depend on the walk.
+__global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __restrict__ table, PbBilCoord* __restrict__ bil_xy) {
+    __shared__ PbBilCoord tile[PB_TILE * PB_TILE];
+    __shared__ float acc[4];
+    PbTileEntry* e = table + blockIdx.x;
+    const int off = e->bil_off;
+    if (off < 0) return;
+    const int slot = off & PB_BIL_SLOT_MASK;
+    PbBilCoord* t = bil_xy + (size_t)slot * (PB_TILE * PB_TILE);
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0.0f;
+    for (int i = threadIdx.x; i < PB_TILE * PB_TILE; i += 256) tile[i] = t[i];
+    __syncthreads();
+    float sx = 0.f, nx = 0.f, sy = 0.f, ny = 0.f;
+    const int far = 64 << PB_BIL_SHIFT;
+    for (int i = threadIdx.x; i < PB_TILE * PB_TILE; i += 256) {
+        const int x = i & 31, y = i >> 5;
+        const PbBilCoord a = tile[i];
+        if (a.y == PB_BIL_DEAD) continue;
+        if (x + 1 < PB_TILE && tile[i + 1].y != PB_BIL_DEAD) {
+            const int d = tile[i + 1].y - a.y;
+            if (d > -far && d < far) { sx += (float)d; nx += 1.f; }
+        }
+        if (y + 1 < PB_TILE && tile[i + PB_TILE].y != PB_BIL_DEAD) {
+            const int d = tile[i + PB_TILE].y - a.y;
+            if (d > -far && d < far) { sy += (float)d; ny += 1.f; }
+        }
+    }
+    atomicAdd(&acc[0], sx); atomicAdd(&acc[1], nx); atomicAdd(&acc[2], sy); atomicAdd(&acc[3], ny);
+    __syncthreads();
+    const float gx = acc[1] > 0.f ? acc[0] / acc[1] : 0.f, gy = acc[3] > 0.f ? acc[2] / acc[3] : 0.f;
+    const bool by_rows = fabsf(gy) < fabsf(gx);  // the source row changes less down a column: lanes along y
+    const float along = by_rows ? gy : gx, across = by_rows ? gx : gy;
+    float slope = across != 0.f ? -along / across : 0.f;
+    slope = fminf(fmaxf(slope, -1.9f), 1.9f);
+#ifdef PB_BIL_NO_SHEAR  // A/B builds only
+    const int q = 0;
+#else
+    const int q = (int)rintf(slope * 64.0f);
+#endif
+    const int packed = slot | ((q & 0xFF) << 20);
+    __syncthreads();
+    // walk order: entry [a][p] = the coordinate of pixel (p, (a + shift(p)) & 31) (by_rows: of pixel ((a + shift(p)) & 31, p))
+    for (int i = threadIdx.x; i < PB_TILE * PB_TILE; i += 256) {
+        const int p = i & 31, a = i >> 5;
+        const int b = (a + pb_bil_slot_shift(packed, p)) & 31;
+        t[i] = by_rows ? tile[p * PB_TILE + b] : tile[b * PB_TILE + p];
+    }
+    if (threadIdx.x == 0) {
+        e->flags = by_rows ? (e->flags | PB_TILE_TAB_Y) : (e->flags & ~PB_TILE_TAB_Y);
+        e->bil_off = packed;
+    }
+}
+
 // ... and the fix list's: out[item * stride + offset]
 template <int SRC_KIND>
 __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_fix_coord_kernel(const PbParams P, const int32_t* __restrict__ fix_px, int n_fix_px,

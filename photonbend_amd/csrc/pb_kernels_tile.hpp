@@ -795,7 +795,8 @@ __global__ void pb_budget_kernel(PbTileEntry* __restrict__ table, const int32_t*
 __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
                                                               PbTileEntry* __restrict__ ltable, const int* __restrict__ unit_of,
                                                               int units_per_xcd, unsigned n_slots, int unit_side,
-                                                              const PbTileEntry* __restrict__ table_r = nullptr, int unit_side_y = 0) {
+                                                              const PbTileEntry* __restrict__ table_r = nullptr, int unit_side_y = 0,
+                                                              int two_eye_left = 0) {
     const unsigned v = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (v >= n_slots) return;
     const unsigned B = v >> 2, wave = v & 3u;
@@ -835,7 +836,11 @@ __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, 
         const bool solo_r = solo_ok && !solo_l && (fl & PB_TILE_BLACK) && (fr & plain);
         if (solo_l || solo_r) {
             if (solo_r) w = wr;
-            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK | PB_TILE_COARSE | PB_TILE_TD3)) | PB_TILE_SOLO | (solo_r ? PB_TILE_EYE_R : 0);
+            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK | PB_TILE_COARSE | PB_TILE_TD3 | PB_TILE_TAB_Y)) | PB_TILE_SOLO | (solo_r ? PB_TILE_EYE_R : 0);
+        } else if (two_eye_left) {
+            // (the bilinear mode's table: a two-eye slot carries the LEFT eye's entry - the wave has it with its slot, one dependent
+            // scalar round trip less - marked PB_TILE_TWO; the right eye's the wave prefetches into lanes)
+            if ((int)lane == FL) w |= PB_TILE_TWO;
         } else {
             w = 0;
         }

@@ -57,6 +57,8 @@
 // c2's, 62 % of c3's by the coefficient bound alone).  The nearest mode never looks at the flag: its exactness is certified for the
 // full model.
 #define PB_TILE_TD3 8192
+#define PB_TILE_TAB_Y 16384  // bilinear mode, tiles served from the exact coordinate table: the slot is stored transposed and walked by rows (pb_bilinear_orient_kernel)
+#define PB_TILE_TWO 32768  // launch-order table of a double-fisheye plan's bilinear mode only: a two-eye slot that carries the LEFT eye's entry
 #define PB_TILE_W_UNIT_BIT 64  // == PB_TILE_W_UNIT (pb_kernels_double.hpp): blend factors exactly 1.0 for every pixel of the tile
 #define PB_LEAN_MAX_PASSES 24  // window rows / rows-per-load-instruction of a LEAN tile (register staging depth)
 

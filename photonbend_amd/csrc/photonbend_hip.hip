@@ -32,6 +32,9 @@
 #include "pb_kernels_double.hpp"
 #include "pb_kernels_bilinear.hpp"
 
+#ifndef PB_BIL_NO_TWO  // A/B builds only: 1 = two-eye slots of the bilinear launch table only name their tile (round 4's flow)
+#define PB_BIL_NO_TWO 0
+#endif
 #define PB_DOUBLE_FRAMES_PER_WAVE 1  // frames a double-source wave loops over (the rest of a batch is a grid dimension)
 #define PB_WAVES_PER_WG 4  // waves per workgroup of the hot kernel (LDS is released per workgroup)
 struct pb_plan {
@@ -367,6 +370,9 @@ static int pb_build_bilinear_list(pb_plan* pl) {
                 hipLaunchKernelGGL(pb_bilinear_coord_kernel<PB_KIND_CAMERA>, grid, block, 0, 0, P, pl->table, pl->bil_xy);
                 if (np) hipLaunchKernelGGL(pb_bilinear_fix_coord_kernel<PB_KIND_CAMERA>, fgrid, block, 0, 0, P, pl->fix_px, (int)np, pl->bil_fix_xy, 1, 0);
             }
+            // which way each slot is walked (lanes along the direction the source position moves least), slots walked by rows transposed
+            hipLaunchKernelGGL(pb_bilinear_orient_kernel, dim3(pl->n_tiles), dim3(256), 0, 0, pl->table, pl->bil_xy);
+            if (dbl) hipLaunchKernelGGL(pb_bilinear_orient_kernel, dim3(pl->n_tiles), dim3(256), 0, 0, pl->table_r, pl->bil_xy);
             e = hipDeviceSynchronize();
         }
     }
@@ -782,7 +788,7 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, fresh, unit_dev, units_per_xcd, n_slots, (int)U,
-                           pl->dbl_ready ? pl->table_r : nullptr, (int)UY);
+                           pl->dbl_ready ? pl->table_r : nullptr, (int)UY, (bil && pl->dbl_ready && !PB_BIL_NO_TWO) ? 1 : 0);
         e = hipDeviceSynchronize();
     }
     pb_tmp_free(unit_dev);
@@ -836,6 +842,9 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
 // table (the bilinear launches then take the float64 kernels), never with a stale one.  Synchronous.
 #ifndef PB_BIL_WIN_BUDGET
 #define PB_BIL_WIN_BUDGET PB_WINLDS_MAX
+#endif
+#ifndef PB_BIL_LDS_PAD  // occupancy experiments only (experiments/r5/): extra dynamic LDS per workgroup of the bilinear launches (fewer workgroups per CU, same work)
+#define PB_BIL_LDS_PAD 0
 #endif
 //  // measured on MI355X (experiments/r4/budget_bil.sh): c1 28.7 us at 7 KiB, 25.2 at 12; c2 68.9 / 62.0; c5 109.8 / 103.4; c3 58.3 / 58.9
 static int pb_build_bilinear_launch(pb_plan* pl) {
@@ -1357,7 +1366,7 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
                 const uint8_t* sf = src_dev + (unsigned long long)f0 * src_frame_stride;
                 uint8_t* df = dst_dev + (unsigned long long)f0 * dst_frame_stride;
 #define PB_LAUNCH_BILINEAR_DOUBLE(WMODE)                                                                                                       \
-    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, pb_window_lds_bytes(Pb, 8), st, Pb, plan->table, plan->table_r, plan->ltable_bil, rows, \
+    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, pb_window_lds_bytes(Pb, 8) + PB_BIL_LDS_PAD, st, Pb, plan->table, plan->table_r, plan->ltable_bil, rows, \
                        plan->lat_tab, sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy,  \
                        plan->fix_px, plan->bil_fix_xy, plan->dbl_tile_fix, plan->dbl_px_fix)
                 if (rows) PB_LAUNCH_BILINEAR_DOUBLE(1);
@@ -1393,7 +1402,7 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
     do {                                                                                                                             \
         for (int f0 = 0; f0 < n_frames; f0 += per_launch) {                                                                          \
             const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;                                                  \
-            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, pb_window_lds_bytes(Pb), st, pb_hot_of_host(Pb), plan->ltable_bil, \
+            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, pb_window_lds_bytes(Pb) + PB_BIL_LDS_PAD, st, pb_hot_of_host(Pb), plan->ltable_bil, \
                                src_dev + (unsigned long long)f0 * src_frame_stride, dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, \
                                (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy, plan->fix_px, \
                                plan->bil_fix_xy);                                                                                    \
@@ -1619,6 +1628,49 @@ int pb_index_from_map_i32(const pb_proj* src, double* map_dev, int height, int w
     }
     PB_HIP(hipGetLastError());
     return PB_OK;
+}
+
+int pb_sample_map_bilinear_px(const pb_proj* src, double* map_dev, int height, int width, const double* dist_l_dev, const double* dist_r_dev,
+                              const void* img_dev, void* out_dev, int channels, int sample_bytes, void* stream) {
+    std::string why;
+    if (!map_dev || !img_dev || !out_dev) return pb_fail(PB_ERR_INVALID, "null argument");
+    if (!pb_end_ok(src, why, PB_ROLE_SRC | PB_ROLE_CUSTOM_OK)) return pb_fail(PB_ERR_INVALID, why);
+    if (height < 1 || width < 1 || (long long)height * width > 0x7FFFFFFFll / 4) return pb_fail(PB_ERR_INVALID, "map size out of range");
+    if (channels < 1 || channels > 16) return pb_fail(PB_ERR_INVALID, "channels outside [1, 16]");
+    if (sample_bytes != 1 && sample_bytes != 2) return pb_fail(PB_ERR_INVALID, "sample_bytes must be 1 or 2");
+    if (src->kind != PB_KIND_PANO && src->lens == PB_LENS_CUSTOM && !dist_l_dev)
+        return pb_fail(PB_ERR_INVALID, "a PB_LENS_CUSTOM source needs the host-evaluated distance plane(s)");
+    if (src->kind == PB_KIND_DOUBLE && dist_l_dev && !dist_r_dev) return pb_fail(PB_ERR_INVALID, "a double source needs both distance planes");
+    if (src->kind == PB_KIND_PANO && (dist_l_dev || dist_r_dev)) return pb_fail(PB_ERR_INVALID, "a panorama source has no lens");
+    PbParams P;
+    memset(&P, 0, sizeof(P));
+    P.src = pb_to_end(src);
+    P.dst = P.src;
+    P.dst.kind = PB_KIND_PANO;  // only the source half of the parameters is used
+    P.dst.height = height;
+    P.dst.width = width;
+    pb_derive(P);
+    const unsigned total = (unsigned)height * (unsigned)width;
+    hipStream_t st = (hipStream_t)stream;
+#define PB_LAUNCH_MAP_BIL(KIND, SAMPLE)                                                                                                  \
+    hipLaunchKernelGGL((pb_sample_map_bilinear_kernel<KIND, SAMPLE>), dim3(pb_blocks(total)), dim3(PB_BLOCK), 0, st, P, map_dev, total, dist_l_dev, \
+                       dist_r_dev, static_cast<const SAMPLE*>(img_dev), out_dev, channels)
+    if (sample_bytes == 1) {
+        if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_MAP_BIL(PB_KIND_PANO, uint8_t);
+        else if (P.src.kind == PB_KIND_CAMERA) PB_LAUNCH_MAP_BIL(PB_KIND_CAMERA, uint8_t);
+        else PB_LAUNCH_MAP_BIL(PB_KIND_DOUBLE, uint8_t);
+    } else {
+        if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_MAP_BIL(PB_KIND_PANO, uint16_t);
+        else if (P.src.kind == PB_KIND_CAMERA) PB_LAUNCH_MAP_BIL(PB_KIND_CAMERA, uint16_t);
+        else PB_LAUNCH_MAP_BIL(PB_KIND_DOUBLE, uint16_t);
+    }
+#undef PB_LAUNCH_MAP_BIL
+    PB_HIP(hipGetLastError());
+    return PB_OK;
+}
+
+int pb_sample_map_bilinear_u8(const pb_proj* src, double* map_dev, int height, int width, const uint8_t* src_dev, uint8_t* dst_dev, void* stream) {
+    return pb_sample_map_bilinear_px(src, map_dev, height, width, nullptr, nullptr, src_dev, dst_dev, 3, 1, stream);
 }
 
 int pb_gather_px(const int32_t* idx_dev, const void* src_dev, void* dst_dev, size_t n_px, int bytes_per_px, void* stream) {

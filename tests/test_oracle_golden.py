@@ -256,3 +256,24 @@ def test_restated_math_is_clean_under_the_sanitizers(tmp_path):
         got, want = np.fromfile(dst, dtype=np.uint64)[: gold[fn].size], gold[fn]
         both_nan = np.isnan(got.view(np.float64)) & np.isnan(want.view(np.float64))
         assert bool(((got == want) | both_nan).all()), fn
+
+
+def test_oracle_with_callable_lenses_reproduces_the_generic_goldens():
+    """Round 5: the oracle takes a Lens of user callables as a (forward, reverse) pair (tests/helpers.py: orc_proj).  Pinned here against
+    the REFERENCE's outputs for every generic case - grey / RGBA / 16-bit images, user lenses on either end, nine rotations, odd-width
+    double frames (tests/golden/generic.npz, captured from photonbend itself) - before the GPU tests use that oracle as the checker of
+    the bilinear mode's map path."""
+    import warnings
+
+    from oracle.synth import synth_image
+    from tests import cases as tc
+    from tests import helpers as H
+
+    gold = np.load(os.path.join(H.GOLD, "generic.npz"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, case, layout in tc.generic_cases():
+            _, h, w, *_ = case.src
+            img = synth_image(h, w, layout, frame=3, circle_mask=case.mask)
+            got = orc.remap(H.orc_proj(case.dst), H.orc_proj(case.src), img, H.orc_rots(case))
+            assert got.dtype == gold[name].dtype and np.array_equal(got, gold[name]), name
