@@ -98,7 +98,7 @@ def self_launch(args) -> int:
     backend = os.environ.get("PB_DIST_BACKEND", "nccl")
     have = torch.cuda.device_count()  # counting devices does not initialise the runtime
     if backend == "nccl" and have < args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible (PB_DIST_BACKEND=gloo lets ranks share a GPU for rehearsal)", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible (PB_DIST_BACKEND=gloo lets ranks share a GPU for rehearsal - at most 5 ranks on this pool: its boxes allow six GPU processes, this launcher included)", file=sys.stderr)
         return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
@@ -706,6 +706,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("PB_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        # rehearsal aid (tests/test_bench_launcher.py): this rank dies before it joins the group - the launcher must end the other ranks
+        # and the whole command must exit non-zero, never print a line for fewer ranks than asked for
+        print(f"bench.py: rank {rank} exits on request (PB_BENCH_FAIL_RANK)", file=sys.stderr)
+        os._exit(3)
     cfg = CONFIGS[args.config]
     batch = args.batch or cfg["batch"]
     pool = args.pool or max(cfg["pool"], POOL_BYTES_MIN // (3 * (cfg["src"][1] * cfg["src"][2] + cfg["dst"][1] * cfg["dst"][2])) + 1)
@@ -956,7 +961,10 @@ def main():
             pass
         torch.cuda.empty_cache()
         sharded = {}
+        shard_cap = int(os.environ.get("PB_SHARD_FRAMES", "0"))  # rehearsals on a shared card: fewer frames per rank than BASELINE's 64 / 32 (0: BASELINE's)
         for wname, cname, per_rank in (("c4", "c2", 64), ("c5", "c5", 32)):
+            if shard_cap > 0:
+                per_rank = min(per_rank, shard_cap)
             passes = 3
             dt_w, n_mine, digest, first_k, wplan, (wd, ws, wcfg) = sharded_workload(lib, nat, parallel, cname, per_rank, rank, world, device, coll_device, sts[0], dist, passes=passes)
             tw = torch.tensor([dt_w], dtype=torch.float64, device=coll_device)
