@@ -83,6 +83,9 @@ typedef struct pb_plan pb_plan; /* opaque, immutable after creation */
 
 /* ---- library / device ------------------------------------------------- */
 int pb_abi_version(void);
+/* 0: the float64 chain runs NumPy's AVX-512 arcsin / arccos / arctan / tan (hosts with AVX512_SKX); 1: glibc's (hosts without).  See
+ * PB_PLAN_MATH_SVML / PB_PLAN_MATH_LIBM. */
+int pb_math_flavour(void);
 const char* pb_last_error(void); /* thread-local, valid until the next failing call */
 int pb_init(int device);         /* hipSetDevice + sanity checks (gfx950 expected) */
 int pb_shutdown(void);
@@ -115,6 +118,16 @@ void pb_plan_destroy(pb_plan* plan);
  * Creation never times anything or allocates frame-sized memory unless PB_PLAN_TUNE is given. */
 #define PB_PLAN_DEFER 1u
 #define PB_PLAN_TUNE 2u
+/* MATH FLAVOURS (ABI 5).  The reference's float64 results depend on which code NumPy dispatches to on the HOST it runs on: with
+ * AVX512_SKX np.arcsin / arccos / arctan / tan (core/lens.py:71-307, core/rotation.py:158) are NumPy's own AVX-512 kernels, without it
+ * they are libm's (glibc 2.35: asin / acos / atan / tan) - 7-8 % of the arcsin / arccos results differ in the last bit, and with them
+ * whole texels of identity-type remaps.  The library comes in both flavours, built from the same sources: libphotonbend_hip.so
+ * (pb_math_flavour() == 0: the AVX-512 kernels' bits, the platform of tests/golden/) and libphotonbend_hip_libm.so (== 1: libm's bits,
+ * tests/golden/npmath_libm.npz, libm_flavour.json); a host loads the one that matches ITS reference (photonbend_amd/_native.py does:
+ * NumPy's own dispatch decides, PB_MATH_FLAVOUR=svml|libm overrides).  The two flags below let a caller STATE which flavour a plan must
+ * have: pb_plan_create_ex returns PB_ERR_UNSUPPORTED from the library of the other flavour instead of silently giving other bits. */
+#define PB_PLAN_MATH_SVML 4u
+#define PB_PLAN_MATH_LIBM 8u
 int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, unsigned flags,
                       int win_budget, pb_plan** out);
 /* Builds the fast path of a deferred plan on the current device (flags: 0 or PB_PLAN_TUNE).  On a prepared plan

@@ -480,6 +480,102 @@ def gen_npmath():
     print("npmath.npz written:", meta)
 
 
+NO_AVX512 = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR AVX512_KNL AVX512_KNM"
+
+
+def gen_npmath_libm():
+    """The SECOND math flavour's pins: NumPy's result bits for np.arcsin / arccos / arctan / tan on the arguments of
+    tests/npmath_args.py when NumPy runs WITHOUT its AVX-512 kernels (NPY_DISABLE_CPU_FEATURES: what every x86-64 host without AVX512_SKX
+    does) - there it calls libm, here glibc 2.35's asin / acos / atan / tan (`_fma` builds).  np.sin / np.cos / np.exp(1j x) / np.log(z).imag
+    do not change (asserted equal to npmath.npz).  Written by a child process, since the dispatch is fixed when NumPy is imported."""
+    import subprocess
+
+    if os.environ.get("PB_NPMATH_LIBM_CHILD") != "1":
+        env = dict(os.environ, NPY_DISABLE_CPU_FEATURES=NO_AVX512, PB_NPMATH_LIBM_CHILD="1")
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--npmath-libm"], env=env, check=True)
+        return
+    from tests import npmath_args
+
+    try:
+        from numpy._core._multiarray_umath import __cpu_features__ as feats
+    except ImportError:
+        from numpy.core._multiarray_umath import __cpu_features__ as feats
+    assert not feats.get("AVX512_SKX") and not feats.get("AVX512F"), "the AVX-512 kernels are still dispatched"
+    import ctypes
+
+    libc = ctypes.CDLL(None)
+    libc.gnu_get_libc_version.restype = ctypes.c_char_p
+    first = np.load(os.path.join(GOLD, "npmath.npz"))
+    arrays, share = {}, {}
+    for fn in npmath_args.FUNCTIONS:
+        x = npmath_args.arguments(fn)
+        with np.errstate(all="ignore"):
+            y = npmath_args.reference(fn, x)
+        if fn in ("arcsin", "arccos", "arctan", "tan"):
+            arrays[fn] = y
+            nan = np.isnan(y.view(np.float64)) & np.isnan(first[fn].view(np.float64))
+            share[fn] = float(((y != first[fn]) & ~nan).mean())
+        else:
+            assert np.array_equal(y, first[fn]), f"{fn} changed with the dispatch: it should be glibc on both kinds of host"
+    meta = {"numpy": np.__version__, "glibc": libc.gnu_get_libc_version().decode(), "AVX512_SKX": False, "FMA3": bool(feats.get("FMA3")),
+            "NPY_DISABLE_CPU_FEATURES": NO_AVX512, "arguments": "tests/npmath_args.py", "n": int(npmath_args.N_PER_FUNCTION),
+            "share_of_results_differing_from_the_first_flavour": share}
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "npmath_libm.npz"), **arrays)
+    print("npmath_libm.npz written:", meta)
+
+
+def gen_libm_flavour():
+    """tests/golden/libm_flavour.json: what the REFERENCE returns for the small and the mid cases on a host without AVX512_SKX (NumPy's
+    arcsin / arccos / arctan / tan = libm's) - per case the SHA-256 of every float64 map stage (NaNs canonicalised), of the index map(s)
+    and of the output bytes, plus how many index entries differ from the first flavour's goldens.  A child process under
+    NPY_DISABLE_CPU_FEATURES (the dispatch is fixed at import); the oracle is asserted equal to the reference on every case there too."""
+    import subprocess
+
+    if os.environ.get("PB_NPMATH_LIBM_CHILD") != "1":
+        env = dict(os.environ, NPY_DISABLE_CPU_FEATURES=NO_AVX512, PB_NPMATH_LIBM_CHILD="1")
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--libm-flavour"], env=env, check=True)
+        return
+    try:
+        from numpy._core._multiarray_umath import __cpu_features__ as feats
+    except ImportError:
+        from numpy.core._multiarray_umath import __cpu_features__ as feats
+    assert not feats.get("AVX512_SKX") and not feats.get("AVX512F"), "the AVX-512 kernels are still dispatched"
+    small = np.load(os.path.join(GOLD, "small.npz"))
+    mid = json.load(open(os.path.join(GOLD, "mid.json")))
+    out = {}
+    for case in small_cases() + mid_cases():
+        dst, cmap, stages, mats = ref_map(case)
+        kind, h, w, *_ = case.src
+        frame = synth_frame(h, w, frame=0, seed=0, circle_mask=case.mask)
+        src = ref_obj(case.src, frame)
+        idx = ref_index(case, cmap)
+        u8 = src.process_coordinate_map(np.copy(cmap))
+        od, os_ = orc_proj(case.dst), orc_proj(case.src)
+        rots = [tuple(map(to_radians, r)) for r in case.rotations]
+        oidx = orc.remap_index(od, os_, rots)
+        n = case.name
+        rec = {"map_sha256": [canonical_map_sha(st) for st in stages], "u8_sha256": sha(u8)}
+        if kind == "double":
+            assert np.array_equal(oidx[0], idx[0]) and np.array_equal(oidx[1], idx[1]), n
+            rec["idx_l_sha256"], rec["idx_r_sha256"] = sha(np.ascontiguousarray(idx[0], dtype=np.int32)), sha(np.ascontiguousarray(idx[1], dtype=np.int32))
+            if f"{n}/idx_l" in small.files:
+                rec["index_entries_differing_from_first_flavour"] = int((small[f"{n}/idx_l"] != idx[0]).sum() + (small[f"{n}/idx_r"] != idx[1]).sum())
+        else:
+            assert np.array_equal(oidx, idx), n
+            rec["idx_sha256"] = sha(np.ascontiguousarray(idx, dtype=np.int32))
+            if f"{n}/idx" in small.files:
+                rec["index_entries_differing_from_first_flavour"] = int((small[f"{n}/idx"] != idx).sum())
+            elif n in mid:
+                rec["same_index_map_as_first_flavour"] = bool(mid[n]["idx_sha256"] == rec["idx_sha256"])
+        assert np.array_equal(orc.remap(od, os_, frame, rots), u8), n
+        out[n] = rec
+        print(f"  {n}: ok", {k: v for k, v in rec.items() if not k.endswith("sha256")})
+    meta = {"numpy": np.__version__, "NPY_DISABLE_CPU_FEATURES": NO_AVX512, "cases": len(out)}
+    json.dump({"meta": meta, "cases": out}, open(os.path.join(GOLD, "libm_flavour.json"), "w"), indent=0)
+    print("libm_flavour.json written,", len(out), "cases")
+
+
 def canonical_map_sha(m):
     """SHA-256 of a float64 coordinate map's bits with every NaN replaced by the one canonical quiet NaN (payloads and signs of NaNs are
     not part of any contract; signed zeros and everything else are)."""
@@ -519,8 +615,16 @@ if __name__ == "__main__":
     ap.add_argument("--mid", action="store_true")
     ap.add_argument("--generic", action="store_true")
     ap.add_argument("--npmath", action="store_true", help="NumPy's arcsin / arccos / arctan / tan result bits (tests/golden/npmath.npz)")
+    ap.add_argument("--npmath-libm", action="store_true", help="the same four functions as NumPy computes them WITHOUT AVX-512 (libm): tests/golden/npmath_libm.npz")
+    ap.add_argument("--libm-flavour", action="store_true", help="map / index / byte hashes of the small and mid cases under the no-AVX-512 dispatch: tests/golden/libm_flavour.json")
     ap.add_argument("--maps", action="store_true", help="only add the float64 map hashes of the mid and full cases to mid.json / full.json")
     a = ap.parse_args()
+    if a.npmath_libm or a.libm_flavour:  # (second-flavour fixtures: generated on request only - they re-run this script under another NumPy dispatch)
+        if a.npmath_libm:
+            gen_npmath_libm()
+        if a.libm_flavour:
+            gen_libm_flavour()
+        sys.exit(0)
     everything = not (a.full_bilinear or a.full_raw or a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic or a.npmath or a.maps)
     os.makedirs(GOLD, exist_ok=True)
     if a.lens or everything:

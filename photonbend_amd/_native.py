@@ -25,11 +25,33 @@ except ImportError:  # the NumPy workflow needs no torch
     torch = None
 
 from ._device import DeviceArray
-from .build import LIB_PATH
+from . import build as _build
+
+
+def host_math_flavour() -> str:
+    """Which code THIS host's NumPy runs for np.arcsin / arccos / arctan / tan - and so which bits the reference would print here:
+    "svml" (NumPy's AVX-512 kernels: x86-64 Linux with AVX512_SKX) or "libm" (everything else: the platform's libm).  PB_MATH_FLAVOUR
+    overrides.  The library is loaded in the same flavour (include/photonbend_hip.h, "MATH FLAVOURS")."""
+    env = os.environ.get("PB_MATH_FLAVOUR", "").lower()
+    if env in ("svml", "libm"):
+        return env
+    try:
+        try:
+            from numpy._core._multiarray_umath import __cpu_features__ as feats
+        except ImportError:
+            from numpy.core._multiarray_umath import __cpu_features__ as feats
+    except Exception:
+        return "svml"
+    return "svml" if feats.get("AVX512_SKX") else "libm"
+
+
+MATH_FLAVOUR = host_math_flavour()
+# PB_LIB_PATH: another build of the same sources (A/B experiments, the diagnostic build); else the product library of the host's flavour
+LIB_PATH = os.environ.get("PB_LIB_PATH") or (_build.LIBM_LIB_PATH if MATH_FLAVOUR == "libm" else _build.LIB_PATH)
 
 ABI_VERSION = 5
 PB_MAX_ROTATIONS = 8
-PLAN_DEFER, PLAN_TUNE = 1, 2
+PLAN_DEFER, PLAN_TUNE, PLAN_MATH_SVML, PLAN_MATH_LIBM = 1, 2, 4, 8
 MODE_AUTO, MODE_FAITHFUL, MODE_FAST, MODE_FAST_DIRECT = 0, 1, 2, 3
 KIND_CAMERA, KIND_DOUBLE, KIND_PANO = 0, 1, 2
 LENS_IDS = {
@@ -66,6 +88,7 @@ class pb_proj(C.Structure):
 _VP = C.c_void_p
 SIGNATURES = {
     "pb_abi_version": (C.c_int, []),
+    "pb_math_flavour": (C.c_int, []),
     "pb_last_error": (C.c_char_p, []),
     "pb_init": (C.c_int, [C.c_int]),
     "pb_shutdown": (C.c_int, []),
@@ -146,7 +169,7 @@ def load() -> C.CDLL:
             return _lib
         if not os.path.exists(LIB_PATH):
             raise PbError(
-                f"{LIB_PATH} is missing - build it with `python -m photonbend_amd.build` "
+                f"{LIB_PATH} is missing - build it with `python -m photonbend_amd.build{' --libm' if MATH_FLAVOUR == 'libm' else ''}` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
             )
         lib = C.CDLL(LIB_PATH)
@@ -156,6 +179,8 @@ def load() -> C.CDLL:
             fn.argtypes = args
         if lib.pb_abi_version() != ABI_VERSION:
             raise PbError(f"ABI version mismatch: library says {lib.pb_abi_version()}, binding expects {ABI_VERSION}")
+        if not os.environ.get("PB_LIB_PATH") and lib.pb_math_flavour() != (1 if MATH_FLAVOUR == "libm" else 0):
+            raise PbError(f"{LIB_PATH} is not the {MATH_FLAVOUR} flavour of the library")
         _lib = lib
     return _lib
 

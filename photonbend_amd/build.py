@@ -11,8 +11,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libphotonbend_hip.so"
-# PB_LIB_PATH: load another build of the same sources (A/B experiments: -DPB_STAMPS, -DPB_ABLATION); the product is the in-tree file
-LIB_PATH = os.environ.get("PB_LIB_PATH") or os.path.join(HERE, LIB_NAME)
+# the product library of the FIRST math flavour (what _native.py loads on a host with AVX512_SKX; PB_LIB_PATH there loads another build
+# of the same sources - A/B experiments: -DPB_STAMPS, -DPB_ABLATION)
+LIB_PATH = os.path.join(HERE, LIB_NAME)
 
 # -ffp-contract=off: the reference rounds every multiply and add separately; the
 # kernels fuse only where they say fma() (see csrc/pb_stages.hpp).
@@ -70,6 +71,19 @@ def build_library(force: bool = False, verbose: bool = False, out: str = None, d
     return out
 
 
+# The SECOND MATH FLAVOUR of the same sources (-DPB_MATH_LIBM, csrc/pb_math.hpp): np.arcsin / arccos / arctan / tan as an x86-64 host
+# WITHOUT AVX512_SKX computes them (glibc's asin / acos / atan / tan instead of NumPy's AVX-512 kernels).  A product library like the
+# first: _native.py loads the one that matches the host's own NumPy dispatch (PB_MATH_FLAVOUR overrides).
+LIBM_LIB_NAME = "libphotonbend_hip_libm.so"
+LIBM_LIB_PATH = os.path.join(HERE, LIBM_LIB_NAME)
+
+
+def build_libm_flavour(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(LIBM_LIB_PATH) and not _stale_against(LIBM_LIB_PATH):
+        return LIBM_LIB_PATH
+    return build_library(force=True, verbose=verbose, out=LIBM_LIB_PATH, defines=("PB_MATH_LIBM",))
+
+
 # NOT in the package directory: only the product library sits next to _native.py (build/ is git-ignored and travels to the GPU box)
 DIAG_LIB_PATH = os.path.join(os.path.dirname(HERE), "build", "libphotonbend_hip_diag.so")
 
@@ -92,5 +106,7 @@ def _stale_against(path: str) -> bool:
 
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    if "--libm" in sys.argv:
+        print(build_libm_flavour(force=True, verbose=True))
     if "--diag" in sys.argv:
         print(build_diagnostic(force=True, verbose=True))

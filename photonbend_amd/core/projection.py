@@ -49,7 +49,7 @@ def _disk_cache_path(key) -> Union[str, None]:
     if not root:
         return None
     lib_stamp = str(os.path.getmtime(nat.LIB_PATH)) if os.path.exists(nat.LIB_PATH) else "?"
-    digest = hashlib.sha256(repr((key[1:], lib_stamp, nat.ABI_VERSION)).encode()).hexdigest()[:32]
+    digest = hashlib.sha256(repr((key[1:], lib_stamp, nat.ABI_VERSION, nat.MATH_FLAVOUR)).encode()).hexdigest()[:32]
     return os.path.join(root, f"plan_{digest}.pbplan")
 
 

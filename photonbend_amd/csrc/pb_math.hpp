@@ -27,3 +27,25 @@
 
 #include "pb_math_np.hpp"
 #include "pb_math_glibc.hpp"
+
+// ---- the second math flavour (round 5) ------------------------------------------------------------------------------------------
+// On an x86-64 host WITHOUT AVX512_SKX NumPy has no SIMD kernel for arcsin / arccos / arctan / tan and calls libm: the reference's bits
+// there are glibc 2.35's asin / acos / atan / tan (the `_fma` builds), which differ from the SVML kernels on 8-17 % of the arguments.
+// A build with -DPB_MATH_LIBM (libphotonbend_hip_libm.so; photonbend_amd/build.py) runs THOSE functions in the float64 chain -
+// pb_math_libm.hpp, generated instruction by instruction from the machine code (gen_libm_flavour.py), pinned by
+// tests/golden/npmath_libm.npz - and is otherwise the same library.  np.sin / np.cos / np.exp(1j x) / np.log(z).imag are glibc on both
+// kinds of host: pb_math_glibc.hpp serves both flavours.  pb_asin_svml ... keep the first flavour's functions reachable for the bit checks.
+#include "pb_math_libm.hpp"
+PB_MATH_FN double pb_asin_svml(double x) { return pb_asin_np(x); }
+PB_MATH_FN double pb_acos_svml(double x) { return pb_acos_np(x); }
+PB_MATH_FN double pb_atan_svml(double x) { return pb_atan_np(x); }
+PB_MATH_FN double pb_tan_svml(double x) { return pb_tan_np(x); }
+#ifdef PB_MATH_LIBM
+#define pb_asin_np pb_asin_libm
+#define pb_acos_np pb_acos_libm
+#define pb_atan_np pb_atan_libm
+#define pb_tan_np pb_tan_libm
+#define PB_MATH_FLAVOUR 1
+#else
+#define PB_MATH_FLAVOUR 0
+#endif

@@ -1029,6 +1029,7 @@ static int pb_plan_prepare_full(pb_plan* pl, unsigned flags, int win_budget) {
 extern "C" {
 
 int pb_abi_version(void) { return PB_ABI_VERSION; }
+int pb_math_flavour(void) { return PB_MATH_FLAVOUR; }
 const char* pb_last_error(void) { return g_err.c_str(); }
 
 int pb_init(int device) {
@@ -1058,7 +1059,12 @@ int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const
     if (!pb_end_ok(dst, why, PB_ROLE_DST) || !pb_end_ok(src, why, PB_ROLE_SRC)) return pb_fail(PB_ERR_INVALID, why);
     if (n_rot < 0 || n_rot > PB_MAX_ROTATIONS) return pb_fail(PB_ERR_INVALID, "n_rot outside [0, PB_MAX_ROTATIONS]");
     if (n_rot > 0 && !rot3x3) return pb_fail(PB_ERR_INVALID, "null rotation matrices");
-    if (flags & ~(unsigned)(PB_PLAN_DEFER | PB_PLAN_TUNE)) return pb_fail(PB_ERR_INVALID, "unknown plan flags");
+    if (flags & ~(unsigned)(PB_PLAN_DEFER | PB_PLAN_TUNE | PB_PLAN_MATH_SVML | PB_PLAN_MATH_LIBM)) return pb_fail(PB_ERR_INVALID, "unknown plan flags");
+    if ((flags & PB_PLAN_MATH_SVML) && (flags & PB_PLAN_MATH_LIBM)) return pb_fail(PB_ERR_INVALID, "a plan has one math flavour");
+    if (((flags & PB_PLAN_MATH_SVML) && PB_MATH_FLAVOUR != 0) || ((flags & PB_PLAN_MATH_LIBM) && PB_MATH_FLAVOUR != 1))
+        return pb_fail(PB_ERR_UNSUPPORTED, PB_MATH_FLAVOUR ? "this is libphotonbend_hip_libm.so (the float64 chain runs glibc's asin / acos / atan / tan): load libphotonbend_hip.so for the AVX-512 (SVML) flavour"
+                                                           : "this is libphotonbend_hip.so (the float64 chain runs NumPy's AVX-512 arcsin / arccos / arctan / tan): load libphotonbend_hip_libm.so for the libm flavour");
+    flags &= ~(unsigned)(PB_PLAN_MATH_SVML | PB_PLAN_MATH_LIBM);
     if (win_budget < 0) return pb_fail(PB_ERR_INVALID, "negative window budget");
     pb_plan* pl = new (std::nothrow) pb_plan();
     if (!pl) return pb_fail(PB_ERR_INVALID, "out of host memory");
@@ -1453,10 +1459,14 @@ __global__ void pb_debug_math_kernel(int fn, const double* __restrict__ in, doub
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     switch (fn) {
-        case 0: out[i] = pb_asin_np(in[i]); break;
-        case 1: out[i] = pb_acos_np(in[i]); break;
-        case 2: out[i] = pb_atan_np(in[i]); break;
-        case 3: out[i] = pb_tan_np(in[i]); break;
+        case 0: out[i] = pb_asin_svml(in[i]); break;
+        case 1: out[i] = pb_acos_svml(in[i]); break;
+        case 2: out[i] = pb_atan_svml(in[i]); break;
+        case 3: out[i] = pb_tan_svml(in[i]); break;
+        case 8: out[i] = pb_asin_libm(in[i]); break;
+        case 9: out[i] = pb_acos_libm(in[i]); break;
+        case 10: out[i] = pb_atan_libm(in[i]); break;
+        case 11: out[i] = pb_tan_libm(in[i]); break;
         case 4: out[i] = pb_sin_np(in[i]); break;
         case 5: out[i] = pb_cos_np(in[i]); break;
         case 6: pb_expi_np(in[i], &out[2 * i], &out[2 * i + 1]); break;
@@ -1464,9 +1474,10 @@ __global__ void pb_debug_math_kernel(int fn, const double* __restrict__ in, doub
     }
 }
 extern "C" {
-// fn (the order of tests/npmath_args.py FUNCTIONS): 0 arcsin, 1 arccos, 2 arctan, 3 tan, 4 sin, 5 cos of n values; 6: np.exp(x * 1j) -> (imag, real) interleaved; 7: n (y, x) pairs -> np.log(x + 1j y).imag
+// fn (the order of tests/npmath_args.py FUNCTIONS): 0 arcsin, 1 arccos, 2 arctan, 3 tan, 4 sin, 5 cos of n values; 6: np.exp(x * 1j) -> (imag, real) interleaved; 7: n (y, x) pairs -> np.log(x + 1j y).imag;
+// 8-11: arcsin, arccos, arctan, tan of the second math flavour (pb_math_libm.hpp)
 __attribute__((visibility("default"))) int pb_debug_math(int fn, const double* in_dev, double* out_dev, size_t n, void* stream) {
-    if (!in_dev || !out_dev || fn < 0 || fn > 7) return pb_fail(PB_ERR_INVALID, "bad argument");
+    if (!in_dev || !out_dev || fn < 0 || fn > 11) return pb_fail(PB_ERR_INVALID, "bad argument");
     if (n) hipLaunchKernelGGL(pb_debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, in_dev, out_dev, n);
     PB_HIP(hipGetLastError());
     return PB_OK;

@@ -1,0 +1,98 @@
+"""The SECOND math flavour end to end: libphotonbend_hip_libm.so - the same sources with the float64 chain's
+arcsin / arccos / arctan / tan replaced by glibc's (what NumPy runs on an x86-64 host without AVX512_SKX) - against
+tests/golden/libm_flavour.json: the REFERENCE's own results for the 59 small and the 13 mid cases when it runs under
+NPY_DISABLE_CPU_FEATURES (oracle/make_goldens.py --libm-flavour).  Done = every float64 map stage 0 ulp (equal SHA-256), every index map
+and every output byte equal, identity remaps included - as for the first flavour against small.npz / mid.json.  A child process with
+PB_MATH_FLAVOUR=libm (the flavour is the library a process loads)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import hashlib, json, sys
+import numpy as np
+import torch
+import photonbend_amd as pb
+from photonbend_amd import _native as nat
+from tests import helpers as H
+from tests.cases import small_cases, mid_cases
+from oracle.synth import synth_frame
+assert nat.MATH_FLAVOUR == "libm" and nat.load().pb_math_flavour() == 1 and nat.LIB_PATH.endswith("libphotonbend_hip_libm.so")
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+out = {}
+for case in small_cases() + mid_cases():
+    rec = {"map_sha256": [H.canonical_map_sha(m) for m in H.pb_map_stages(case)]}
+    plan = H.pb_plan_private(case)
+    idx = plan.index_map()
+    idx = idx.cpu().numpy() if hasattr(idx, "cpu") else idx.numpy()
+    if case.src[0] == "double":
+        rec["idx_l_sha256"], rec["idx_r_sha256"] = sha(idx[0].astype(np.int32)), sha(idx[1].astype(np.int32))
+    else:
+        rec["idx_sha256"] = sha(idx.astype(np.int32))
+    frame = synth_frame(case.src[1], case.src[2], frame=0, seed=0, circle_mask=case.mask)
+    src, cmap = H.pb_chain(case, frame)
+    rec["u8_sha256"] = sha(src.process_coordinate_map(cmap))          # first use of the geometry: the float64 kernel
+    rec["u8_fast_sha256"] = sha(plan.remap(torch.from_numpy(frame).cuda()).cpu().numpy())  # the prepared plan's tile kernels
+    out[case.name] = rec
+# the flags of pb_plan_create_ex state the flavour: this library refuses the other one
+import ctypes as C
+d, s = nat.make_proj(nat.KIND_PANO, 32, 64), nat.make_proj(nat.KIND_PANO, 32, 64)
+h = C.c_void_p()
+rc_other = nat.load().pb_plan_create_ex(C.byref(d), None, 0, C.byref(s), nat.PLAN_DEFER | nat.PLAN_MATH_SVML, 0, C.byref(h))
+rc_same = nat.load().pb_plan_create_ex(C.byref(d), None, 0, C.byref(s), nat.PLAN_DEFER | nat.PLAN_MATH_LIBM, 0, C.byref(h))
+if rc_same == 0:
+    nat.load().pb_plan_destroy(h)
+out["_flags"] = [rc_other, rc_same]
+json.dump(out, open(sys.argv[1], "w"))
+"""
+
+
+@pytest.mark.gpu
+def test_libm_flavour_library_reproduces_the_reference_without_avx512(tmp_path):
+    from photonbend_amd.build import LIBM_LIB_PATH
+
+    if not os.path.exists(LIBM_LIB_PATH):
+        pytest.skip("needs the second-flavour build (python -m photonbend_amd.build --libm)")
+    res_path = str(tmp_path / "res.json")
+    env = dict(os.environ, PB_MATH_FLAVOUR="libm")
+    env.pop("PB_LIB_PATH", None)
+    res = subprocess.run([sys.executable, "-c", _WORKER, res_path], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    got = json.load(open(res_path))
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "libm_flavour.json")))["cases"]
+    assert got.pop("_flags") == [-3, 0], "PB_PLAN_MATH_SVML must be refused (PB_ERR_UNSUPPORTED) and PB_PLAN_MATH_LIBM accepted by this library"
+    assert set(got) == set(want) and len(got) == 72
+    bad = []
+    for name, w in want.items():
+        g = got[name]
+        for key in ("map_sha256", "idx_sha256", "idx_l_sha256", "idx_r_sha256", "u8_sha256"):
+            if key in w and g.get(key) != w[key]:
+                bad.append((name, key))
+        if g["u8_fast_sha256"] != w["u8_sha256"]:
+            bad.append((name, "u8 through the prepared plan"))
+    assert not bad, f"{len(bad)} differences from the reference under the no-AVX-512 dispatch: {bad[:12]}"
+    # and the flavours are really two: the identity through a rotation (arccos decides every texel) differs between the fixtures
+    first = json.load(open(os.path.join(ROOT, "tests", "golden", "mid.json")))["M_ident_eqd_rot0"]
+    assert want["M_ident_eqd_rot0"]["idx_sha256"] != first["idx_sha256"]
+
+
+@pytest.mark.gpu
+def test_first_flavour_library_refuses_the_libm_flag():
+    import ctypes as C
+
+    from photonbend_amd import _native as nat
+
+    if nat.MATH_FLAVOUR != "svml":
+        pytest.skip("this host's own flavour is libm")
+    d, s = nat.make_proj(nat.KIND_PANO, 32, 64), nat.make_proj(nat.KIND_PANO, 32, 64)
+    h = C.c_void_p()
+    assert nat.load().pb_math_flavour() == 0
+    assert nat.load().pb_plan_create_ex(C.byref(d), None, 0, C.byref(s), nat.PLAN_DEFER | nat.PLAN_MATH_LIBM, 0, C.byref(h)) == -3
+    assert nat.load().pb_plan_create_ex(C.byref(d), None, 0, C.byref(s), nat.PLAN_DEFER | nat.PLAN_MATH_SVML, 0, C.byref(h)) == 0
+    nat.load().pb_plan_destroy(h)

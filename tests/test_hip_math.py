@@ -53,3 +53,28 @@ def test_device_build_of_the_numpy_functions_returns_numpys_bits(name, tmp_path)
     both_nan = np.isnan(got.view(np.float64)) & np.isnan(want.view(np.float64))
     bad = np.flatnonzero((got != want) & ~both_nan)
     assert bad.size == 0, f"{name}: {bad.size} of {got.size} device results differ from NumPy, first at result {bad[0]}: {got[bad[0]]:#018x} vs {want[bad[0]]:#018x}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["arcsin", "arccos", "arctan", "tan"])
+def test_device_build_of_the_second_flavour_returns_libms_bits(name, tmp_path):
+    """csrc/pb_math_libm.hpp as the gfx950 build runs it (tables in device memory) against tests/golden/npmath_libm.npz - the result bits
+    of NumPy WITHOUT its AVX-512 kernels, i.e. glibc 2.35's asin / acos / atan / tan: every bit of 40 000 results per function."""
+    from photonbend_amd.build import DIAG_LIB_PATH
+    from tests import npmath_args
+
+    if not os.path.exists(DIAG_LIB_PATH):
+        pytest.skip("needs the diagnostic build (python -m photonbend_amd.build --diag)")
+    fn = 8 + ["arcsin", "arccos", "arctan", "tan"].index(name)
+    x = npmath_args.arguments(name)
+    src, dev_out = str(tmp_path / "in.bin"), str(tmp_path / "dev.bin")
+    x.tofile(src)
+    env = dict(os.environ, PB_LIB_PATH=DIAG_LIB_PATH)
+    res = subprocess.run([sys.executable, "-c", _SCRIPT, str(fn), src, dev_out], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    got = np.fromfile(dev_out, dtype=np.uint64)
+    want = np.load(os.path.join(ROOT, "tests", "golden", "npmath_libm.npz"))[name]
+    assert got.size == want.size
+    both_nan = np.isnan(got.view(np.float64)) & np.isnan(want.view(np.float64))
+    bad = np.flatnonzero((got != want) & ~both_nan)
+    assert bad.size == 0, f"{name}: {bad.size} of {got.size} device results differ from NumPy-without-AVX-512, first at result {bad[0]}: {got[bad[0]]:#018x} vs {want[bad[0]]:#018x}"
