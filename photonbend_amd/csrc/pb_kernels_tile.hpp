@@ -871,6 +871,19 @@ __global__ void pb_unit_cost_kernel(const PbTileEntry* __restrict__ table, unsig
     const unsigned ty = t / tiles_x, tx = t - ty * tiles_x;
     atomicAdd(&unit_cost[(ty / (unit_tiles_y ? unit_tiles_y : unit_tiles)) * units_x + tx / unit_tiles], (unsigned)(c * 1024.0f + 0.5f));
 }
+#ifdef PB_ABLATION  // experiments only (experiments/r5/xcd_by_source.sh): the mean SOURCE row each super-tile samples
+__global__ void pb_unit_srcrow_kernel(const PbTileEntry* __restrict__ table, unsigned n_tiles, unsigned tiles_x, unsigned unit_tiles, unsigned units_x,
+                                      unsigned long long* __restrict__ sum, unsigned* __restrict__ cnt) {
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const PbTileEntry& e = table[t];
+    if (!(e.flags & (PB_TILE_LEAN | PB_TILE_DIRECT))) return;  // (plain tiles: anchor + the model's constant term = the tile centre's source row)
+    const float r = (float)e.anchor_r + e.c[0][0];
+    const unsigned ty = t / tiles_x, tx = t - ty * tiles_x, u = (ty / unit_tiles) * units_x + tx / unit_tiles;
+    atomicAdd(&sum[u], (unsigned long long)(r < 0.f ? 0.f : r));
+    atomicAdd(&cnt[u], 1u);
+}
+#endif
 __global__ void pb_save_flags_kernel(const PbTileEntry* __restrict__ table, int32_t* __restrict__ saved, unsigned n_tiles) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_tiles) saved[t] = table[t].flags;

@@ -768,6 +768,34 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
                     ahead[b] += best;
                 }
             }
+#ifdef PB_ABLATION
+        } else if (pb_knob("PB_XCD_BY_SRC", 0) && !bil && ns % 8u == 0) {
+            // VERDICT r4 item 8, ONE bounded experiment: super-tiles dealt to XCDs by the eighth of the SOURCE rows they sample (each XCD's
+            // L2 then sees one band of the source), the walk's order kept inside an XCD
+            std::vector<unsigned long long> sum(ns, 0ull);
+            std::vector<unsigned> cnt(ns, 0u);
+            unsigned long long* sum_dev = nullptr;
+            unsigned* cnt_dev = nullptr;
+            if (hipMalloc((void**)&sum_dev, ns * 8) == hipSuccess && hipMalloc((void**)&cnt_dev, ns * 4) == hipSuccess) {
+                (void)hipMemset(sum_dev, 0, ns * 8);
+                (void)hipMemset(cnt_dev, 0, ns * 4);
+                hipLaunchKernelGGL(pb_unit_srcrow_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->n_tiles, tiles_x, 2u * U, sgx, sum_dev, cnt_dev);
+                (void)hipMemcpy(sum.data(), sum_dev, ns * 8, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(cnt.data(), cnt_dev, ns * 4, hipMemcpyDeviceToHost);
+            }
+            (void)hipFree(sum_dev);
+            (void)hipFree(cnt_dev);
+            std::vector<unsigned> by_row(ns);
+            for (unsigned S = 0; S < ns; ++S) by_row[S] = S;
+            auto row_of = [&](unsigned S) { return cnt[S] ? (double)sum[S] / cnt[S] : 1e18; };  // (units without plain tiles: last)
+            std::stable_sort(by_row.begin(), by_row.end(), [&](unsigned a, unsigned b) { return row_of(a) < row_of(b); });
+            std::vector<int> xcd_of(ns, 0);
+            for (unsigned k = 0; k < ns; ++k) xcd_of[by_row[k]] = (int)(k / (ns / 8u));
+            for (unsigned p = 0; p < ns; ++p) {
+                const int x = xcd_of[seq[p]];
+                unit_of[(size_t)x * units_per_xcd + filled[x]++] = (int)seq[p];
+            }
+#endif
         } else {
             for (unsigned p = 0; p < ns; ++p) unit_of[(size_t)(p & 7u) * units_per_xcd + filled[p & 7u]++] = (int)seq[p];  // XCD = position in the walk, mod 8
         }
