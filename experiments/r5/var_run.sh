@@ -1,7 +1,7 @@
 #!/bin/bash
 # bilinear kernel time per config under each variant build: var_run.sh <tag> <libs: "product name1 name2"> <configs...>
 R=$GRAFT_REPO_ROOT; T=$1; LIBS=$2; shift 2; O=$R/gpurun_out/$T; mkdir -p $O; cd $R
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for lib in $LIBS; do
   for c in "$@"; do
     if [ $lib = product ]; then p=""; else p=$R/experiments/r5/libpb_$lib.so; fi

@@ -30,6 +30,9 @@
 #ifndef PB_BIL_WPE  // waves per SIMD the bilinear tile kernels are compiled for (the register budget: 512 / PB_BIL_WPE VGPRs)
 #define PB_BIL_WPE 3
 #endif
+#ifndef PB_BIL_WPE_DBL  // ... and the double-fisheye kernel (134 VGPRs at 3; forced to 4 it spills 20 registers and is no faster: experiments/README.md round 5)
+#define PB_BIL_WPE_DBL 3
+#endif
 #ifndef PB_BIL_ABL  // timing experiments only (experiments/r4/): bits skip parts of the bilinear tile code (wrong pixels); 0 in the product
 #define PB_BIL_ABL 0
 #endif
@@ -720,7 +723,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_ho
     if (e->bil_off >= 0 && !bil_xy) return;  // (no coordinate table: the float64 pass owns the tile)
     const int tx = e->tile_xy & 0xFFFF, ty = (int)((unsigned)e->tile_xy >> 16);
     unsigned v[16];
-    pb_bil_vals<SRC_KIND == PB_KIND_PANO>(Hd, e, flags, lane, pb_dyn_lds + (size_t)wave * ((Hd.win_budget >> 2) + 4), windows, src, bil_xy, 0, Hd.src_w, v);
+    // (the wave's LDS region: its slot says where in the workgroup's pool - pb_bilinear_pool_kernel)
+    pb_bil_vals<SRC_KIND == PB_KIND_PANO>(Hd, e, flags, lane, pb_dyn_lds + ((unsigned)e->win_r0 >> 2), windows, src, bil_xy, 0, Hd.src_w, v);
     pb_bil_store<SRC_KIND == PB_KIND_CAMERA>(v, dst, tx * PB_TILE, ty * PB_TILE, lane, Hd.dst_w, Hd.dst_h);
     const int n_fix = e->fix_cnt;
     if (n_fix > 0 && fix_xy && e->bil_off < 0) {
@@ -861,7 +865,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_kernel(const PbPa
 // table) blends with the faithful factors the nearest mode stores for its pixels (PbDoubleFix).  The fix pixels of either eye's
 // list are redone from their exact coordinates and stored factors after the wave's stores.
 template <int WMODE>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_double_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
+__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinear_double_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
                                                                                      const PbTileEntry* __restrict__ table_r,
                                                                                      const PbTileEntry* __restrict__ ltable,
                                                                                      const PbSepRow* __restrict__ rows,
@@ -892,7 +896,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_do
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
     const int xg = lane & 7, yb = lane >> 3;
     const int W = Hd.dst_w, H = Hd.dst_h, eye_w = P.src_eye_w;
-    unsigned* win = pb_dyn_lds + (size_t)wave * ((Hd.win_budget >> 2) + 8);
+    unsigned* win = pb_dyn_lds + ((unsigned)entry.win_r0 >> 2);  // (the wave's LDS region: its slot says where in the workgroup's pool)
     unsigned a[16];
     if ((PB_BIL_ABL & 128) && (entry.flags & PB_TILE_SOLO)) return;   // skip one-eye tiles
     if ((PB_BIL_ABL & 256) && !(entry.flags & PB_TILE_SOLO)) return;  // skip two-eye tiles
@@ -1003,6 +1007,64 @@ __global__ void pb_bilinear_tile_list_kernel(PbTileEntry* __restrict__ table_l, 
     if (table_r) table_r[t].bil_off = need_r ? (int)atomicAdd(&counters[1], 1u) : -1;
     const bool failed = ((table_l[t].flags | (table_r ? table_r[t].flags : 0)) & PB_TILE_FAILED) != 0;
     if ((need_l || need_r) && !failed) list[atomicAdd(&counters[0], 1u)] = (int32_t)t;
+}
+
+// The LDS POOL of a workgroup (round 5).  Round 4 gave each of a workgroup's four waves a region of the full window budget (12 KiB: three
+// workgroups per CU), though most windows are far smaller and a direct-gather or table tile needs only its 4 KiB regrouping buffer.
+// Here every slot of the bilinear launch table gets the byte offset of ITS region in the workgroup's pool (stored in the slot's win_r0,
+// which plain tiles do not use): regions are packed by their real size, so that a smaller pool - four workgroups per CU, measured
+// -4 % (c1) / -5 % (c3) / -11 % (c5) at fixed work - holds the same windows.  One thread per workgroup.  Where four regions exceed the
+// pool the largest window of a one-source slot is demoted to the direct-gather path (same pixels) until they fit; counters[0] counts the
+// demoted tiles, counters[1] the workgroups that cannot be made to fit (two-eye tiles keep their windows).  dry: count only.
+__device__ __forceinline__ unsigned pb_bil_region_bytes(const PbTileEntry& e, int flags) {
+    if (flags & (PB_TILE_SKIP | PB_TILE_BLACK)) return e.bil_off >= 0 && !(flags & PB_TILE_SKIP) ? (unsigned)PB_DIRECT_LDS_BYTES + 16u : 0u;
+    if (e.bil_off >= 0 || !(flags & PB_TILE_LEAN)) return (unsigned)PB_DIRECT_LDS_BYTES + 16u;
+    const unsigned w = (unsigned)(e.win_rows * 16 * e.win_n16);  // (frames LDS-DMA cannot address send a window tile down the direct path: its buffer too)
+    return (w > (unsigned)PB_DIRECT_LDS_BYTES ? w : (unsigned)PB_DIRECT_LDS_BYTES) + 16u;
+}
+__global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const PbTileEntry* __restrict__ table_l, const PbTileEntry* __restrict__ table_r,
+                                        unsigned n_groups, unsigned tiles_x, unsigned pool_bytes, int dry, unsigned* __restrict__ counters) {
+    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    unsigned need[4];
+    bool solo_lean[4];
+    for (int w = 0; w < 4; ++w) {
+        const PbTileEntry& e = ltable[4u * g + w];
+        const int f = e.flags;
+        solo_lean[w] = false;
+        if (f & PB_TILE_SKIP) { need[w] = 0u; continue; }
+        if (table_r && !(f & PB_TILE_SOLO)) {  // a two-eye tile: both eyes' regions, one after the other in the same place
+            const unsigned t = (unsigned)((unsigned)e.tile_xy >> 16) * tiles_x + (unsigned)(e.tile_xy & 0xFFFF);
+            const unsigned a = pb_bil_region_bytes(table_l[t], table_l[t].flags), b = pb_bil_region_bytes(table_r[t], table_r[t].flags);
+            need[w] = a > b ? a : b;
+            if (need[w] < (unsigned)PB_DIRECT_LDS_BYTES + 16u) need[w] = (unsigned)PB_DIRECT_LDS_BYTES + 16u;
+            continue;
+        }
+        need[w] = pb_bil_region_bytes(e, f);
+        solo_lean[w] = e.bil_off < 0 && (f & PB_TILE_LEAN) != 0;
+    }
+    unsigned demoted = 0;
+    for (;;) {
+        if (need[0] + need[1] + need[2] + need[3] <= pool_bytes) break;
+        int big = -1;
+        for (int w = 0; w < 4; ++w)
+            if (solo_lean[w] && need[w] > (unsigned)PB_DIRECT_LDS_BYTES + 16u && (big < 0 || need[w] > need[big])) big = w;
+        if (big < 0) {
+            atomicAdd(&counters[1], 1u);
+            return;  // (the host falls back to the pool that always fits)
+        }
+        need[big] = (unsigned)PB_DIRECT_LDS_BYTES + 16u;
+        solo_lean[big] = false;
+        if (!dry) ltable[4u * g + big].flags = (ltable[4u * g + big].flags & ~PB_TILE_LEAN) | PB_TILE_DIRECT;
+        ++demoted;
+    }
+    if (demoted) atomicAdd(&counters[0], demoted);
+    if (dry) return;
+    unsigned off = 0;
+    for (int w = 0; w < 4; ++w) {
+        ltable[4u * g + w].win_r0 = (int)off;
+        off += need[w];
+    }
 }
 
 // diagnostics (pb_plan_bilinear_tile_mix): how the bilinear mode serves the tiles of a table - counters: [0] window, [1] direct,

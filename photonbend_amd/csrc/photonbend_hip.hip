@@ -87,6 +87,7 @@ struct pb_plan {
     PbTileEntry* ltable_bil = nullptr;
     unsigned launch_groups_bil = 0;
     int bil_budget = 0;
+    unsigned bil_pool_bytes = 0;  // dynamic LDS of a bilinear launch's workgroup: the slots' regions are packed into it (pb_bilinear_pool_kernel)
     PbParams* P_dev = nullptr;   // device copy of P as the hot launches see it (refreshed with every budget change)
     unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
     int walk = 0;                // launch-order rule: 0 = by policy (pb_build_launch_table), 1 = plain, 2 = rows from the heaviest outwards,
@@ -871,6 +872,12 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
 #ifndef PB_BIL_WIN_BUDGET
 #define PB_BIL_WIN_BUDGET PB_WINLDS_MAX
 #endif
+#ifndef PB_BIL_POOL_SMALL  // the bilinear workgroups' small LDS pool: four of them per CU (160 KiB of LDS)
+#define PB_BIL_POOL_SMALL 40448u
+#endif
+#ifndef PB_BIL_NO_POOL  // A/B builds only: 1 = always the full pool (round 4's occupancy)
+#define PB_BIL_NO_POOL 0
+#endif
 #ifndef PB_BIL_LDS_PAD  // occupancy experiments only (experiments/r5/): extra dynamic LDS per workgroup of the bilinear launches (fewer workgroups per CU, same work)
 #define PB_BIL_LDS_PAD 0
 #endif
@@ -883,7 +890,37 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     pl->bil_budget = pb_clamp_budget(PB_BIL_WIN_BUDGET);
     int rc = pb_classify_under_budget(pl, pl->bil_budget, nullptr);
     if (rc == PB_OK) rc = pb_build_launch_table(pl, true);
-    return rc;
+    if (rc != PB_OK) return rc;
+    // the workgroups' LDS pool: four workgroups per CU where the slots' real regions allow it (few demotions), else the round-4 size
+    // (four full-budget regions: always fits, three workgroups per CU)
+    const unsigned full = 4u * ((unsigned)pl->bil_budget + 32u), small = PB_BIL_POOL_SMALL;
+    unsigned* counters = nullptr;
+    PB_HIP(pb_tmp_alloc((void**)&counters, 2 * sizeof(unsigned)));
+    const unsigned ng = pl->launch_groups_bil, tiles_x = (pl->P.dst.width + PB_TILE - 1) / PB_TILE;
+    const dim3 grid((ng + 127) / 128), block(128);
+    unsigned res[2] = {0u, 0u};
+    hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
+    unsigned pool = full;
+    if (e == hipSuccess && small < full && !PB_BIL_NO_POOL) {
+        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r : nullptr, ng, tiles_x, small, 1, counters);
+        e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && res[1] == 0u && res[0] * 50u <= pl->n_tiles) pool = small;  // (at most 2 % of the tiles lose their window)
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r : nullptr, ng, tiles_x, pool, 0, counters);
+        e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) (void)hipDeviceSynchronize();
+    pb_tmp_free(counters);
+    if (e != hipSuccess || res[1] != 0u) {
+        (void)hipFree(pl->ltable_bil);
+        pl->ltable_bil = nullptr;
+        pl->launch_groups_bil = 0;
+        return pb_fail(PB_ERR_HIP, e != hipSuccess ? std::string("bilinear LDS pool: ") + hipGetErrorString(e) : std::string("bilinear LDS pool: a workgroup does not fit"));
+    }
+    pl->bil_pool_bytes = pool;
+    return PB_OK;
 }
 
 // applies `budget` to the certified flags and rebuilds the nearest mode's launch-order table; synchronous on the default stream
@@ -1400,7 +1437,7 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
                 const uint8_t* sf = src_dev + (unsigned long long)f0 * src_frame_stride;
                 uint8_t* df = dst_dev + (unsigned long long)f0 * dst_frame_stride;
 #define PB_LAUNCH_BILINEAR_DOUBLE(WMODE)                                                                                                       \
-    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, pb_window_lds_bytes(Pb, 8) + PB_BIL_LDS_PAD, st, Pb, plan->table, plan->table_r, plan->ltable_bil, rows, \
+    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, (size_t)plan->bil_pool_bytes + PB_BIL_LDS_PAD, st, Pb, plan->table, plan->table_r, plan->ltable_bil, rows, \
                        plan->lat_tab, sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy,  \
                        plan->fix_px, plan->bil_fix_xy, plan->dbl_tile_fix, plan->dbl_px_fix)
                 if (rows) PB_LAUNCH_BILINEAR_DOUBLE(1);
@@ -1436,7 +1473,7 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
     do {                                                                                                                             \
         for (int f0 = 0; f0 < n_frames; f0 += per_launch) {                                                                          \
             const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;                                                  \
-            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, pb_window_lds_bytes(Pb) + PB_BIL_LDS_PAD, st, pb_hot_of_host(Pb), plan->ltable_bil, \
+            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, (size_t)plan->bil_pool_bytes + PB_BIL_LDS_PAD, st, pb_hot_of_host(Pb), plan->ltable_bil, \
                                src_dev + (unsigned long long)f0 * src_frame_stride, dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, \
                                (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy, plan->fix_px, \
                                plan->bil_fix_xy);                                                                                    \
