@@ -725,7 +725,11 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_ho
     unsigned v[16];
     // (the wave's LDS region: its slot says where in the workgroup's pool - pb_bilinear_pool_kernel)
     pb_bil_vals<SRC_KIND == PB_KIND_PANO>(Hd, e, flags, lane, pb_dyn_lds + ((unsigned)e->win_r0 >> 2), windows, src, bil_xy, 0, Hd.src_w, v);
+#ifdef PB_BIL_PLAIN_STORES  // A/B builds only
+    pb_bil_store<false>(v, dst, tx * PB_TILE, ty * PB_TILE, lane, Hd.dst_w, Hd.dst_h);
+#else
     pb_bil_store<SRC_KIND == PB_KIND_CAMERA>(v, dst, tx * PB_TILE, ty * PB_TILE, lane, Hd.dst_w, Hd.dst_h);
+#endif
     const int n_fix = e->fix_cnt;
     if (n_fix > 0 && fix_xy && e->bil_off < 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own stores have completed
