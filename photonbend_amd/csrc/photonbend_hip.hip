@@ -85,6 +85,7 @@ struct pb_plan {
     // bilinear mode two 8-byte loads per pixel, the nearest mode one dword - its best budget is larger) and ordered by its own costs;
     // built once per plan (pb_build_bilinear_launch), untouched by pb_plan_set_window_budget
     PbTileEntry* ltable_bil = nullptr;
+    PbTileEntry* table_r_bil = nullptr;  // double-fisheye plans: the right eye's tile table as classified under the bilinear mode's budget (the two-eye waves read it)
     unsigned launch_groups_bil = 0;
     int bil_budget = 0;
     unsigned bil_pool_bytes = 0;  // dynamic LDS of a bilinear launch's workgroup: the slots' regions are packed into it (pb_bilinear_pool_kernel)
@@ -891,6 +892,21 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     int rc = pb_classify_under_budget(pl, pl->bil_budget, nullptr);
     if (rc == PB_OK) rc = pb_build_launch_table(pl, true);
     if (rc != PB_OK) return rc;
+    (void)hipFree(pl->table_r_bil);
+    pl->table_r_bil = nullptr;
+    if (pl->dbl_ready) {
+        // a two-eye wave reads its right eye's entry by tile: from a copy of the table AS CLASSIFIED NOW (round 4 read the live table, which
+        // pb_apply_budget re-classifies under the nearest mode's smaller budget: the right eyes of c5's seam tiles took the direct path)
+        const size_t bytes = (size_t)pl->n_tiles * sizeof(PbTileEntry);
+        if (hipMalloc((void**)&pl->table_r_bil, bytes) != hipSuccess || hipMemcpy(pl->table_r_bil, pl->table_r, bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+            (void)hipFree(pl->table_r_bil);
+            pl->table_r_bil = nullptr;
+            (void)hipFree(pl->ltable_bil);
+            pl->ltable_bil = nullptr;
+            pl->launch_groups_bil = 0;
+            return pb_fail(PB_ERR_HIP, "bilinear launch table: out of device memory");
+        }
+    }
     // the workgroups' LDS pool: four workgroups per CU where the slots' real regions allow it (few demotions), else the round-4 size
     // (four full-budget regions: always fits, three workgroups per CU)
     const unsigned full = 4u * ((unsigned)pl->bil_budget + 32u), small = PB_BIL_POOL_SMALL;
@@ -1212,6 +1228,7 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->saved_r);
     (void)hipFree(plan->ltable);
     (void)hipFree(plan->ltable_bil);
+    (void)hipFree(plan->table_r_bil);
     (void)hipFree(plan->P_dev);
     (void)hipFree(plan->bil_tiles);
     (void)hipFree(plan->bil_xy);
@@ -1437,7 +1454,7 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
                 const uint8_t* sf = src_dev + (unsigned long long)f0 * src_frame_stride;
                 uint8_t* df = dst_dev + (unsigned long long)f0 * dst_frame_stride;
 #define PB_LAUNCH_BILINEAR_DOUBLE(WMODE)                                                                                                       \
-    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, (size_t)plan->bil_pool_bytes + PB_BIL_LDS_PAD, st, Pb, plan->table, plan->table_r, plan->ltable_bil, rows, \
+    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, (size_t)plan->bil_pool_bytes + PB_BIL_LDS_PAD, st, Pb, plan->table, plan->table_r_bil ? plan->table_r_bil : plan->table_r, plan->ltable_bil, rows, \
                        plan->lat_tab, sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy,  \
                        plan->fix_px, plan->bil_fix_xy, plan->dbl_tile_fix, plan->dbl_px_fix)
                 if (rows) PB_LAUNCH_BILINEAR_DOUBLE(1);
