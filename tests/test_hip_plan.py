@@ -310,6 +310,25 @@ def test_scattered_frames_in_one_launch_equal_single_launches(case):
     assert odd.data_ptr() % 16 != 0
     mixed = plan.remap_each([srcs[6], odd, srcs[8]])
     assert torch.equal(mixed[0], outs[6]) and torch.equal(mixed[1], outs[7]) and torch.equal(mixed[2], outs[8])
+    # the launch reads the pointer tables when it is ISSUED and neither allocates nor synchronises: a pb_remap_u8v call captures into a
+    # HIP graph; the host tables may be overwritten once the call has returned, and a replay writes the same frames again
+    n_g = 5
+    g_out = [torch.zeros((Hd, Wd, 3), dtype=torch.uint8, device="cuda") for _ in range(n_g)]
+    sp_g = (C.c_void_p * n_g)(*[s.data_ptr() for s in srcs[30 : 30 + n_g]])
+    dp_g = (C.c_void_p * n_g)(*[o.data_ptr() for o in g_out])
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            nat.check(nat.load().pb_remap_u8v(plan.handle, sp_g, dp_g, n_g, int(side.cuda_stream)))
+    for k in range(n_g):
+        sp_g[k] = dp_g[k] = 0  # (the tables were read at capture time)
+    torch.cuda.current_stream().wait_stream(side)
+    for o in g_out:
+        o.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(g_out[k], outs[30 + k]) for k in range(n_g))
     # argument checks
     L = nat.load()
     sp = (C.c_void_p * 2)(srcs[0].data_ptr(), 0)
