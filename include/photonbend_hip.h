@@ -172,11 +172,13 @@ int pb_plan_window_budget(const pb_plan* plan);
  * somewhere (fine for the reference's truncating sampler, whose exceptions are tabulated; too coarse to interpolate at), and
  * - double-fisheye sources - tiles that are not plain for an eye that sees them.  0 for a deferred plan. */
 int pb_plan_bilinear_float64_tiles(const pb_plan* plan);
-/* Diagnostics of the opt-in bilinear mode (ABI 5; synchronous, not for the hot loop): how its launches serve the plan's tiles -
- * mix[0] LDS-window tiles, [1] direct-gather tiles, [2] tiles read from the exact coordinate table, [3] black tiles, [4] window / direct
- * tiles whose coordinate is evaluated on the certified low-degree part of the tile model (PB_TILE_TD3), [5] entries counted (a
- * double-fisheye plan: both eyes' tables).  All zero without tile tables. */
-int pb_plan_bilinear_tile_mix(const pb_plan* plan, long long mix[6]);
+/* Diagnostics of the opt-in bilinear mode (ABI 5; synchronous, not for the hot loop): how its launch serves the tile entries its waves
+ * read - mix[0] LDS-window entries, [1] direct-gather entries, [2] entries read from the exact coordinate table, [3] black entries,
+ * [4] window / direct entries whose coordinate is evaluated on the certified low-degree part of the tile model (PB_TILE_TD3),
+ * [5] entries counted (one per tile; a double-fisheye plan's two-eye tiles have one per eye), [6] of the window entries [0], those
+ * staged as two half windows (their source box exceeds the budget, its top and bottom halves do not), [7] reserved.  All zero
+ * without tile tables. */
+int pb_plan_bilinear_tile_mix(const pb_plan* plan, long long mix[8]);
 
 /* 1 when `plan` was made for exactly this request (same projections, same rotation bits), 0 when not, negative on bad
  * arguments (ABI 3).  What a cache of serialized plans checks after pb_plan_deserialize: the blob's checksum says it is

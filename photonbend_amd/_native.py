@@ -381,9 +381,9 @@ class Plan:
 
     def bilinear_tile_mix(self) -> dict:
         """How the opt-in bilinear mode serves the plan's tiles (diagnostic, synchronous)."""
-        m = (C.c_longlong * 6)()
+        m = (C.c_longlong * 8)()
         check(load().pb_plan_bilinear_tile_mix(self._h, m))
-        return dict(zip(("window", "direct", "table", "black", "td3", "entries"), (int(x) for x in m)))
+        return dict(zip(("window", "direct", "table", "black", "td3", "entries", "half_windows"), (int(x) for x in m)))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

@@ -30,6 +30,9 @@
 #ifndef PB_BIL_WPE  // waves per SIMD the bilinear tile kernels are compiled for (the register budget: 512 / PB_BIL_WPE VGPRs)
 #define PB_BIL_WPE 3
 #endif
+#ifndef PB_BIL_HALVES_MAX  // bytes both half windows of a PB_TILE_HALVES tile may have in sum
+#define PB_BIL_HALVES_MAX 24576
+#endif
 #ifndef PB_BIL_WPE_DBL  // ... and the double-fisheye kernel (134 VGPRs at 3; forced to 4 it spills 20 registers and is no faster: experiments/README.md round 5)
 #define PB_BIL_WPE_DBL 3
 #endif
@@ -512,6 +515,63 @@ __device__ __forceinline__ void pb_bil_direct_gather(const uint8_t* __restrict__
     }
 }
 
+// The HALVES path of a plain tile (PB_TILE_HALVES): the two half windows staged one after the other in the wave's LDS region, the
+// lane's eight pixels of each half sampled from it like a window tile's.  The model is evaluated in the order the direct path would use
+// for the tile (the slot's window geometry was measured with exactly this evaluation: pb_bilinear_halves_kernel).
+template <bool TD3>
+__device__ __forceinline__ void pb_bil_halves_vals(const PbHot& Hd, const PbTileEntry* __restrict__ e, const int lane, unsigned* win,
+                                                   const uint8_t* __restrict__ s, unsigned v[16]) {
+    const int xg = lane & 7, yb = lane >> 3;
+    const unsigned rowbytes = 3u * (unsigned)Hd.src_w, safe_len = (rowbytes * (unsigned)Hd.src_h) & ~15u;
+    const bool along_x = fabsf(e->c[1][0]) <= fabsf(e->c[5][0]);
+    const pb_f2 half = {0.5f, 0.5f};
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)win;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const unsigned hw = part ? ((unsigned)e->bil_off & 0x7FFFFFFFu) : (unsigned)e->win_c0;
+        const unsigned dr = PB_HALF_DR(hw), dc = PB_HALF_DC(hw), rows = PB_HALF_ROWS(hw), n16 = PB_HALF_N16(hw);
+        const unsigned pitch = 16u * n16;
+        const unsigned gbase = ((unsigned)e->anchor_r + dr) * rowbytes + 3u * ((unsigned)e->anchor_c + dc);
+        pb_issue_window_loads(s, win, lane, gbase, rowbytes, (int)rows, (int)n16, safe_len);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pb_wave_sync();
+        // LDS address of a tap = (row - dr) * pitch + (col - dc) * 3 + (the first sample's byte phase) + the region's base
+        const unsigned a0w = (gbase & 15u) + base - dr * pitch - 3u * dc;
+        if (along_x) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk += 2) {
+                pb_f2 b0[5], b1[5], sv[4];
+                unsigned o[4];
+                pb_bil_collapse<TD3>(e, true, 4 * xg + kk, b0);
+                pb_bil_collapse<TD3>(e, true, 4 * xg + kk + 1, b1);
+                b0[0] = b0[0] - half;
+                b1[0] = b1[0] - half;
+                sv[0] = pb_bil_eval<TD3>(b0, pb_tile_coord(yb + 8 * (2 * part)));
+                sv[1] = pb_bil_eval<TD3>(b0, pb_tile_coord(yb + 8 * (2 * part + 1)));
+                sv[2] = pb_bil_eval<TD3>(b1, pb_tile_coord(yb + 8 * (2 * part)));
+                sv[3] = pb_bil_eval<TD3>(b1, pb_tile_coord(yb + 8 * (2 * part + 1)));
+                pb_bil_lds4(sv, pitch, a0w, o);
+                v[(2 * part) * 4 + kk] = o[0];
+                v[(2 * part + 1) * 4 + kk] = o[1];
+                v[(2 * part) * 4 + kk + 1] = o[2];
+                v[(2 * part + 1) * 4 + kk + 1] = o[3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int jr = 2 * part + j;
+                pb_f2 a[5], sv[4];
+                pb_bil_collapse<TD3>(e, false, yb + 8 * jr, a);
+                a[0] = a[0] - half;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sv[k] = pb_bil_eval<TD3>(a, pb_tile_coord(4 * xg + k));
+                pb_bil_lds4(sv, pitch, a0w, &v[jr * 4]);
+            }
+        }
+        pb_wave_sync();  // every lane has read its taps: the region may be refilled
+    }
+}
+
 // The window and the direct-gather path of a plain tile (LEAN / DIRECT), on the full tile model or on its TD3 part.
 template <bool TD3>
 __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileEntry* __restrict__ e, const int flags, const int lane, unsigned* win,
@@ -556,6 +616,10 @@ __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileE
         }
         PB_MARK("end");
         pb_wave_sync();  // every lane has read its taps: the window may be refilled (the other eye, the next path)
+        return;
+    }
+    if ((flags & PB_TILE_HALVES) && windows) {
+        pb_bil_halves_vals<TD3>(Hd, e, lane, win, s, v);
         return;
     }
     if (!(PB_BIL_PATHS & 2)) return;
@@ -1013,6 +1077,74 @@ __global__ void pb_bilinear_tile_list_kernel(PbTileEntry* __restrict__ table_l, 
     if ((need_l || need_r) && !failed) list[atomicAdd(&counters[0], 1u)] = (int32_t)t;
 }
 
+// Plan creation: which direct-gather slots of the bilinear launch table can be served as two half windows (PB_TILE_HALVES).  One wave per
+// slot: every pixel's tap coordinate with the hot path's own evaluation (same functions, same order, TD3 or not), the bounding box of the
+// taps of the top and of the bottom half, both at most `budget` bytes of LDS and loadable like a window tile's.  counters[2] counts them.
+// what: 0 the launch table of a single-source plan; 3 the launch table of a double-fisheye plan, its one-eye slots only (the product);
+// 1 the same with the left-eye entries its two-eye slots carry and 2 the bilinear mode's copy of the right-eye table, read by the
+// two-eye waves (both measured slower than the direct path on c5: A/B builds only).
+__global__ __launch_bounds__(256) void pb_bilinear_halves_kernel(PbTileEntry* __restrict__ ltable, unsigned n_slots, int budget, int src_h, int src_w, int what,
+                                                                 unsigned* __restrict__ counters) {
+    const unsigned v = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: the entry is read with scalar loads)
+    const int lane = threadIdx.x & 63;
+    if (v >= n_slots) return;
+    PbTileEntry* slot = ltable + v;
+    PbTileEntry L;
+    pb_load_entry(slot, L);
+    const PbTileEntry* __restrict__ e = &L;
+    const int f = e->flags;
+    if ((f & PB_TILE_SKIP) || !(f & PB_TILE_DIRECT) || (f & PB_TILE_MASKED) || e->bil_off >= 0) return;
+    if (what == 1 && !(f & (PB_TILE_SOLO | PB_TILE_TWO))) return;
+    if (what == 3 && !(f & PB_TILE_SOLO)) return;
+    const unsigned rowbytes = 3u * (unsigned)src_w, frame_bytes = rowbytes * (unsigned)src_h, safe_len = frame_bytes & ~15u;
+    if (rowbytes & 15u) return;
+    const int xg = lane & 7, yb = lane >> 3;
+    const bool along_x = fabsf(e->c[1][0]) <= fabsf(e->c[5][0]);
+    const bool td3 = (f & PB_TILE_TD3) != 0;
+    const pb_f2 half = {0.5f, 0.5f};
+    int ymin[2] = {0x7fffffff, 0x7fffffff}, ymax[2] = {-1, -1}, xmin[2] = {0x7fffffff, 0x7fffffff}, xmax[2] = {-1, -1};
+    bool ok = true;
+    for (int jr = 0; jr < 4; ++jr)
+        for (int k = 0; k < 4; ++k) {
+            pb_f2 c[5], sv;
+            if (td3) {
+                pb_bil_collapse<true>(e, along_x, along_x ? 4 * xg + k : yb + 8 * jr, c);
+                c[0] = c[0] - half;
+                sv = pb_bil_eval<true>(c, pb_tile_coord(along_x ? yb + 8 * jr : 4 * xg + k));
+            } else {
+                pb_bil_collapse<false>(e, along_x, along_x ? 4 * xg + k : yb + 8 * jr, c);
+                c[0] = c[0] - half;
+                sv = pb_bil_eval<false>(c, pb_tile_coord(along_x ? yb + 8 * jr : 4 * xg + k));
+            }
+            ok = ok && sv.x >= 0.0f && sv.y >= 0.0f && sv.x < 60000.0f && sv.y < 60000.0f;
+            const int iy = (int)sv.x, ix = (int)sv.y, p = jr >> 1;
+            ymin[p] = min(ymin[p], iy); ymax[p] = max(ymax[p], iy);
+            xmin[p] = min(xmin[p], ix); xmax[p] = max(xmax[p], ix);
+        }
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0) return;
+    int packed[2];
+    bool fits = true;
+    for (int p = 0; p < 2; ++p) {
+        const int y0 = pb_wave_min(ymin[p]), y1 = pb_wave_max(ymax[p]), x0 = pb_wave_min(xmin[p]), x1 = pb_wave_max(xmax[p]);
+        const unsigned rows = (unsigned)(y1 - y0 + 2), cols = (unsigned)(x1 - x0 + 2);  // taps i and i + 1
+        const unsigned lr0 = (unsigned)e->anchor_r + (unsigned)y0, lc0 = (unsigned)e->anchor_c + (unsigned)x0;
+        const unsigned a0 = (3u * lc0) & 15u, n16 = (a0 + 3u * cols + 1u + 15u) >> 4;
+        const unsigned last_chunk_end = ((lr0 + rows - 1u) * rowbytes + 3u * lc0 & ~15u) + 16u * n16;
+        fits = fits && y0 >= 0 && y0 < 256 && x0 >= 0 && x0 < 1024 && rows < 128u && n16 <= 64u && rows * 16u * n16 <= (unsigned)budget &&
+               lr0 + rows <= (unsigned)src_h && lc0 + cols <= (unsigned)src_w && last_chunk_end <= safe_len &&
+               (lr0 + rows - 1u) * rowbytes + 3u * (lc0 + cols - 1u) + 4u <= frame_bytes;
+        packed[p] = PB_HALF_PACK(y0, x0, rows, n16);
+    }
+    // (two half windows move more bytes than the tile's direct gathers do when they are large: beyond PB_BIL_HALVES_MAX bytes in sum the
+    // direct path is the faster one - measured, experiments/README.md round 5)
+    if (PB_HALF_ROWS(packed[0]) * 16u * PB_HALF_N16(packed[0]) + PB_HALF_ROWS(packed[1]) * 16u * PB_HALF_N16(packed[1]) > (unsigned)PB_BIL_HALVES_MAX) fits = false;
+    if (!fits || lane != 0) return;
+    slot->flags = f | PB_TILE_HALVES;
+    slot->win_c0 = packed[0];
+    slot->bil_off = (int)(0x80000000u | (unsigned)packed[1]);  // (negative like every tile without a coordinate-table slot)
+    atomicAdd(&counters[2], 1u);
+}
+
 // The LDS POOL of a workgroup (round 5).  Round 4 gave each of a workgroup's four waves a region of the full window budget (12 KiB: three
 // workgroups per CU), though most windows are far smaller and a direct-gather or table tile needs only its 4 KiB regrouping buffer.
 // Here every slot of the bilinear launch table gets the byte offset of ITS region in the workgroup's pool (stored in the slot's win_r0,
@@ -1022,6 +1154,12 @@ __global__ void pb_bilinear_tile_list_kernel(PbTileEntry* __restrict__ table_l, 
 // demoted tiles, counters[1] the workgroups that cannot be made to fit (two-eye tiles keep their windows).  dry: count only.
 __device__ __forceinline__ unsigned pb_bil_region_bytes(const PbTileEntry& e, int flags) {
     if (flags & (PB_TILE_SKIP | PB_TILE_BLACK)) return e.bil_off >= 0 && !(flags & PB_TILE_SKIP) ? (unsigned)PB_DIRECT_LDS_BYTES + 16u : 0u;
+    if (e.bil_off < 0 && (flags & PB_TILE_HALVES)) {  // two half windows, one after the other (and the direct path's buffer for frames LDS-DMA cannot address)
+        const unsigned hb = (unsigned)e.bil_off & 0x7FFFFFFFu;
+        const unsigned a = PB_HALF_ROWS(e.win_c0) * 16u * PB_HALF_N16(e.win_c0), b = PB_HALF_ROWS(hb) * 16u * PB_HALF_N16(hb);
+        const unsigned w = a > b ? a : b;
+        return (w > (unsigned)PB_DIRECT_LDS_BYTES ? w : (unsigned)PB_DIRECT_LDS_BYTES) + 16u;
+    }
     if (e.bil_off >= 0 || !(flags & PB_TILE_LEAN)) return (unsigned)PB_DIRECT_LDS_BYTES + 16u;
     const unsigned w = (unsigned)(e.win_rows * 16 * e.win_n16);  // (frames LDS-DMA cannot address send a window tile down the direct path: its buffer too)
     return (w > (unsigned)PB_DIRECT_LDS_BYTES ? w : (unsigned)PB_DIRECT_LDS_BYTES) + 16u;
@@ -1039,13 +1177,15 @@ __global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const 
         if (f & PB_TILE_SKIP) { need[w] = 0u; continue; }
         if (table_r && !(f & PB_TILE_SOLO)) {  // a two-eye tile: both eyes' regions, one after the other in the same place
             const unsigned t = (unsigned)((unsigned)e.tile_xy >> 16) * tiles_x + (unsigned)(e.tile_xy & 0xFFFF);
-            const unsigned a = pb_bil_region_bytes(table_l[t], table_l[t].flags), b = pb_bil_region_bytes(table_r[t], table_r[t].flags);
+            // (the entries the wave reads: the left eye's from its slot when the slot carries it, the right eye's from the mode's copy)
+            const unsigned a = (f & PB_TILE_TWO) ? pb_bil_region_bytes(e, f & ~PB_TILE_TWO) : pb_bil_region_bytes(table_l[t], table_l[t].flags);
+            const unsigned b = pb_bil_region_bytes(table_r[t], table_r[t].flags);
             need[w] = a > b ? a : b;
             if (need[w] < (unsigned)PB_DIRECT_LDS_BYTES + 16u) need[w] = (unsigned)PB_DIRECT_LDS_BYTES + 16u;
             continue;
         }
         need[w] = pb_bil_region_bytes(e, f);
-        solo_lean[w] = e.bil_off < 0 && (f & PB_TILE_LEAN) != 0;
+        solo_lean[w] = e.bil_off < 0 && (f & (PB_TILE_LEAN | PB_TILE_HALVES)) != 0;
     }
     unsigned demoted = 0;
     for (;;) {
@@ -1059,7 +1199,7 @@ __global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const 
         }
         need[big] = (unsigned)PB_DIRECT_LDS_BYTES + 16u;
         solo_lean[big] = false;
-        if (!dry) ltable[4u * g + big].flags = (ltable[4u * g + big].flags & ~PB_TILE_LEAN) | PB_TILE_DIRECT;
+        if (!dry) ltable[4u * g + big].flags = (ltable[4u * g + big].flags & ~(PB_TILE_LEAN | PB_TILE_HALVES)) | PB_TILE_DIRECT;
         ++demoted;
     }
     if (demoted) atomicAdd(&counters[0], demoted);
@@ -1071,19 +1211,35 @@ __global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const 
     }
 }
 
-// diagnostics (pb_plan_bilinear_tile_mix): how the bilinear mode serves the tiles of a table - counters: [0] window, [1] direct,
-// [2] exact coordinate table, [3] black, [4] plain tiles evaluated on their TD3 part, [5] entries seen
-__global__ void pb_bilinear_mix_kernel(const PbTileEntry* __restrict__ table, unsigned n, unsigned* __restrict__ counters) {
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const int f = table[t].flags;
-    if (f & PB_TILE_SKIP) return;
+// diagnostics (pb_plan_bilinear_tile_mix): how the bilinear mode serves the entries its waves read - counters: [0] window, [1] direct,
+// [2] exact coordinate table, [3] black, [4] plain tiles evaluated on their TD3 part, [5] entries seen, [6] window tiles staged as two half windows
+__device__ __forceinline__ void pb_bil_mix_count(const PbTileEntry& e, int f, unsigned* __restrict__ counters) {
     atomicAdd(&counters[5], 1u);
-    if (table[t].bil_off >= 0) atomicAdd(&counters[2], 1u);
-    else if (f & PB_TILE_LEAN) atomicAdd(&counters[0], 1u);
+    if (e.bil_off < 0 && (f & PB_TILE_HALVES)) atomicAdd(&counters[6], 1u);
+    if (e.bil_off >= 0) atomicAdd(&counters[2], 1u);
+    else if (f & (PB_TILE_LEAN | PB_TILE_HALVES)) atomicAdd(&counters[0], 1u);  // (window tiles, whole or in two halves)
     else if (f & PB_TILE_DIRECT) atomicAdd(&counters[1], 1u);
     else if (f & PB_TILE_BLACK) atomicAdd(&counters[3], 1u);
-    if (table[t].bil_off < 0 && (f & (PB_TILE_LEAN | PB_TILE_DIRECT)) && (f & PB_TILE_TD3)) atomicAdd(&counters[4], 1u);
+    if (e.bil_off < 0 && (f & (PB_TILE_LEAN | PB_TILE_DIRECT)) && (f & PB_TILE_TD3)) atomicAdd(&counters[4], 1u);
+}
+// the launch-order table of a plan: a single source (table_r null) has every tile's entry in its slot; a double-fisheye plan's one-eye
+// slots carry the live eye's entry, its two-eye slots the left eye's (PB_TILE_TWO; else the plan's left table) next to the right eye's
+// in the mode's copy of the right table - one count per entry a wave reads
+__global__ void pb_bilinear_mix_kernel(const PbTileEntry* __restrict__ ltable, const PbTileEntry* __restrict__ table_l, const PbTileEntry* __restrict__ table_r,
+                                       unsigned n_slots, unsigned tiles_x, unsigned* __restrict__ counters) {
+    const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_slots) return;
+    const PbTileEntry& e = ltable[v];
+    const int f = e.flags;
+    if (f & PB_TILE_SKIP) return;
+    if (!table_r || (f & PB_TILE_SOLO)) {
+        pb_bil_mix_count(e, f, counters);
+        return;
+    }
+    const unsigned t = (unsigned)((unsigned)e.tile_xy >> 16) * tiles_x + (unsigned)(e.tile_xy & 0xFFFF);
+    if (f & PB_TILE_TWO) pb_bil_mix_count(e, f & ~PB_TILE_TWO, counters);
+    else pb_bil_mix_count(table_l[t], table_l[t].flags, counters);
+    pb_bil_mix_count(table_r[t], table_r[t].flags, counters);
 }
 
 // fills the coordinate table: 4 blocks per tile, every tile with a slot (pixels beyond the image repeat the edge: never stored)

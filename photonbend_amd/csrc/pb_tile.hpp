@@ -59,6 +59,17 @@
 #define PB_TILE_TD3 8192
 #define PB_TILE_TAB_Y 16384  // bilinear mode, tiles served from the exact coordinate table: the slot is stored transposed and walked by rows (pb_bilinear_orient_kernel)
 #define PB_TILE_TWO 32768  // launch-order table of a double-fisheye plan's bilinear mode only: a two-eye slot that carries the LEFT eye's entry
+// HALVES (bilinear launch table only, round 5): a plain tile whose source box exceeds the window budget but whose TOP and BOTTOM halves
+// (output rows 0-15 / 16-31) each fit: the wave stages the two half windows one after the other in its LDS region and samples 8 pixels
+// per lane from each - the window path's cost per pixel instead of the direct-gather path's (c2: 4 392 of its ~5 000 direct tiles).
+// The entry's win_c0 and bil_off (made negative: such a tile has no coordinate-table slot) hold the two half windows (PB_HALF_* fields
+// below), found at plan time with the hot path's own evaluation.
+#define PB_TILE_HALVES 65536
+#define PB_HALF_PACK(dr, dc, rows, n16) ((int)((unsigned)(dr) | ((unsigned)(dc) << 8) | ((unsigned)(rows) << 18) | ((unsigned)((n16) - 1) << 25)))
+#define PB_HALF_DR(h) ((unsigned)(h) & 0xFFu)
+#define PB_HALF_DC(h) (((unsigned)(h) >> 8) & 0x3FFu)
+#define PB_HALF_ROWS(h) (((unsigned)(h) >> 18) & 0x7Fu)
+#define PB_HALF_N16(h) ((((unsigned)(h) >> 25) & 0x3Fu) + 1u)
 #define PB_TILE_W_UNIT_BIT 64  // == PB_TILE_W_UNIT (pb_kernels_double.hpp): blend factors exactly 1.0 for every pixel of the tile
 #define PB_LEAN_MAX_PASSES 24  // window rows / rows-per-load-instruction of a LEAN tile (register staging depth)
 

@@ -876,6 +876,12 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
 #ifndef PB_BIL_POOL_SMALL  // the bilinear workgroups' small LDS pool: four of them per CU (160 KiB of LDS)
 #define PB_BIL_POOL_SMALL 40448u
 #endif
+#ifndef PB_BIL_NO_HALVES  // A/B builds only: 1 = no half-window tiles
+#define PB_BIL_NO_HALVES 0
+#endif
+#ifndef PB_BIL_HALVES_TWO  // A/B builds only: 1 = half windows for the eyes of two-eye tiles too
+#define PB_BIL_HALVES_TWO 0
+#endif
 #ifndef PB_BIL_NO_POOL  // A/B builds only: 1 = always the full pool (round 4's occupancy)
 #define PB_BIL_NO_POOL 0
 #endif
@@ -911,20 +917,30 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     // (four full-budget regions: always fits, three workgroups per CU)
     const unsigned full = 4u * ((unsigned)pl->bil_budget + 32u), small = PB_BIL_POOL_SMALL;
     unsigned* counters = nullptr;
-    PB_HIP(pb_tmp_alloc((void**)&counters, 2 * sizeof(unsigned)));
+    PB_HIP(pb_tmp_alloc((void**)&counters, 4 * sizeof(unsigned)));
     const unsigned ng = pl->launch_groups_bil, tiles_x = (pl->P.dst.width + PB_TILE - 1) / PB_TILE;
     const dim3 grid((ng + 127) / 128), block(128);
     unsigned res[2] = {0u, 0u};
-    hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
+    hipError_t e = hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
+    if (e == hipSuccess && !PB_BIL_NO_HALVES)  // direct-gather slots that can be served as two half windows
+    {
+        hipLaunchKernelGGL(pb_bilinear_halves_kernel, dim3(ng), dim3(256), 0, 0, pl->ltable_bil, 4u * ng, pl->bil_budget, pl->P.src.height, pl->P.src.width,
+                           pl->dbl_ready ? (PB_BIL_HALVES_TWO ? 1 : 3) : 0, counters);
+        // (the eyes of two-eye tiles keep the direct path: as half windows - four serial window loads per wave - c5 measured 113 us
+        // against 106, experiments/README.md round 5; PB_BIL_HALVES_TWO=1 rebuilds that variant)
+        if (pl->table_r_bil && PB_BIL_HALVES_TWO)
+            hipLaunchKernelGGL(pb_bilinear_halves_kernel, dim3((pl->n_tiles + 3u) / 4u), dim3(256), 0, 0, pl->table_r_bil, pl->n_tiles, pl->bil_budget, pl->P.src.height,
+                               pl->P.src.width, 2, counters);
+    }
     unsigned pool = full;
     if (e == hipSuccess && small < full && !PB_BIL_NO_POOL) {
-        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r : nullptr, ng, tiles_x, small, 1, counters);
+        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r_bil : nullptr, ng, tiles_x, small, 1, counters);
         e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
         if (e == hipSuccess && res[1] == 0u && res[0] * 50u <= pl->n_tiles) pool = small;  // (at most 2 % of the tiles lose their window)
     }
     if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r : nullptr, ng, tiles_x, pool, 0, counters);
+        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r_bil : nullptr, ng, tiles_x, pool, 0, counters);
         e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
     }
     if (e != hipSuccess) (void)hipDeviceSynchronize();
@@ -1247,32 +1263,26 @@ int pb_plan_bilinear_float64_tiles(const pb_plan* plan) {
     if (plan->bil_xy) return 0;  // every tile the models cannot serve has its exact coordinates in the plan's table
     return (int)(plan->n_fail_tiles + (plan->bil_tiles ? plan->n_bil_tiles : 0u));
 }
-int pb_plan_bilinear_tile_mix(const pb_plan* plan, long long mix[6]) {
+int pb_plan_bilinear_tile_mix(const pb_plan* plan, long long mix[8]) {
     if (!plan || !mix) return pb_fail(PB_ERR_INVALID, "null argument");
-    for (int k = 0; k < 6; ++k) mix[k] = 0;
+    for (int k = 0; k < 8; ++k) mix[k] = 0;
     if (!(plan->fast_ready || plan->dbl_ready) || !plan->ltable_bil || plan->launch_groups_bil == 0) return PB_OK;
     if (plan->device >= 0) {
         int dev = -1;
         PB_HIP(hipGetDevice(&dev));
         if (dev != plan->device) return pb_fail(PB_ERR_INVALID, "plan was prepared on another device");
     }
-    // the tables the bilinear launches read, classified under the mode's own budget: the launch-order table of a single source
-    // carries every tile's flags; a double-fisheye plan's two-eye slots only name their tile, so its eyes' tables are counted (their
-    // LEAN / DIRECT split is whatever budget was applied last)
+    // the entries the bilinear launch's waves read, classified as the kernel takes them (pb_bilinear_mix_kernel)
     unsigned* counters = nullptr;
     PB_HIP(pb_tmp_alloc((void**)&counters, 8 * sizeof(unsigned)));
     hipError_t e = hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), 0);
     if (e == hipSuccess) {
-        if (plan->dbl_ready) {
-            hipLaunchKernelGGL(pb_bilinear_mix_kernel, dim3((plan->n_tiles + 255) / 256), dim3(256), 0, 0, plan->table, plan->n_tiles, counters);
-            hipLaunchKernelGGL(pb_bilinear_mix_kernel, dim3((plan->n_tiles + 255) / 256), dim3(256), 0, 0, plan->table_r, plan->n_tiles, counters);
-        } else {
-            const unsigned n_slots = 4u * plan->launch_groups_bil;
-            hipLaunchKernelGGL(pb_bilinear_mix_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, 0, plan->ltable_bil, n_slots, counters);
-        }
+        const unsigned n_slots = 4u * plan->launch_groups_bil;
+        hipLaunchKernelGGL(pb_bilinear_mix_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, 0, plan->ltable_bil, plan->table,
+                           plan->dbl_ready ? (plan->table_r_bil ? plan->table_r_bil : plan->table_r) : nullptr, n_slots, (unsigned)((plan->P.dst.width + PB_TILE - 1) / PB_TILE), counters);
         unsigned res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
-        for (int k = 0; k < 6; ++k) mix[k] = res[k];
+        for (int k = 0; k < 8; ++k) mix[k] = res[k];
     }
     if (e != hipSuccess) (void)hipDeviceSynchronize();
     pb_tmp_free(counters);
