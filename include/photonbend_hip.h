@@ -176,8 +176,8 @@ int pb_plan_bilinear_float64_tiles(const pb_plan* plan);
  * read - mix[0] LDS-window entries, [1] direct-gather entries, [2] entries read from the exact coordinate table, [3] black entries,
  * [4] window / direct entries whose coordinate is evaluated on the certified low-degree part of the tile model (PB_TILE_TD3),
  * [5] entries counted (one per tile; a double-fisheye plan's two-eye tiles have one per eye), [6] of the window entries [0], those
- * staged as two half windows (their source box exceeds the budget, its top and bottom halves do not), [7] reserved.  All zero
- * without tile tables. */
+ * staged as two half windows (their source box exceeds the budget, its top and bottom halves do not), [7] of the table entries [2],
+ * those whose taps all lie inside the frame (read without clamps or wrap).  All zero without tile tables. */
 int pb_plan_bilinear_tile_mix(const pb_plan* plan, long long mix[8]);
 
 /* 1 when `plan` was made for exactly this request (same projections, same rotation bits), 0 when not, negative on bad

@@ -383,7 +383,7 @@ class Plan:
         """How the opt-in bilinear mode serves the plan's tiles (diagnostic, synchronous)."""
         m = (C.c_longlong * 8)()
         check(load().pb_plan_bilinear_tile_mix(self._h, m))
-        return dict(zip(("window", "direct", "table", "black", "td3", "entries", "half_windows"), (int(x) for x in m)))
+        return dict(zip(("window", "direct", "table", "black", "td3", "entries", "half_windows", "table_plain"), (int(x) for x in m)))
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

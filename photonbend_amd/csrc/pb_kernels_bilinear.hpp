@@ -30,6 +30,9 @@
 #ifndef PB_BIL_WPE  // waves per SIMD the bilinear tile kernels are compiled for (the register budget: 512 / PB_BIL_WPE VGPRs)
 #define PB_BIL_WPE 3
 #endif
+#ifndef PB_BIL_NO_TAB_PLAIN  // A/B builds only: 1 = every table tile on the guarded path
+#define PB_BIL_NO_TAB_PLAIN 0
+#endif
 #ifndef PB_BIL_HALVES_MAX  // bytes both half windows of a PB_TILE_HALVES tile may have in sum
 #define PB_BIL_HALVES_MAX 24576
 #endif
@@ -391,11 +394,22 @@ struct PbBilTap {
     float tx, ty;
     int kind;         // 0: neighbours, 1: the right tap is the left tap, 2: wrapped, -1: black
 };
-template <bool WRAP>
+template <bool WRAP, bool PLAIN>
 __device__ __forceinline__ PbBilTap pb_bil_table_tap(int qy, int qx, int h, int w, int cmin, int cmax) {
     PbBilTap t;
     const bool dead = qy == PB_BIL_DEAD;
     if (dead) qy = 0;
+    if (PLAIN) {  // (PB_TILE_TAB_PLAIN: the four taps of every live pixel are inside the frame and the column range)
+        if (dead) qx = 0;
+        t.ty = (float)(qy & ((1 << PB_BIL_SHIFT) - 1)) * (1.0f / (float)(1 << PB_BIL_SHIFT));
+        t.tx = (float)(qx & ((1 << PB_BIL_SHIFT) - 1)) * (1.0f / (float)(1 << PB_BIL_SHIFT));
+        t.o0 = __umul24((unsigned)(qy >> PB_BIL_SHIFT), 3u * (unsigned)w) + __umul24((unsigned)(qx >> PB_BIL_SHIFT), 3u);
+        t.o1 = t.o0 + 3u * (unsigned)w;
+        if (PB_BIL_ABL & 1024) t.o0 = t.o1 = 3u * (unsigned)((qx >> PB_BIL_SHIFT) & 15);
+        t.kind = dead ? -1 : 0;
+        t.c1off = 3u;
+        return t;
+    }
     t.ty = (float)(qy & ((1 << PB_BIL_SHIFT) - 1)) * (1.0f / (float)(1 << PB_BIL_SHIFT));
     t.tx = (float)(qx & ((1 << PB_BIL_SHIFT) - 1)) * (1.0f / (float)(1 << PB_BIL_SHIFT));
     int r0 = qy >> PB_BIL_SHIFT, c0 = qx >> PB_BIL_SHIFT;
@@ -422,7 +436,7 @@ __device__ __forceinline__ unsigned long long pb_bil_load8(const uint8_t* __rest
     __builtin_memcpy(&t, s + oo, 8);
     return t >> (8u * (o - oo));
 }
-template <bool WRAP>
+template <bool WRAP, bool PLAIN>
 __device__ __forceinline__ void pb_bil_table8(const uint8_t* __restrict__ s, const int4 q[4], int h, int w, int cmin, int cmax, unsigned frame_bytes,
                                               unsigned out[8]) {
     PbBilTap t[8];
@@ -430,9 +444,14 @@ __device__ __forceinline__ void pb_bil_table8(const uint8_t* __restrict__ s, con
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         const int4 qq = q[n >> 1];
-        t[n] = pb_bil_table_tap<WRAP>((n & 1) ? qq.z : qq.x, (n & 1) ? qq.w : qq.y, h, w, cmin, cmax);
-        r0[n] = pb_bil_load8(s, t[n].o0, frame_bytes);
-        r1[n] = pb_bil_load8(s, t[n].o1, frame_bytes);
+        t[n] = pb_bil_table_tap<WRAP, PLAIN>((n & 1) ? qq.z : qq.x, (n & 1) ? qq.w : qq.y, h, w, cmin, cmax);
+        if (PLAIN) {  // (both 8-byte loads end inside the buffer: checked at plan time)
+            __builtin_memcpy(&r0[n], s + t[n].o0, 8);
+            __builtin_memcpy(&r1[n], s + t[n].o1, 8);
+        } else {
+            r0[n] = pb_bil_load8(s, t[n].o0, frame_bytes);
+            r1[n] = pb_bil_load8(s, t[n].o1, frame_bytes);
+        }
     }
 #pragma unroll
     for (int n = 0; n < 8; n += 2) {
@@ -444,13 +463,13 @@ __device__ __forceinline__ void pb_bil_table8(const uint8_t* __restrict__ s, con
             hi0[i] = (unsigned)(r0[n + i] >> 32);
             lo1[i] = (unsigned)r1[n + i];
             hi1[i] = (unsigned)(r1[n + i] >> 32);
-            if (tt.kind == 1) {  // the right tap is the left tap again: bytes 0-2 repeated as bytes 3-5
+            if (!PLAIN && tt.kind == 1) {  // the right tap is the left tap again: bytes 0-2 repeated as bytes 3-5
                 hi0[i] = lo0[i] >> 8;
                 lo0[i] = (lo0[i] & 0xFFFFFFu) | (lo0[i] << 24);
                 hi1[i] = lo1[i] >> 8;
                 lo1[i] = (lo1[i] & 0xFFFFFFu) | (lo1[i] << 24);
             }
-            if (WRAP && tt.kind == 2) {  // the panorama's seam: the right tap by itself
+            if (!PLAIN && WRAP && tt.kind == 2) {  // the panorama's seam: the right tap by itself
                 const unsigned p01 = pb_bil_load_px(s, tt.o0 + tt.c1off, frame_bytes), p11 = pb_bil_load_px(s, tt.o1 + tt.c1off, frame_bytes);
                 lo0[i] = (lo0[i] & 0xFFFFFFu) | (p01 << 24);
                 hi0[i] = p01 >> 8;
@@ -700,7 +719,8 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
             unsigned o[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) q[i] = make_int4(c[8 * half + 2 * i].x, c[8 * half + 2 * i].y, c[8 * half + 2 * i + 1].x, c[8 * half + 2 * i + 1].y);
-            pb_bil_table8<WRAP>(s, q, h, w, cmin, cmax, frame_bytes, o);
+            if (flags & PB_TILE_TAB_PLAIN) pb_bil_table8<WRAP, true>(s, q, h, w, cmin, cmax, frame_bytes, o);
+            else pb_bil_table8<WRAP, false>(s, q, h, w, cmin, cmax, frame_bytes, o);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int a = (2 * (8 * half + m) + hh + shift) & 31;  // (the slot is stored in walk order: entry [2 n + hh][p] is this pixel's)
@@ -1212,10 +1232,11 @@ __global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const 
 }
 
 // diagnostics (pb_plan_bilinear_tile_mix): how the bilinear mode serves the entries its waves read - counters: [0] window, [1] direct,
-// [2] exact coordinate table, [3] black, [4] plain tiles evaluated on their TD3 part, [5] entries seen, [6] window tiles staged as two half windows
+// [2] exact coordinate table, [3] black, [4] plain tiles evaluated on their TD3 part, [5] entries seen, [6] window tiles staged as two half windows, [7] table tiles whose taps need no guards (PB_TILE_TAB_PLAIN)
 __device__ __forceinline__ void pb_bil_mix_count(const PbTileEntry& e, int f, unsigned* __restrict__ counters) {
     atomicAdd(&counters[5], 1u);
     if (e.bil_off < 0 && (f & PB_TILE_HALVES)) atomicAdd(&counters[6], 1u);
+    if (e.bil_off >= 0 && (f & PB_TILE_TAB_PLAIN)) atomicAdd(&counters[7], 1u);
     if (e.bil_off >= 0) atomicAdd(&counters[2], 1u);
     else if (f & (PB_TILE_LEAN | PB_TILE_HALVES)) atomicAdd(&counters[0], 1u);  // (window tiles, whole or in two halves)
     else if (f & PB_TILE_DIRECT) atomicAdd(&counters[1], 1u);
@@ -1260,7 +1281,11 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_coord_kernel(const PbPar
 // discontinuity inside the tile - the rim of the image circle - is not a gradient).  The walk runs along the direction with the smaller
 // change (along y: PB_TILE_TAB_Y) and is sheared by slope = -g_along / g_across so that a half-wave follows the line of constant
 // source row; the slot is rewritten in walk order, the shear goes into bil_off.  Speed only: the pixels do not depend on the walk.
-__global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __restrict__ table, PbBilCoord* __restrict__ bil_xy) {
+// It also says whether the slot is PLAIN (PB_TILE_TAB_PLAIN, pb_tile.hpp): every live pixel's taps inside the h x w frame, in columns
+// [cmin, cmax) (an eye's half), an 8-byte load at each tap's two rows inside the buffer.
+// off: 2 = flag no slot plain, 4 = no walk (every slot by columns, no shear) - the diagnostic build's PB_BIL_OFF knob; 0 in the product.
+__global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __restrict__ table, PbBilCoord* __restrict__ bil_xy, int h, int w, int cmin,
+                                                                 int cmax, int off_bits) {
     __shared__ PbBilCoord tile[PB_TILE * PB_TILE];
     __shared__ float acc[4];
     PbTileEntry* e = table + blockIdx.x;
@@ -1273,10 +1298,16 @@ __global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __
     __syncthreads();
     float sx = 0.f, nx = 0.f, sy = 0.f, ny = 0.f;
     const int far = 64 << PB_BIL_SHIFT;
+    const unsigned frame_bytes = 3u * (unsigned)w * (unsigned)h;
+    int plain = (3u * (unsigned)w + 8u <= frame_bytes) ? 1 : 0;  // (a dead pixel loads at offset 0 of both rows)
     for (int i = threadIdx.x; i < PB_TILE * PB_TILE; i += 256) {
         const int x = i & 31, y = i >> 5;
         const PbBilCoord a = tile[i];
         if (a.y == PB_BIL_DEAD) continue;
+        {
+            const int r0 = a.y >> PB_BIL_SHIFT, c0 = a.x >> PB_BIL_SHIFT;
+            if (r0 < 0 || r0 + 1 > h - 1 || c0 < cmin || c0 + 1 > cmax - 1 || 3u * ((unsigned)(r0 + 1) * (unsigned)w + (unsigned)c0) + 8u > frame_bytes) plain = 0;
+        }
         if (x + 1 < PB_TILE && tile[i + 1].y != PB_BIL_DEAD) {
             const int d = tile[i + 1].y - a.y;
             if (d > -far && d < far) { sx += (float)d; nx += 1.f; }
@@ -1287,16 +1318,16 @@ __global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __
         }
     }
     atomicAdd(&acc[0], sx); atomicAdd(&acc[1], nx); atomicAdd(&acc[2], sy); atomicAdd(&acc[3], ny);
-    __syncthreads();
+    plain = __syncthreads_and(plain);
     const float gx = acc[1] > 0.f ? acc[0] / acc[1] : 0.f, gy = acc[3] > 0.f ? acc[2] / acc[3] : 0.f;
-    const bool by_rows = fabsf(gy) < fabsf(gx);  // the source row changes less down a column: lanes along y
+    const bool by_rows = fabsf(gy) < fabsf(gx) && !(off_bits & 4);  // the source row changes less down a column: lanes along y
     const float along = by_rows ? gy : gx, across = by_rows ? gx : gy;
     float slope = across != 0.f ? -along / across : 0.f;
     slope = fminf(fmaxf(slope, -1.9f), 1.9f);
 #ifdef PB_BIL_NO_SHEAR  // A/B builds only
     const int q = 0;
 #else
-    const int q = (int)rintf(slope * 64.0f);
+    const int q = (off_bits & 4) ? 0 : (int)rintf(slope * 64.0f);
 #endif
     const int packed = slot | ((q & 0xFF) << 20);
     __syncthreads();
@@ -1307,7 +1338,10 @@ __global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __
         t[i] = by_rows ? tile[p * PB_TILE + b] : tile[b * PB_TILE + p];
     }
     if (threadIdx.x == 0) {
-        e->flags = by_rows ? (e->flags | PB_TILE_TAB_Y) : (e->flags & ~PB_TILE_TAB_Y);
+        int f = e->flags & ~(PB_TILE_TAB_Y | PB_TILE_TAB_PLAIN);
+        if (by_rows) f |= PB_TILE_TAB_Y;
+        if (plain && !PB_BIL_NO_TAB_PLAIN && !(off_bits & 2)) f |= PB_TILE_TAB_PLAIN;
+        e->flags = f;
         e->bil_off = packed;
     }
 }

@@ -836,7 +836,7 @@ __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, 
         const bool solo_r = solo_ok && !solo_l && (fl & PB_TILE_BLACK) && (fr & plain);
         if (solo_l || solo_r) {
             if (solo_r) w = wr;
-            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK | PB_TILE_COARSE | PB_TILE_TD3 | PB_TILE_TAB_Y)) | PB_TILE_SOLO | (solo_r ? PB_TILE_EYE_R : 0);
+            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK | PB_TILE_COARSE | PB_TILE_TD3 | PB_TILE_TAB_Y | PB_TILE_TAB_PLAIN)) | PB_TILE_SOLO | (solo_r ? PB_TILE_EYE_R : 0);
         } else if (two_eye_left) {
             // (the bilinear mode's table: a two-eye slot carries the LEFT eye's entry - the wave has it with its slot, one dependent
             // scalar round trip less - marked PB_TILE_TWO; the right eye's the wave prefetches into lanes)

@@ -116,6 +116,10 @@ static bool pb_test_alloc_fails() {
     return false;
 }
 
+// -DPB_ABLATION only: PB_BIL_OFF=<bits> switches SPEED-ONLY features of the opt-in bilinear mode off at plan creation (tests: the pixels
+// must not depend on them) - 1 half windows, 2 unguarded table tiles, 4 the table tiles' walk, 8 left entries in two-eye slots, 16 the small LDS pool
+static inline bool pb_bil_off(int bit) { return (pb_knob("PB_BIL_OFF", 0) & bit) != 0; }
+
 static thread_local std::string g_err;
 static int pb_fail(int code, const std::string& msg) {
     g_err = msg;
@@ -373,8 +377,12 @@ static int pb_build_bilinear_list(pb_plan* pl) {
                 if (np) hipLaunchKernelGGL(pb_bilinear_fix_coord_kernel<PB_KIND_CAMERA>, fgrid, block, 0, 0, P, pl->fix_px, (int)np, pl->bil_fix_xy, 1, 0);
             }
             // which way each slot is walked (lanes along the direction the source position moves least), slots walked by rows transposed
-            hipLaunchKernelGGL(pb_bilinear_orient_kernel, dim3(pl->n_tiles), dim3(256), 0, 0, pl->table, pl->bil_xy);
-            if (dbl) hipLaunchKernelGGL(pb_bilinear_orient_kernel, dim3(pl->n_tiles), dim3(256), 0, 0, pl->table_r, pl->bil_xy);
+            // ... and whether its taps need the guards at all (PB_TILE_TAB_PLAIN); an eye's taps stay in its half of the frame
+            hipLaunchKernelGGL(pb_bilinear_orient_kernel, dim3(pl->n_tiles), dim3(256), 0, 0, pl->table, pl->bil_xy, P.src.height, P.src.width, 0,
+                               dbl ? P.src_eye_w : P.src.width, pb_knob("PB_BIL_OFF", 0));
+            if (dbl)
+                hipLaunchKernelGGL(pb_bilinear_orient_kernel, dim3(pl->n_tiles), dim3(256), 0, 0, pl->table_r, pl->bil_xy, P.src.height, P.src.width, P.src_eye_w,
+                                   P.src.width, pb_knob("PB_BIL_OFF", 0));
             e = hipDeviceSynchronize();
         }
     }
@@ -818,7 +826,7 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, fresh, unit_dev, units_per_xcd, n_slots, (int)U,
-                           pl->dbl_ready ? pl->table_r : nullptr, (int)UY, (bil && pl->dbl_ready && !PB_BIL_NO_TWO) ? 1 : 0);
+                           pl->dbl_ready ? pl->table_r : nullptr, (int)UY, (bil && pl->dbl_ready && !PB_BIL_NO_TWO && !pb_bil_off(8)) ? 1 : 0);
         e = hipDeviceSynchronize();
     }
     pb_tmp_free(unit_dev);
@@ -922,7 +930,7 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     const dim3 grid((ng + 127) / 128), block(128);
     unsigned res[2] = {0u, 0u};
     hipError_t e = hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
-    if (e == hipSuccess && !PB_BIL_NO_HALVES)  // direct-gather slots that can be served as two half windows
+    if (e == hipSuccess && !PB_BIL_NO_HALVES && !pb_bil_off(1))  // direct-gather slots that can be served as two half windows
     {
         hipLaunchKernelGGL(pb_bilinear_halves_kernel, dim3(ng), dim3(256), 0, 0, pl->ltable_bil, 4u * ng, pl->bil_budget, pl->P.src.height, pl->P.src.width,
                            pl->dbl_ready ? (PB_BIL_HALVES_TWO ? 1 : 3) : 0, counters);
@@ -933,7 +941,7 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
                                pl->P.src.width, 2, counters);
     }
     unsigned pool = full;
-    if (e == hipSuccess && small < full && !PB_BIL_NO_POOL) {
+    if (e == hipSuccess && small < full && !PB_BIL_NO_POOL && !pb_bil_off(16)) {
         hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r_bil : nullptr, ng, tiles_x, small, 1, counters);
         e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
         if (e == hipSuccess && res[1] == 0u && res[0] * 50u <= pl->n_tiles) pool = small;  // (at most 2 % of the tiles lose their window)
