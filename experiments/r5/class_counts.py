@@ -10,4 +10,4 @@ for name in (sys.argv[1:] or ['c1', 'c2', 'c3', 'c5']):
         plan.set_window_budget(b)
         i = plan.info()
         print(name, b, {k: i[k] for k in ('tiles', 'lean_tiles', 'direct_tiles', 'black_tiles', 'fix_tiles', 'fix_pixels')}, flush=True)
-    print(name, 'bilinear mix', plan.bilinear_tile_mix(), flush=True)
+    print(name, 'bilinear mix', plan.bilinear_tile_mix(), plan.bilinear_launch_shape(), flush=True)

@@ -9,7 +9,7 @@ B="--steps 12 --warmup 2 --no-cpu-baseline --no-configs --no-events"
 for c in ${CFGS:-c1 c2 c3 c5}; do
   i=1
   for P in "$P1" "$P2" "$P3"; do
-    bash experiments/r5/sq_pass.sh ${c}_bilinear_${S}_p$i "bilinear.*hot" $P -- python3 $R/bench.py --config $c --sampling bilinear $B || exit 1
+    bash experiments/r5/sq_pass.sh ${c}_bilinear_${S}_p$i "${RX:-bilinear.*(hot|pipe)_kernel}" $P -- python3 $R/bench.py --config $c --sampling bilinear $B || exit 1
     i=$((i+1))
   done
 done

@@ -108,6 +108,7 @@ SIGNATURES = {
     "pb_plan_window_budget": (C.c_int, [_VP]),
     "pb_plan_bilinear_float64_tiles": (C.c_int, [_VP]),
     "pb_plan_bilinear_tile_mix": (C.c_int, [_VP, C.POINTER(C.c_longlong)]),
+    "pb_plan_bilinear_launch_shape": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pb_plan_matches": (C.c_int, [_VP, C.POINTER(pb_proj), C.POINTER(C.c_double), C.c_int, C.POINTER(pb_proj)]),
     "pb_remap_u8": (C.c_int, [_VP, _VP, _VP, C.c_int, C.c_size_t, C.c_size_t, _VP]),
     "pb_remap_u8v": (C.c_int, [_VP, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, _VP]),
@@ -378,6 +379,12 @@ class Plan:
             "window_budget": int(load().pb_plan_window_budget(self._h)),
             "bilinear_float64_tiles": int(load().pb_plan_bilinear_float64_tiles(self._h)),
         }
+
+    def bilinear_launch_shape(self) -> dict:
+        """The bilinear launch's workgroup LDS (bytes) and tiles per wave (1 in the product) - diagnostic."""
+        lds, tpw = C.c_int(), C.c_int()
+        check(load().pb_plan_bilinear_launch_shape(self._h, C.byref(lds), C.byref(tpw)))
+        return {"lds_bytes": lds.value, "tiles_per_wave": tpw.value}
 
     def bilinear_tile_mix(self) -> dict:
         """How the opt-in bilinear mode serves the plan's tiles (diagnostic, synchronous)."""

@@ -33,6 +33,12 @@
 #ifndef PB_BIL_NO_TAB_PLAIN  // A/B builds only: 1 = every table tile on the guarded path
 #define PB_BIL_NO_TAB_PLAIN 0
 #endif
+#ifndef PB_BIL_LDS_AHEAD  // 1: A/B builds only (the LDS reads of the next four pixels issued before four are blended: measured +5..+12 %, more registers)
+#define PB_BIL_LDS_AHEAD 0
+#endif
+#ifndef PB_BIL_POOL_HALVES_FIRST  // 0: A/B builds only (a half-window tile counts like a window tile when the small pool is tried)
+#define PB_BIL_POOL_HALVES_FIRST 1
+#endif
 #ifndef PB_BIL_HALVES_MAX  // bytes both half windows of a PB_TILE_HALVES tile may have in sum
 #define PB_BIL_HALVES_MAX 24576
 #endif
@@ -311,42 +317,51 @@ __device__ __forceinline__ pb_f2 pb_bil_eval(const pb_f2 c[5], const float t) {
 // a0w: the byte offset of the window's first sample from the START OF LDS (the wave's window offset folded in: a multiple of 16, so
 // the byte phase of an address is the sample's) - an address is two multiply-adds and one AND.
 typedef const __attribute__((address_space(3))) unsigned* pb_lds_cptr;
-__device__ __forceinline__ void pb_bil_lds4(const pb_f2 sv[4], unsigned pitch, unsigned a0w, unsigned out[4]) {
+struct PbLdsTaps {  // four pixels' taps on their way out of LDS: the dwords, the byte phases, the weights
     unsigned l0[4], w[4][6];
     float tx[4], ty[4];
+};
+__device__ __forceinline__ void pb_bil_lds4_issue(const pb_f2 sv[4], unsigned pitch, unsigned a0w, PbLdsTaps& T) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        ty[k] = __builtin_amdgcn_fractf(sv[k].x);
-        tx[k] = __builtin_amdgcn_fractf(sv[k].y);
-        l0[k] = pb_umad24((unsigned)(int)sv[k].x, pitch, pb_umad24((unsigned)(int)sv[k].y, 3u, a0w));
-        if (PB_BIL_ABL & 2) l0[k] = (l0[k] & 3u) + (a0w & ~15u) + 64u;  // every lane reads the same dwords: no bank conflicts
-        const unsigned b0 = l0[k] & ~3u;  // (the pitch is a multiple of 16: both rows share the byte phase)
+        T.ty[k] = __builtin_amdgcn_fractf(sv[k].x);
+        T.tx[k] = __builtin_amdgcn_fractf(sv[k].y);
+        T.l0[k] = pb_umad24((unsigned)(int)sv[k].x, pitch, pb_umad24((unsigned)(int)sv[k].y, 3u, a0w));
+        if (PB_BIL_ABL & 2) T.l0[k] = (T.l0[k] & 3u) + (a0w & ~15u) + 64u;  // every lane reads the same dwords: no bank conflicts
+        const unsigned b0 = T.l0[k] & ~3u;  // (the pitch is a multiple of 16: both rows share the byte phase)
         const pb_lds_cptr r0 = (pb_lds_cptr)(uintptr_t)b0, r1 = (pb_lds_cptr)(uintptr_t)(b0 + pitch);
-        w[k][0] = r0[0];
-        w[k][1] = r0[1];
-        w[k][2] = r0[2];
-        w[k][3] = r1[0];
-        w[k][4] = r1[1];
-        w[k][5] = r1[2];
+        T.w[k][0] = r0[0];
+        T.w[k][1] = r0[1];
+        T.w[k][2] = r0[2];
+        T.w[k][3] = r1[0];
+        T.w[k][4] = r1[1];
+        T.w[k][5] = r1[2];
     }
+}
+__device__ __forceinline__ void pb_bil_lds4_blend(const PbLdsTaps& T, unsigned out[4]) {
 #pragma unroll
     for (int k = 0; k < 4; k += 2) {
         unsigned lo0[2], hi0[2], lo1[2], hi1[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            lo0[i] = __builtin_amdgcn_alignbyte(w[k + i][1], w[k + i][0], l0[k + i]);
-            hi0[i] = __builtin_amdgcn_alignbyte(w[k + i][2], w[k + i][1], l0[k + i]);
-            lo1[i] = __builtin_amdgcn_alignbyte(w[k + i][4], w[k + i][3], l0[k + i]);
-            hi1[i] = __builtin_amdgcn_alignbyte(w[k + i][5], w[k + i][4], l0[k + i]);
+            lo0[i] = __builtin_amdgcn_alignbyte(T.w[k + i][1], T.w[k + i][0], T.l0[k + i]);
+            hi0[i] = __builtin_amdgcn_alignbyte(T.w[k + i][2], T.w[k + i][1], T.l0[k + i]);
+            lo1[i] = __builtin_amdgcn_alignbyte(T.w[k + i][4], T.w[k + i][3], T.l0[k + i]);
+            hi1[i] = __builtin_amdgcn_alignbyte(T.w[k + i][5], T.w[k + i][4], T.l0[k + i]);
         }
-        const pb_f2 tx2 = {tx[k], tx[k + 1]}, ty2 = {ty[k], ty[k + 1]};
+        const pb_f2 tx2 = {T.tx[k], T.tx[k + 1]}, ty2 = {T.ty[k], T.ty[k + 1]};
         if (PB_BIL_ABL & 8) {
-            out[k] = lo0[0] ^ hi0[0] ^ lo1[0] ^ hi1[0] ^ __float_as_uint(tx[k] + ty[k]);
-            out[k + 1] = lo0[1] ^ hi0[1] ^ lo1[1] ^ hi1[1] ^ __float_as_uint(tx[k + 1] + ty[k + 1]);
+            out[k] = lo0[0] ^ hi0[0] ^ lo1[0] ^ hi1[0] ^ __float_as_uint(T.tx[k] + T.ty[k]);
+            out[k + 1] = lo0[1] ^ hi0[1] ^ lo1[1] ^ hi1[1] ^ __float_as_uint(T.tx[k + 1] + T.ty[k + 1]);
         } else {
             pb_bil_mix64x2(lo0, hi0, lo1, hi1, tx2, ty2, &out[k]);
         }
     }
+}
+__device__ __forceinline__ void pb_bil_lds4(const pb_f2 sv[4], unsigned pitch, unsigned a0w, unsigned out[4]) {
+    PbLdsTaps T;
+    pb_bil_lds4_issue(sv, pitch, a0w, T);
+    pb_bil_lds4_blend(T, out);
 }
 
 // the three bytes of a pixel at byte offset o of the frame as the low bytes of a dword; the frame's very last pixel is read one byte
@@ -534,6 +549,32 @@ __device__ __forceinline__ void pb_bil_direct_gather(const uint8_t* __restrict__
     }
 }
 
+// The window path's sixteen pixels of a lane, four at a time (ALONG_X: the four rows of one column, else the four columns of one row - the
+// order the model is collapsed in), the LDS reads of group g + 1 issued before group g is blended.
+template <bool TD3, bool ALONG_X>
+__device__ __forceinline__ void pb_bil_window_groups(const PbTileEntry* __restrict__ e, const int xg, const int yb, const unsigned pitch, const unsigned a0w,
+                                                     unsigned v[16]) {
+    const pb_f2 half = {0.5f, 0.5f};
+    PbLdsTaps T[2];
+#pragma unroll
+    for (int g = 0; g <= 4; ++g) {
+        if (g < 4) {
+            pb_f2 c[5], sv[4];
+            pb_bil_collapse<TD3>(e, ALONG_X, ALONG_X ? 4 * xg + g : yb + 8 * g, c);
+            c[0] = c[0] - half;  // s = f - 0.5, folded into the constant term (window path and direct path alike)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sv[m] = pb_bil_eval<TD3>(c, pb_tile_coord(ALONG_X ? yb + 8 * m : 4 * xg + m));
+            pb_bil_lds4_issue(sv, pitch, a0w, T[g & 1]);
+        }
+        if (g > 0) {
+            unsigned o[4];
+            pb_bil_lds4_blend(T[(g - 1) & 1], o);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v[ALONG_X ? m * 4 + (g - 1) : (g - 1) * 4 + m] = o[m];
+        }
+    }
+}
+
 // The HALVES path of a plain tile (PB_TILE_HALVES): the two half windows staged one after the other in the wave's LDS region, the
 // lane's eight pixels of each half sampled from it like a window tile's.  The model is evaluated in the order the direct path would use
 // for the tile (the slot's window geometry was measured with exactly this evaluation: pb_bilinear_halves_kernel).
@@ -592,9 +633,10 @@ __device__ __forceinline__ void pb_bil_halves_vals(const PbHot& Hd, const PbTile
 }
 
 // The window and the direct-gather path of a plain tile (LEAN / DIRECT), on the full tile model or on its TD3 part.
+// win_state (experiments/r5/pb_pipe_experiment.hpp only; 0 in the product): a LEAN tile's window loads are 0 still to issue, 1 issued, 2 landed.
 template <bool TD3>
 __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileEntry* __restrict__ e, const int flags, const int lane, unsigned* win,
-                                                  const int windows, const uint8_t* __restrict__ s, unsigned v[16]) {
+                                                  const int windows, const uint8_t* __restrict__ s, unsigned v[16], const int win_state = 0) {
     const int xg = lane & 7, yb = lane >> 3;
     const unsigned rowbytes = 3u * (unsigned)Hd.src_w, frame_bytes = rowbytes * (unsigned)Hd.src_h, safe_len = frame_bytes & ~15u;
     const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
@@ -602,11 +644,18 @@ __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileE
     if (!(PB_BIL_PATHS & 1) && (flags & PB_TILE_LEAN) && windows) return;
     if ((PB_BIL_PATHS & 1) && (flags & PB_TILE_LEAN) && windows) {
         const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
-        if (!(PB_BIL_ABL & 4)) pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(PB_BIL_ABL & 4) && win_state == 0) pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
+        if (win_state != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pb_wave_sync();
         const pb_f2 half = {0.5f, 0.5f};
         const unsigned a0w = a0 + (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)win;  // (LDS addresses are 32-bit offsets)
+#if PB_BIL_LDS_AHEAD
+        // Two groups of four pixels in flight: the LDS reads of group g + 1 are issued before group g is blended, so a wave's wait for LDS
+        // (16 reads, ~60 % of them bank-conflicted) overlaps its own arithmetic instead of another wave's (the launches hold 3-4 waves
+        // per SIMD; a wave waited for LDS four times per tile with nothing of its own to issue).
+        if (along_x) pb_bil_window_groups<TD3, true>(e, xg, yb, pitch, a0w, v);
+        else pb_bil_window_groups<TD3, false>(e, xg, yb, pitch, a0w, v);
+#else
         if (along_x) {
             PB_MARK("window_colfirst");
 #pragma unroll
@@ -633,6 +682,7 @@ __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileE
                 pb_bil_lds4(sv, pitch, a0w, &v[jr * 4]);
             }
         }
+#endif
         PB_MARK("end");
         pb_wave_sync();  // every lane has read its taps: the window may be refilled (the other eye, the next path)
         return;
@@ -687,7 +737,7 @@ __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileE
 template <bool WRAP>
 __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* __restrict__ e, const int flags, const int lane, unsigned* win,
                                             const int windows, const uint8_t* __restrict__ s, const PbBilCoord* __restrict__ bil_xy, const int cmin,
-                                            const int cmax, unsigned v[16]) {
+                                            const int cmax, unsigned v[16], const int win_state = 0) {
     const int xg = lane & 7, yb = lane >> 3;
     const int h = Hd.src_h, w = Hd.src_w;
     const unsigned frame_bytes = 3u * (unsigned)w * (unsigned)h;
@@ -744,9 +794,9 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
 #ifdef PB_BIL_NO_TD3  // A/B builds only (experiments/r5/): the full tile model everywhere
     if (false) pb_bil_model_vals<true>(Hd, e, flags, lane, win, windows, s, v);
 #else
-    if (flags & PB_TILE_TD3) pb_bil_model_vals<true>(Hd, e, flags, lane, win, windows, s, v);
+    if (flags & PB_TILE_TD3) pb_bil_model_vals<true>(Hd, e, flags, lane, win, windows, s, v, win_state);
 #endif
-    else pb_bil_model_vals<false>(Hd, e, flags, lane, win, windows, s, v);
+    else pb_bil_model_vals<false>(Hd, e, flags, lane, win, windows, s, v, win_state);
 }
 
 // the lane's four 12-byte stores (4 consecutive pixels x 4 rows); tiles on the image's edge are clipped
@@ -1210,9 +1260,14 @@ __global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const 
     unsigned demoted = 0;
     for (;;) {
         if (need[0] + need[1] + need[2] + need[3] <= pool_bytes) break;
+        // (half-window tiles first: they go back to the direct path they came from, and do not count against the pool - PB_BIL_POOL_HALVES_FIRST)
         int big = -1;
-        for (int w = 0; w < 4; ++w)
-            if (solo_lean[w] && need[w] > (unsigned)PB_DIRECT_LDS_BYTES + 16u && (big < 0 || need[w] > need[big])) big = w;
+        bool big_half = false;
+        for (int w = 0; w < 4; ++w) {
+            if (!solo_lean[w] || need[w] <= (unsigned)PB_DIRECT_LDS_BYTES + 16u) continue;
+            const bool half = PB_BIL_POOL_HALVES_FIRST && (ltable[4u * g + w].flags & PB_TILE_HALVES) != 0;
+            if (big < 0 || (half && !big_half) || (half == big_half && need[w] > need[big])) { big = w; big_half = half; }
+        }
         if (big < 0) {
             atomicAdd(&counters[1], 1u);
             return;  // (the host falls back to the pool that always fits)
@@ -1220,7 +1275,7 @@ __global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const 
         need[big] = (unsigned)PB_DIRECT_LDS_BYTES + 16u;
         solo_lean[big] = false;
         if (!dry) ltable[4u * g + big].flags = (ltable[4u * g + big].flags & ~(PB_TILE_LEAN | PB_TILE_HALVES)) | PB_TILE_DIRECT;
-        ++demoted;
+        if (!big_half) ++demoted;
     }
     if (demoted) atomicAdd(&counters[0], demoted);
     if (dry) return;
@@ -1392,3 +1447,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_fix_kernel(const 
         o[2] = (uint8_t)((v >> 16) & 0xFF);
     }
 }
+
+#ifdef PB_BIL_PIPE_EXPERIMENT  // A/B builds only: the pipelined launch measured and rejected in round 5 (experiments/README.md)
+#include "../../experiments/r5/pb_pipe_experiment.hpp"
+#endif

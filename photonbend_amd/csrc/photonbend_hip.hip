@@ -89,6 +89,7 @@ struct pb_plan {
     unsigned launch_groups_bil = 0;
     int bil_budget = 0;
     unsigned bil_pool_bytes = 0;  // dynamic LDS of a bilinear launch's workgroup: the slots' regions are packed into it (pb_bilinear_pool_kernel)
+    unsigned bil_pipe_wgs = 0;    // always 0 in the product (> 0: the -DPB_BIL_PIPE_EXPERIMENT build's pipelined launch, workgroups per frame)
     PbParams* P_dev = nullptr;   // device copy of P as the hot launches see it (refreshed with every budget change)
     unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
     int walk = 0;                // launch-order rule: 0 = by policy (pb_build_launch_table), 1 = plain, 2 = rows from the heaviest outwards,
@@ -890,6 +891,12 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
 #ifndef PB_BIL_HALVES_TWO  // A/B builds only: 1 = half windows for the eyes of two-eye tiles too
 #define PB_BIL_HALVES_TWO 0
 #endif
+#ifndef PB_BIL_NO_PIPE  // A/B builds only: 1 = never the pipelined launch
+#define PB_BIL_NO_PIPE 0
+#endif
+#ifndef PB_BIL_PIPE_POOL  // the pipelined workgroups' LDS pool: two of them per CU (160 KiB of LDS)
+#define PB_BIL_PIPE_POOL 80896u
+#endif
 #ifndef PB_BIL_NO_POOL  // A/B builds only: 1 = always the full pool (round 4's occupancy)
 #define PB_BIL_NO_POOL 0
 #endif
@@ -941,6 +948,37 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
                                pl->P.src.width, 2, counters);
     }
     unsigned pool = full;
+    pl->bil_pipe_wgs = 0;
+#ifdef PB_BIL_PIPE_EXPERIMENT  // A/B builds only (experiments/r5/pb_pipe_experiment.hpp: measured, rejected)
+    if (e == hipSuccess && !pl->dbl_ready && !PB_BIL_NO_PIPE && !pb_bil_off(32) && ng % 8u == 0u) {
+        // the pipelined launch (two workgroups per CU, each wave PB_BIL_PIPE tiles with the next window in flight) where its pool holds
+        // the windows (few demotions) and the runtime grants a workgroup that much LDS
+        const unsigned n_wgs = 8u * ((ng / 8u + (unsigned)PB_BIL_PIPE - 1u) / (unsigned)PB_BIL_PIPE);
+        const dim3 pgrid((n_wgs + 127) / 128);
+        hipLaunchKernelGGL(pb_bilinear_pipe_pool_kernel, pgrid, block, 0, 0, pl->ltable_bil, ng, n_wgs, (unsigned)PB_BIL_PIPE_POOL, 1, counters);
+        e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
+        bool ok = e == hipSuccess && res[1] == 0u && res[0] * 50u <= pl->n_tiles;
+        if (ok) {
+            const void* fn = pl->P.src.kind == PB_KIND_PANO ? (const void*)pb_bilinear_pipe_kernel<PB_KIND_PANO> : (const void*)pb_bilinear_pipe_kernel<PB_KIND_CAMERA>;
+            ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_BIL_PIPE_POOL + PB_BIL_LDS_PAD) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+        }
+        if (ok) {
+            e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(pb_bilinear_pipe_pool_kernel, pgrid, block, 0, 0, pl->ltable_bil, ng, n_wgs, (unsigned)PB_BIL_PIPE_POOL, 0, counters);
+                e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
+            }
+            if (e == hipSuccess && res[1] == 0u) {
+                pb_tmp_free(counters);
+                pl->bil_pool_bytes = PB_BIL_PIPE_POOL;
+                pl->bil_pipe_wgs = n_wgs;
+                return PB_OK;
+            }
+        }
+        if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
+    }
+#endif
     if (e == hipSuccess && small < full && !PB_BIL_NO_POOL && !pb_bil_off(16)) {
         hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r_bil : nullptr, ng, tiles_x, small, 1, counters);
         e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
@@ -1297,6 +1335,13 @@ int pb_plan_bilinear_tile_mix(const pb_plan* plan, long long mix[8]) {
     PB_HIP(e);
     return PB_OK;
 }
+int pb_plan_bilinear_launch_shape(const pb_plan* plan, int* lds_bytes, int* tiles_per_wave) {
+    if (!plan || !lds_bytes || !tiles_per_wave) return pb_fail(PB_ERR_INVALID, "null argument");
+    const bool tiles = (plan->fast_ready || plan->dbl_ready) && plan->ltable_bil && plan->launch_groups_bil > 0;
+    *lds_bytes = tiles ? (int)plan->bil_pool_bytes : 0;
+    *tiles_per_wave = tiles ? (plan->bil_pipe_wgs ? 4 : 1) : 0;
+    return PB_OK;
+}
 int pb_plan_window_budget(const pb_plan* plan) {
     return (plan && (plan->fast_ready || plan->dbl_ready)) ? plan->P.win_budget : 0;
 }
@@ -1504,10 +1549,22 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         const int windows = plan->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
                             ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
         const int per_launch = (int)(0x7FFFFFFFu / gpf);
+#ifdef PB_BIL_PIPE_EXPERIMENT
+#define PB_LAUNCH_BILINEAR_PIPE(KIND)                                                                                                \
+    if (plan->bil_pipe_wgs)                                                                                                          \
+        hipLaunchKernelGGL((pb_bilinear_pipe_kernel<KIND>), dim3(plan->bil_pipe_wgs * (unsigned)nf), block, (size_t)plan->bil_pool_bytes + PB_BIL_LDS_PAD, st, \
+                           pb_hot_of_host(Pb), plan->ltable_bil, src_dev + (unsigned long long)f0 * src_frame_stride,                \
+                           dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, plan->bil_pipe_wgs, (unsigned long long)src_frame_stride, \
+                           (unsigned long long)dst_frame_stride, windows, plan->bil_xy, plan->fix_px, plan->bil_fix_xy);             \
+    else
+#else
+#define PB_LAUNCH_BILINEAR_PIPE(KIND)
+#endif
 #define PB_LAUNCH_BILINEAR(KIND)                                                                                                     \
     do {                                                                                                                             \
         for (int f0 = 0; f0 < n_frames; f0 += per_launch) {                                                                          \
             const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;                                                  \
+            PB_LAUNCH_BILINEAR_PIPE(KIND)                                                                                            \
             hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, (size_t)plan->bil_pool_bytes + PB_BIL_LDS_PAD, st, pb_hot_of_host(Pb), plan->ltable_bil, \
                                src_dev + (unsigned long long)f0 * src_frame_stride, dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, \
                                (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy, plan->fix_px, \

@@ -34,7 +34,7 @@ for case in cases:
     frame = nat.synth_frame(case.src[1], case.src[2], frame=3, seed=11, circle_mask=case.mask)
     got = plan.remap(frame, interpolation="bilinear")
     out[case.name] = {"sha256": hashlib.sha256(got.cpu().numpy().tobytes()).hexdigest(), "mix": plan.bilinear_tile_mix(),
-                      "float64_tiles": plan.info()["bilinear_float64_tiles"]}
+                      "float64_tiles": plan.info()["bilinear_float64_tiles"], "shape": plan.bilinear_launch_shape()}
 json.dump(out, open(sys.argv[1], "w"))
 """
 
@@ -63,5 +63,6 @@ def test_speed_only_features_do_not_move_a_bit(tmp_path):
     # the features were really exercised in one run and really absent in the other
     assert sum(r["mix"]["half_windows"] for r in on.values()) > 1000 and sum(r["mix"]["table_plain"] for r in on.values()) > 1000
     assert sum(r["mix"]["half_windows"] for r in off.values()) == 0 and sum(r["mix"]["table_plain"] for r in off.values()) == 0
+    assert any(r["shape"]["lds_bytes"] == 40448 for r in on.values()) and all(r["shape"]["lds_bytes"] != 40448 for r in off.values())  # (the small LDS pool)
     for name in ("c2", "c3"):
         assert on[name]["mix"]["half_windows"] > 0 and on[name]["mix"]["window"] > off[name]["mix"]["window"], (name, on[name]["mix"], off[name]["mix"])
