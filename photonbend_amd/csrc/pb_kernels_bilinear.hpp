@@ -1038,32 +1038,43 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinea
     unsigned a[16];
     if ((PB_BIL_ABL & 128) && (entry.flags & PB_TILE_SOLO)) return;   // skip one-eye tiles
     if ((PB_BIL_ABL & 256) && !(entry.flags & PB_TILE_SOLO)) return;  // skip two-eye tiles
-    if (entry.flags & PB_TILE_SOLO) {
-        if (entry.bil_off >= 0 && !bil_xy) return;  // (no coordinate table: on the plan's float64 list)
-        const bool right = (entry.flags & PB_TILE_EYE_R) != 0;
-        pb_bil_vals<false>(Hd, &entry, entry.flags, lane, win, windows, src, bil_xy, right ? eye_w : 0, right ? Hd.src_w : eye_w, a);
-        pb_bil_store<false>(a, dst, X0, Y0, lane, W, H);
-        return;
-    }
+    // ONE instance of the tile code serves a one-eye tile (one pass: the slot's entry is the live eye's) and both eyes of a two-eye tile
+    // (two passes): three inlined instances - one-eye, left, right - kept 200 SGPR spills alive in this kernel (the 64-SGPR entry went
+    // through VGPR lanes at every use; profiles/r05_c5_bilinear_final_sq.txt: 1 460 vector instructions per wave against 1 075 at the
+    // start of the round, vector units 81 % busy).
+    const bool solo = (entry.flags & PB_TILE_SOLO) != 0;
     const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
     // Two eyes.  The RIGHT eye's entry is on its way into one vector register (lane i = dword i of the 256-byte entry: one coalesced
     // load, issued before anything else) while the left eye is sampled; the LEFT eye's entry came with the slot (PB_TILE_TWO).  Round 4
     // fetched both with dependent scalar loads, one before each eye: three serial round trips per two-eye wave before its first
     // window load, where a one-eye wave makes one (c5's 4 448 two-eye tiles, 13.6 % of its tiles, cost 36 of 106 us).
-    const unsigned rlane = reinterpret_cast<const unsigned*>(table_r + tile)[lane];
-    if (!(entry.flags & PB_TILE_TWO)) pb_load_entry(table_l + tile, entry);
+    unsigned rlane = 0;
+    if (!solo) {
+        rlane = reinterpret_cast<const unsigned*>(table_r + tile)[lane];
+        if (!(entry.flags & PB_TILE_TWO)) pb_load_entry(table_l + tile, entry);
+    }
     const int fl0 = entry.flags & ~PB_TILE_TWO, lat_slot = entry.aux_off, nl = entry.fix_cnt, off_l = entry.fix_off;
-    if (entry.bil_off >= 0 && !bil_xy) return;
+    const bool solo_right = solo && (fl0 & PB_TILE_EYE_R) != 0;
+    int fl = fl0, cmin = solo_right ? eye_w : 0, cmax = (solo && !solo_right) || !solo ? eye_w : Hd.src_w;
     unsigned al[16];
-    pb_bil_vals<false>(Hd, &entry, fl0, lane, win, windows, src, bil_xy, 0, eye_w, al);
-    {
+    for (int pass = 0;; ++pass) {
+        if (entry.bil_off >= 0 && !bil_xy) return;  // (no coordinate table: on the plan's float64 list)
+        pb_bil_vals<false>(Hd, &entry, fl, lane, win, windows, src, bil_xy, cmin, cmax, a);
+        if (solo || pass == 1) break;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) al[n] = a[n];
         int* w = reinterpret_cast<int*>(&entry);
 #pragma unroll
         for (int i = 0; i < 64; ++i) w[i] = __builtin_amdgcn_readlane((int)rlane, i);
+        fl = entry.flags;
+        cmin = eye_w;
+        cmax = Hd.src_w;
     }
-    if (entry.bil_off >= 0 && !bil_xy) return;
+    if (solo) {
+        pb_bil_store<false>(a, dst, X0, Y0, lane, W, H);
+        return;
+    }
     const int nr = entry.fix_cnt, off_r = entry.fix_off;
-    pb_bil_vals<false>(Hd, &entry, entry.flags, lane, win, windows, src, bil_xy, eye_w, Hd.src_w, a);
     if (fl0 & PB_TILE_FAILED) {
         // the faithful factors of every pixel of a failed tile (slot = the right-eye entry's aux_off, pb_double_tables_kernel)
         const PbDoubleFix* __restrict__ slot = tile_fix + (size_t)entry.aux_off * (PB_TILE * PB_TILE);
