@@ -66,3 +66,46 @@ def test_speed_only_features_do_not_move_a_bit(tmp_path):
     assert any(r["shape"]["lds_bytes"] == 40448 for r in on.values()) and all(r["shape"]["lds_bytes"] != 40448 for r in off.values())  # (the small LDS pool)
     for name in ("c2", "c3"):
         assert on[name]["mix"]["half_windows"] > 0 and on[name]["mix"]["window"] > off[name]["mix"]["window"], (name, on[name]["mix"], off[name]["mix"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c2", "c3", "mid_dbl", "mid_pole"])
+def test_frames_lds_dma_cannot_address_give_the_same_pixels(name):
+    """A source frame that is not 16-byte aligned cannot be staged by LDS-DMA: window and half-window tiles then take the direct-gather
+    path (same taps, same weights).  Same bytes as from an aligned frame - single frames and a batch whose frame stride is odd - and as
+    from the plan in MODE_FAST_DIRECT (no windows at all)."""
+    import torch
+
+    from photonbend_amd import _native as nat
+    from tests import helpers as H
+    from tests.cases import Case, dbl, full_cases, pano
+
+    cases = {c.name: c for c in full_cases()}
+    cases["mid_dbl"] = Case("mid_dbl", pano(1024, 2048), dbl(972, 1944, "equidistant", 190), mask=2)
+    cases["mid_pole"] = Case("mid_pole", pano(512, 1024), pano(1536, 3072), rotations=[(90.0, 0.0, 0.0)])
+    case = cases[name]
+    plan = H.pb_plan_private(case)
+    _, h, w, *_ = case.src
+    n = h * w * 3
+    frames = [nat.synth_frame(h, w, frame=f, seed=5, circle_mask=case.mask) for f in range(2)]
+    want = [plan.remap(f, interpolation="bilinear") for f in frames]
+    # one byte into a larger buffer: the pointer is odd
+    buf = torch.empty(2 * n + 64, dtype=torch.uint8, device="cuda")
+    for k, f in enumerate(frames):
+        odd = buf[1:1 + n].view(h, w, 3)
+        odd.copy_(f)
+        assert odd.data_ptr() % 16 != 0
+        got = plan.remap(odd, interpolation="bilinear")
+        assert torch.equal(got, want[k]), f"frame {k}: an unaligned frame changes {int((got != want[k]).any(dim=2).sum())} pixels"
+    # a batch of two frames at an odd stride (the second frame is unaligned): through the C ABI
+    stride = n + 3
+    both = torch.empty(2 * stride, dtype=torch.uint8, device="cuda")
+    for k, f in enumerate(frames):
+        both[k * stride:k * stride + n].copy_(f.reshape(-1))
+    out = torch.empty((2, case.dst[1], case.dst[2], 3), dtype=torch.uint8, device="cuda")
+    nat.check(nat.load().pb_remap_bilinear_u8(plan._h, both.data_ptr(), out.data_ptr(), 2, stride, 0, nat.current_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], want[0]) and torch.equal(out[1], want[1])
+    plan.set_mode(nat.MODE_FAST_DIRECT)
+    got = plan.remap(frames[0], interpolation="bilinear")
+    assert torch.equal(got, want[0]), f"MODE_FAST_DIRECT changes {int((got != want[0]).any(dim=2).sum())} pixels"
