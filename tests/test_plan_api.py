@@ -103,8 +103,13 @@ def test_deferred_prepare_serialize_roundtrip(case):
     twin = nat.Plan.deserialize(blob, d, rots, s)
     assert twin.info() == info
     assert torch.equal(twin.remap(frames), faithful) and torch.equal(twin.remap(frames[1]), faithful[1])
+    # the opt-in bilinear mode's launch (its own budget, table copies, half windows, LDS pool) is rebuilt from the blob: same tiles, same bytes
+    bil = plan.remap(frames, interpolation="bilinear").clone()
+    assert twin.bilinear_tile_mix() == plan.bilinear_tile_mix() and twin.bilinear_launch_shape() == plan.bilinear_launch_shape()
+    assert torch.equal(twin.remap(frames, interpolation="bilinear"), bil)
     twin.set_window_budget(12288)  # the certified flags travel with the blob
     assert twin.info()["lean_tiles"] >= info["lean_tiles"] and torch.equal(twin.remap(frames), faithful)
+    assert torch.equal(twin.remap(frames, interpolation="bilinear"), bil)  # (the nearest mode's budget does not reach the bilinear mode's tables)
     # a corrupted blob is rejected, not uploaded
     bad = bytearray(blob)
     bad[len(bad) // 2] ^= 0x40
