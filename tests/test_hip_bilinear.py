@@ -67,7 +67,7 @@ def test_bilinear_matches_definition(case, mode):
     rim = np.zeros_like(black)
     for dy, dx in ((0, 1), (1, 0), (0, -1), (-1, 0), (1, 1), (1, -1), (-1, 1), (-1, -1)):
         rim |= black != np.roll(np.roll(black, dy, axis=0), dx, axis=1)
-    limit = 2 if case.src[0] == "double" else 1
+    limit = 1
     inside = d[~rim]
     assert int((inside > limit).sum()) == 0, f"{int((inside > limit).sum())} pixels off the black rims differ by more than {limit} LSB (max {int(inside.max())})"
     assert int(rim.sum()) <= n // 8 and int((d > 0).sum()) <= n // 8, f"{int((d > 0).sum())} of {n} pixels differ"
@@ -131,8 +131,9 @@ def test_bilinear_full_size_against_definition(case):
     """the bilinear mode at the sizes it is benchmarked at (c1, c2, c3, c5 at 180 and 195 degrees), on the
     synthetic NOISE frame (255 LSB per pixel of coordinate error), against oracle.remap_bilinear's values captured at full size
     (tests/golden/full_bilinear.npz, oracle/make_goldens.py --full-bilinear): 65 536 seeded samples, two whole 128 x 128 crops
-    (centre; rim / seam), the number of black pixels and the sum of all bytes.  +-1 LSB (+-2 for the double blend) everywhere but
-    on the one-pixel rim of the black regions."""
+    (centre; rim / seam), the number of black pixels and the sum of all bytes.  +-1 LSB EVERYWHERE, the double blend and the one-pixel
+    rims of the black regions included, and no sample black in one output and not in the other (round 5: the allowances of rounds 3-4 -
+    2 LSB on the blend, flips, rim pixels - were not in use any more; tests/test_hip_bilinear_map.py checks every pixel)."""
     pin = H.load_full()[case.name]
     gold = np.load(os.path.join(H.GOLD, "full_bilinear.npz"))
     plan = H.pb_plan_private(case)
@@ -157,7 +158,7 @@ def test_bilinear_full_size_against_definition(case):
     flips = ((got == 0).all(axis=1) != (want == 0).all(axis=1))  # black <-> sampled: a validity / image boundary within float32 reach
     off = int(((d > limit) & ~flips).sum())
     assert off == 0, f"{off} of 65536 sampled pixels beyond {limit} LSB (max {int(d[~flips].max())})"
-    assert int(flips.sum()) <= 8, f"{int(flips.sum())} sampled pixels flipped between black and sampled"
+    assert int(flips.sum()) == 0, f"{int(flips.sum())} sampled pixels flipped between black and sampled"
     assert int((d > 0).sum()) <= 65536 // 20, f"{int((d > 0).sum())} of 65536 samples differ at all"
     for tag, (r0, c0) in pin["bilinear"]["crops"].items():
         wantc = gold[f"{case.name}/crop_{tag}"]
@@ -165,7 +166,7 @@ def test_bilinear_full_size_against_definition(case):
         dc = diff(gotc, wantc)
         rim = _rim_of((wantc == 0).all(axis=2))
         assert int((dc[~rim] > limit).sum()) == 0, f"crop {tag}: {int((dc[~rim] > limit).sum())} pixels off the black rims beyond {limit} LSB (max {int(dc[~rim].max())})"
-        assert int((dc[rim] > limit).sum()) <= max(4, int(rim.sum()) // 50), f"crop {tag}: {int((dc[rim] > limit).sum())} of {int(rim.sum())} rim pixels differ"
+        assert int((dc[rim] > limit).sum()) == 0, f"crop {tag}: {int((dc[rim] > limit).sum())} of {int(rim.sum())} rim pixels differ"
     black = int((out == 0).all(dim=2).sum())
     assert abs(black - pin["bilinear"]["black_pixels"]) <= 64, (black, pin["bilinear"]["black_pixels"])
     total = int(out.to(torch.int64).sum())
@@ -194,11 +195,9 @@ def test_bilinear_double_tiles_against_float64_at_full_size(fov):
     rim = torch.zeros_like(black)
     for dy, dx in ((0, 1), (1, 0), (0, -1), (-1, 0), (1, 1), (1, -1), (-1, 1), (-1, -1)):
         rim |= black != torch.roll(black, (dy, dx), (0, 1))
-    n_off = int(((d > 2) & ~rim).sum())
-    assert n_off == 0, f"{n_off} pixels off the black rims differ by more than 2 LSB (max {int(d[~rim].max())})"
-    assert int(((d > 2) & rim).sum()) <= d.numel() // 20000, int(((d > 2) & rim).sum())
-    assert int((d > 1).sum()) <= d.numel() // 2000, f"{int((d > 1).sum())} of {d.numel()} pixels differ by more than 1 LSB"
-    assert int((d > 0).sum()) <= d.numel() // 20, int((d > 0).sum())
+    # round 5: no pixel beyond 1 LSB, the rims included (rounds 3-4 allowed 2 LSB and more on the rims: no longer in use)
+    assert int((d > 1).sum()) == 0, f"{int((d > 1).sum())} of {d.numel()} pixels differ by more than 1 LSB (max {int(d.max())}; {int(((d > 1) & rim).sum())} on a black rim)"
+    assert int((d > 0).sum()) <= d.numel() // 100, int((d > 0).sum())
 
 
 def _noise_cases():
@@ -215,18 +214,28 @@ def _noise_cases():
 @pytest.mark.parametrize("case", _noise_cases(), ids=lambda c: f"{c.name}:{c.dst[0]}{c.dst[1]}x{c.dst[2]}<-{c.src[0]}{c.src[1]}x{c.src[2]}:r{len(c.rotations)}")
 def test_bilinear_tiles_on_noise_frames(case):
     """The steepest content there is - independent random texels - shows every coordinate error as a value error (255 LSB per
-    pixel of offset).  Round 3: certification measures each tile model against the faithful pre-truncation coordinate and the
-    bilinear kernels leave tiles beyond 1/1024 px (PB_TILE_COARSE: small images, lens-domain edges) to the float64 pass - a fuzz
-    run had found 0.7 % of such pixels beyond 2 LSB on 40-300 px images.  Tile kernels against the float64 kernel of the same mode:
-    <= 2 LSB, but for a handful of pixels on a black / sampled rim."""
+    pixel of offset), on sixteen random geometries of 70-1000 px (small images: 32-px tiles span tens of degrees).  Round 3:
+    certification measures each tile model against the faithful pre-truncation coordinate and the bilinear kernels leave tiles beyond
+    1/1024 px (PB_TILE_COARSE) to exact coordinates.  Round 5: against the per-pixel DEFINITION kernel (pb_sample_map_bilinear_u8, equal
+    to oracle.remap_bilinear to the bit) - single sources: no pixel beyond 1 LSB; double-fisheye sources: two eye samples of +-1 LSB
+    blended and truncated like the reference's can land 2 LSB off (measured: 9 pixels of 5.4 million), never more.  The float64-mode
+    kernel of the same plan (MODE_FAITHFUL) stays within 1 LSB of the definition everywhere."""
     plan = H.pb_plan_private(case)
     info = plan.info()
     assert info["bilinear_float64_tiles"] == 0  # (round 4: every tile the models cannot serve has its exact coordinates in the plan)
     frame = nat.synth_frame(case.src[1], case.src[2], frame=5)
+    src, cmap = H.pb_chain(case, frame)
+    want = nat.sample_map_bilinear(src._proj("src"), cmap.device_tensor(), frame, 3, np.uint8).reshape(case.dst[1], case.dst[2], 3).to(torch.int16)
     got = plan.remap(frame, interpolation="bilinear").to(torch.int16)
     plan.set_mode(nat.MODE_FAITHFUL)
-    want = plan.remap(frame, interpolation="bilinear").to(torch.int16)
-    d = (got - want).abs()
-    d = torch.minimum(d, 256 - d).amax(dim=2)
-    off = int((d > 2).sum())
-    assert off <= max(8, d.numel() // 50000), f"{off} of {d.numel()} pixels beyond 2 LSB"
+    f64 = plan.remap(frame, interpolation="bilinear").to(torch.int16)
+
+    def dist(a, b):
+        d = (a - b).abs()
+        return torch.minimum(d, 256 - d).amax(dim=2)
+
+    d = dist(got, want)
+    double = case.src[0] == "double"
+    assert int((d > (2 if double else 1)).sum()) == 0, f"{int((d > 1).sum())} of {d.numel()} pixels beyond 1 LSB, max {int(d.max())}"
+    assert int((d > 1).sum()) <= max(8, d.numel() // 50000), f"{int((d > 1).sum())} of {d.numel()} pixels beyond 1 LSB"
+    assert int((dist(f64, want) > 1).sum()) == 0
