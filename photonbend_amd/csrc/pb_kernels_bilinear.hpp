@@ -418,8 +418,11 @@ __device__ __forceinline__ PbBilTap pb_bil_table_tap(int qy, int qx, int h, int 
         if (dead) qx = 0;
         t.ty = (float)(qy & ((1 << PB_BIL_SHIFT) - 1)) * (1.0f / (float)(1 << PB_BIL_SHIFT));
         t.tx = (float)(qx & ((1 << PB_BIL_SHIFT) - 1)) * (1.0f / (float)(1 << PB_BIL_SHIFT));
-        t.o0 = __umul24((unsigned)(qy >> PB_BIL_SHIFT), 3u * (unsigned)w) + __umul24((unsigned)(qx >> PB_BIL_SHIFT), 3u);
-        t.o1 = t.o0 + 3u * (unsigned)w;
+        // (rows clamp to the image like the definition's - the rim of a fisheye output samples a panorama's last row -, columns do not)
+        const int r0 = qy >> PB_BIL_SHIFT;
+        const unsigned cb = __umul24((unsigned)(qx >> PB_BIL_SHIFT), 3u);
+        t.o0 = __umul24((unsigned)max(r0, 0), 3u * (unsigned)w) + cb;
+        t.o1 = __umul24((unsigned)min(r0 + 1, h - 1), 3u * (unsigned)w) + cb;
         if (PB_BIL_ABL & 1024) t.o0 = t.o1 = 3u * (unsigned)((qx >> PB_BIL_SHIFT) & 15);
         t.kind = dead ? -1 : 0;
         t.c1off = 3u;
@@ -743,7 +746,8 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
     const unsigned frame_bytes = 3u * (unsigned)w * (unsigned)h;
     if ((PB_BIL_ABL & 32) && e->bil_off >= 0) return;                                                 // skip table tiles
     if ((PB_BIL_ABL & 64) && e->bil_off < 0 && (flags & PB_TILE_LEAN) && windows) return;            // skip window tiles
-    if ((PB_BIL_ABL & 16) && e->bil_off < 0 && (flags & PB_TILE_DIRECT)) return;                     // skip direct-gather tiles
+    if ((PB_BIL_ABL & 16) && e->bil_off < 0 && (flags & PB_TILE_DIRECT) && !(flags & PB_TILE_HALVES)) return;  // skip direct-gather tiles
+    if ((PB_BIL_ABL & 4096) && e->bil_off < 0 && (flags & PB_TILE_HALVES)) return;                  // skip half-window tiles
     if (!(PB_BIL_PATHS & 4) && e->bil_off >= 0) return;
     if ((PB_BIL_PATHS & 4) && e->bil_off >= 0) {
         PB_MARK("table");
@@ -1347,8 +1351,8 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_coord_kernel(const PbPar
 // discontinuity inside the tile - the rim of the image circle - is not a gradient).  The walk runs along the direction with the smaller
 // change (along y: PB_TILE_TAB_Y) and is sheared by slope = -g_along / g_across so that a half-wave follows the line of constant
 // source row; the slot is rewritten in walk order, the shear goes into bil_off.  Speed only: the pixels do not depend on the walk.
-// It also says whether the slot is PLAIN (PB_TILE_TAB_PLAIN, pb_tile.hpp): every live pixel's taps inside the h x w frame, in columns
-// [cmin, cmax) (an eye's half), an 8-byte load at each tap's two rows inside the buffer.
+// It also says whether the slot is PLAIN (PB_TILE_TAB_PLAIN, pb_tile.hpp): every live pixel's taps in columns [cmin, cmax) of the frame
+// (an eye's half) without wrap, its rows at most one beyond the image (clamped), an 8-byte load at each tap's two rows inside the buffer.
 // off: 2 = flag no slot plain, 4 = no walk (every slot by columns, no shear) - the diagnostic build's PB_BIL_OFF knob; 0 in the product.
 __global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __restrict__ table, PbBilCoord* __restrict__ bil_xy, int h, int w, int cmin,
                                                                  int cmax, int off_bits) {
@@ -1372,7 +1376,7 @@ __global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __
         if (a.y == PB_BIL_DEAD) continue;
         {
             const int r0 = a.y >> PB_BIL_SHIFT, c0 = a.x >> PB_BIL_SHIFT;
-            if (r0 < 0 || r0 + 1 > h - 1 || c0 < cmin || c0 + 1 > cmax - 1 || 3u * ((unsigned)(r0 + 1) * (unsigned)w + (unsigned)c0) + 8u > frame_bytes) plain = 0;
+            if (r0 < -1 || r0 > h - 1 || c0 < cmin || c0 + 1 > cmax - 1 || 3u * ((unsigned)min(r0 + 1, h - 1) * (unsigned)w + (unsigned)c0) + 8u > frame_bytes) plain = 0;
         }
         if (x + 1 < PB_TILE && tile[i + 1].y != PB_BIL_DEAD) {
             const int d = tile[i + 1].y - a.y;

@@ -70,10 +70,10 @@
 #define PB_HALF_DC(h) (((unsigned)(h) >> 8) & 0x3FFu)
 #define PB_HALF_ROWS(h) (((unsigned)(h) >> 18) & 0x7Fu)
 #define PB_HALF_N16(h) ((((unsigned)(h) >> 25) & 0x3Fu) + 1u)
-// TAB_PLAIN (bilinear mode, tiles served from the exact coordinate table, round 5): every live pixel's four taps lie strictly inside the
-// frame (and inside the eye's half), none at the panorama's seam, and an 8-byte load at either row of any tap stays inside the buffer
-// (pb_bilinear_orient_kernel checks the slot's own coordinates): the table path then runs without clamps, wrap, repeated-tap cases or
-// end-of-frame handling - a third of its instructions (c3: its 1 506 table tiles took 3 100 vector instructions each, 38 % of the
+// TAB_PLAIN (bilinear mode, tiles served from the exact coordinate table, round 5): every live pixel's taps lie inside the frame's
+// columns (and the eye's half), none at the panorama's seam, its rows at most one beyond the image, and an 8-byte load at either row of
+// any tap stays inside the buffer (pb_bilinear_orient_kernel checks the slot's own coordinates): the table path then runs without
+// column clamps, wrap, repeated-tap cases or end-of-frame handling (rows clamp with two instructions) - a third of its instructions (c3: its 1 506 table tiles took 3 100 vector instructions each, 38 % of the
 // launch's, against 620 for a window tile).  Same taps, same weights, same arithmetic: the pixels do not depend on the flag.
 #define PB_TILE_TAB_PLAIN 131072
 #define PB_TILE_W_UNIT_BIT 64  // == PB_TILE_W_UNIT (pb_kernels_double.hpp): blend factors exactly 1.0 for every pixel of the tile
