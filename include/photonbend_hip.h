@@ -180,9 +180,9 @@ int pb_plan_bilinear_float64_tiles(const pb_plan* plan);
  * those whose taps all lie inside the frame (read without clamps or wrap).  All zero without tile tables. */
 int pb_plan_bilinear_tile_mix(const pb_plan* plan, long long mix[8]);
 /* ... and the shape of its launch (ABI 5): the dynamic LDS of a workgroup (the pool its four waves' windows are packed into: 40 448 bytes -
- * four workgroups per CU - where at most 2 % of the tiles lose their window to it, else four full-budget regions) and how many tiles a
- * wave takes (1; a pipelined launch with 4 was measured and rejected, experiments/README.md round 5); both 0 without tile tables. */
-int pb_plan_bilinear_launch_shape(const pb_plan* plan, int* lds_bytes, int* tiles_per_wave);
+ * four workgroups per CU - where at most 2 % of the tiles lose their window to it, else four full-budget regions) and the workgroups
+ * of one frame (four waves = four tiles each; the grid of an n-frame launch is n times that); both 0 without tile tables. */
+int pb_plan_bilinear_launch_shape(const pb_plan* plan, int* lds_bytes, int* workgroups_per_frame);
 
 /* 1 when `plan` was made for exactly this request (same projections, same rotation bits), 0 when not, negative on bad
  * arguments (ABI 3).  What a cache of serialized plans checks after pb_plan_deserialize: the blob's checksum says it is

@@ -381,10 +381,10 @@ class Plan:
         }
 
     def bilinear_launch_shape(self) -> dict:
-        """The bilinear launch's workgroup LDS (bytes) and tiles per wave (1 in the product) - diagnostic."""
-        lds, tpw = C.c_int(), C.c_int()
-        check(load().pb_plan_bilinear_launch_shape(self._h, C.byref(lds), C.byref(tpw)))
-        return {"lds_bytes": lds.value, "tiles_per_wave": tpw.value}
+        """The bilinear launch's workgroup LDS (bytes) and workgroups per frame - diagnostic."""
+        lds, wgs = C.c_int(), C.c_int()
+        check(load().pb_plan_bilinear_launch_shape(self._h, C.byref(lds), C.byref(wgs)))
+        return {"lds_bytes": lds.value, "workgroups": wgs.value}
 
     def bilinear_tile_mix(self) -> dict:
         """How the opt-in bilinear mode serves the plan's tiles (diagnostic, synchronous)."""

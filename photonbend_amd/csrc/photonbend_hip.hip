@@ -1335,11 +1335,11 @@ int pb_plan_bilinear_tile_mix(const pb_plan* plan, long long mix[8]) {
     PB_HIP(e);
     return PB_OK;
 }
-int pb_plan_bilinear_launch_shape(const pb_plan* plan, int* lds_bytes, int* tiles_per_wave) {
-    if (!plan || !lds_bytes || !tiles_per_wave) return pb_fail(PB_ERR_INVALID, "null argument");
+int pb_plan_bilinear_launch_shape(const pb_plan* plan, int* lds_bytes, int* workgroups_per_frame) {
+    if (!plan || !lds_bytes || !workgroups_per_frame) return pb_fail(PB_ERR_INVALID, "null argument");
     const bool tiles = (plan->fast_ready || plan->dbl_ready) && plan->ltable_bil && plan->launch_groups_bil > 0;
     *lds_bytes = tiles ? (int)plan->bil_pool_bytes : 0;
-    *tiles_per_wave = tiles ? (plan->bil_pipe_wgs ? 4 : 1) : 0;
+    *workgroups_per_frame = tiles ? (int)(plan->bil_pipe_wgs ? plan->bil_pipe_wgs : plan->launch_groups_bil) : 0;
     return PB_OK;
 }
 int pb_plan_window_budget(const pb_plan* plan) {
