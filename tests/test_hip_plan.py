@@ -177,6 +177,38 @@ def test_remap_is_graph_capturable(case):
         assert torch.equal(outs[f], want2[f])
 
 
+@pytest.mark.parametrize("case", GRAPH_CASES, ids=[c.name for c in GRAPH_CASES])
+def test_bilinear_remap_is_graph_capturable(case):
+    """The opt-in bilinear launch is ONE kernel over the plan's own launch table (windows, half windows, coordinate tables: all built at
+    plan preparation): pb_remap_bilinear_u8 neither allocates nor synchronises, captures into a HIP graph - a burst of single frames and
+    a batch of two - and replays with the same bytes on new pixels."""
+    plan = H.pb_plan_private(case)
+    sh, sw = case.src[1], case.src[2]
+    dh, dw = case.dst[1], case.dst[2]
+    frames = torch.stack([nat.synth_frame(sh, sw, frame=f) for f in range(4)])
+    outs = torch.zeros((4, dh, dw, 3), dtype=torch.uint8, device="cuda")
+    want = plan.remap(frames, interpolation="bilinear").clone()
+    lib = nat.load()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for f in range(2):
+                nat.check(lib.pb_remap_bilinear_u8(plan.handle, frames[f].data_ptr(), outs[f].data_ptr(), 1, 0, 0, int(side.cuda_stream)))
+            nat.check(lib.pb_remap_bilinear_u8(plan.handle, frames[2].data_ptr(), outs[2].data_ptr(), 2, 0, 0, int(side.cuda_stream)))
+    torch.cuda.current_stream().wait_stream(side)
+    outs.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs, want)
+    frames.copy_(torch.stack([nat.synth_frame(sh, sw, frame=10 + f) for f in range(4)]))
+    want2 = plan.remap(frames, interpolation="bilinear").clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs, want2)
+
+
 def test_remap_batch_sharded_single_process():
     """parallel.remap_batch_sharded without a process group = one shard holding every frame, launched in chunks."""
     import photonbend_amd as pb
