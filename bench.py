@@ -335,7 +335,7 @@ def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0
                "frac_note": "frac_must_move = the bytes that MUST cross HBM (every 128-byte source line holding a sample, once, + the output: the nearest mode's) / kernel time / 8 TB/s - the roofline figure; "
                             "frac_4tap prices four taps per sample (3 B written per output pixel + 4 x 3 B read per in-bounds sample): arithmetic riding on that traffic, not a roofline fraction",
                "traffic_bytes_per_frame": traffic_for(name + "_bilinear", info)[0],
-               "bilinear_float64_tiles": info["bilinear_float64_tiles"], "tiles": info["tiles"], "tile_mix": plan.bilinear_tile_mix(),
+               "bilinear_float64_tiles": info["bilinear_float64_tiles"], "tiles": info["tiles"], "tile_mix": plan.bilinear_tile_mix(), "launch_shape": plan.bilinear_launch_shape(),
                "nearest_over_bilinear_note": "one launch per call: tile models where certified to 1/1024 px, the plan's exact coordinate table elsewhere; no float64 per frame"}
         del srcs, dsts, plan
         torch.cuda.empty_cache()
