@@ -14,7 +14,7 @@ from oracle import reference_path as orc
 from oracle.synth import synth_frame
 from photonbend_amd import _native as nat
 from tests import helpers as H
-from tests.cases import Case, cam, case_by_name, full_cases, inscribed, pano
+from tests.cases import Case, cam, case_by_name, dbl, full_cases, inscribed, pano
 
 pytestmark = pytest.mark.gpu
 
@@ -239,3 +239,31 @@ def test_bilinear_tiles_on_noise_frames(case):
     assert int((d > (2 if double else 1)).sum()) == 0, f"{int((d > 1).sum())} of {d.numel()} pixels beyond 1 LSB, max {int(d.max())}"
     assert int((d > 1).sum()) <= max(8, d.numel() // 50000), f"{int((d > 1).sum())} of {d.numel()} pixels beyond 1 LSB"
     assert int((dist(f64, want) > 1).sum()) == 0
+
+
+_TINY = [
+    Case("tiny_pano_2x4", cam(33, 35, "equidistant", 180), pano(2, 4)),
+    Case("tiny_pano_3x6", cam(40, 40, "equidistant", 360, inscribed(40)), pano(3, 6)),
+    Case("tiny_cam_3x3", pano(5, 9), cam(3, 3, "equisolid", 180, inscribed(3))),
+    Case("tiny_cam_2x2", pano(64, 128), cam(2, 2, "equidistant", 180, inscribed(2))),
+    Case("tiny_double_2x4", pano(40, 80), dbl(2, 4, "equidistant", 190)),
+    Case("tiny_dst_1x1", cam(1, 1, "equidistant", 180, 0.5), pano(8, 16)),
+    Case("tiny_dst_1x2", pano(1, 2), pano(8, 16), [(10, 20, 30)]),
+    Case("tiny_pano_1x2", pano(70, 140), pano(1, 2)),
+    Case("tiny_pano_2x3", cam(64, 64, "rectilinear", 100, inscribed(64)), pano(2, 3)),
+]
+
+
+@pytest.mark.parametrize("case", _TINY, ids=lambda c: c.name)
+def test_bilinear_on_sources_and_destinations_of_a_few_pixels(case):
+    """Frames of 1-12 pixels: every tap clamps or wraps, 8-byte loads end at the buffer's end, a tile holds more pixels than the source
+    (half windows, unguarded table tiles and the LDS pool must all decline gracefully).  Against oracle.remap_bilinear: 1 LSB."""
+    rng = np.random.default_rng(3)
+    frame = rng.integers(0, 256, size=(case.src[1], case.src[2], 3), dtype=np.uint8)
+    want = orc.remap_bilinear(H.orc_proj(case.dst), H.orc_proj(case.src), frame, H.orc_rots(case))
+    plan = H.pb_plan_private(case)
+    got = plan.remap(torch.from_numpy(frame).cuda(), interpolation="bilinear").cpu().numpy()
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    if case.src[0] == "double":
+        d = np.minimum(d, 256 - d)
+    assert int(d.max()) <= 1, f"max difference {int(d.max())}"
