@@ -370,3 +370,22 @@ def test_scattered_frames_in_one_launch_equal_single_launches(case):
     assert L.pb_remap_u8v(plan.handle, None, None, 0, nat.current_stream()) == 0
     torch.cuda.synchronize()
     del decoys
+
+
+def _tiny_cases():
+    from tests.test_hip_bilinear import _TINY
+
+    return _TINY
+
+
+@pytest.mark.parametrize("case", _tiny_cases(), ids=lambda c: c.name)
+def test_remap_on_sources_and_destinations_of_a_few_pixels(case):
+    """The reference's (nearest) sampler on frames of 1-12 pixels - tiles larger than the source, windows that are the whole frame, a
+    1 x 1 destination: byte-identical to the oracle (which is pinned to the reference on the 59 small cases)."""
+    from oracle import reference_path as orc
+
+    rng = np.random.default_rng(3)
+    frame = rng.integers(0, 256, size=(case.src[1], case.src[2], 3), dtype=np.uint8)
+    want = orc.remap(H.orc_proj(case.dst), H.orc_proj(case.src), frame, H.orc_rots(case))
+    got = H.pb_plan_private(case).remap(torch.from_numpy(frame).cuda()).cpu().numpy()
+    assert np.array_equal(got, want), f"{int((got != want).any(axis=2).sum())} pixels differ"
