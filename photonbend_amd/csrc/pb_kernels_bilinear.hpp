@@ -18,6 +18,12 @@
 // tables: what the models cannot reproduce is looked up, not recomputed).  Round 3 recomputed those tiles per frame in
 // float64 (c3: 1 506 of 16 384 tiles, 61 us of a 115 us frame; c5: 63 us).
 //
+// Round 5: tile models evaluated on their certified low-degree part (PB_TILE_TD3); table tiles walked along the line of
+// constant source row (pb_bilinear_orient_kernel) and read without guards where their taps allow (PB_TILE_TAB_PLAIN); direct-gather
+// tiles staged as two half windows (PB_TILE_HALVES); an LDS pool per workgroup (pb_bilinear_pool_kernel); two-eye slots that carry
+// the left entry (PB_TILE_TWO); one instance of the tile code for both eyes.  None of these moves a bit of the output
+// (tests/test_hip_bilinear_invariance.py).
+//
 //   pb_bilinear_hot_kernel          pano / camera sources: one wave per tile over the plan's launch-order table
 //   pb_bilinear_double_hot_kernel   double-fisheye sources: one-eye (SOLO) tiles through the same tile code, two-eye tiles
 //                                   sample both eyes and blend with the tile's weight class
@@ -42,7 +48,7 @@
 #ifndef PB_BIL_HALVES_MAX  // bytes both half windows of a PB_TILE_HALVES tile may have in sum
 #define PB_BIL_HALVES_MAX 24576
 #endif
-#ifndef PB_BIL_WPE_DBL  // ... and the double-fisheye kernel (134 VGPRs at 3; forced to 4 it spills 20 registers and is no faster: experiments/README.md round 5)
+#ifndef PB_BIL_WPE_DBL  // ... and the double-fisheye kernel (168 VGPRs at 3; forced to 4 it spills 35 registers to scratch)
 #define PB_BIL_WPE_DBL 3
 #endif
 #ifndef PB_BIL_ABL  // timing experiments only (experiments/r4/): bits skip parts of the bilinear tile code (wrong pixels); 0 in the product
