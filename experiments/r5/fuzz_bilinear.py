@@ -1,0 +1,45 @@
+"""One-off fuzz of the round's bilinear changes: N random geometries (tests/test_hip_random.random_case, scaled x1..x6), noise frames.
+Tile kernels against the per-pixel definition kernel (1 LSB single sources, 2 LSB double), the nearest tile kernels against the float64
+kernel of the same plan (equal bytes).  usage: fuzz_bilinear.py [N] [seed0]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from photonbend_amd import _native as nat
+from tests import helpers as H
+from tests.cases import Case
+from tests.test_hip_random import random_case
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 777000
+bad = 0
+mix_tot = {}
+t0 = time.time()
+for k in range(N):
+    rng = np.random.default_rng(seed0 + k)
+    c = random_case(rng, k)
+    f = int(rng.integers(int(os.environ.get("FZ_LO", "1")), int(os.environ.get("FZ_HI", "7"))))
+    up = lambda p: (p[0], p[1] * f, p[2] * f, p[3], p[4], None if p[5] is None else p[5] * f)
+    case = Case(f"fz{k}", up(c.dst), up(c.src), c.rotations, c.mask)
+    try:
+        frame = nat.synth_frame(case.src[1], case.src[2], frame=k % 7)
+        plan = H.pb_plan_private(case)
+        got = plan.remap(frame, interpolation="bilinear").to(torch.int16)
+        near = plan.remap(frame)
+        src, cmap = H.pb_chain(case, frame)
+        want = nat.sample_map_bilinear(src._proj("src"), cmap.device_tensor(), frame, 3, np.uint8).reshape(case.dst[1], case.dst[2], 3).to(torch.int16)
+        d = (got - want).abs(); d = torch.minimum(d, 256 - d).amax(dim=2)
+        lim = 2 if case.src[0] == "double" else 1
+        nb = int((d > lim).sum()); n1 = int((d > 1).sum())
+        mix = plan.bilinear_tile_mix()
+        for key, val in mix.items(): mix_tot[key] = mix_tot.get(key, 0) + val
+        fast = plan.info()["fast_path"]
+        plan.set_mode(nat.MODE_FAITHFUL)
+        nf = plan.remap(frame)
+        neq = bool(torch.equal(near, nf))
+        if nb or not neq or n1 > max(8, d.numel() // 50000):
+            bad += 1
+            print(f"BAD {case.name} x{f} {case.dst} <- {case.src} rots {len(case.rotations)}: beyond {lim}: {nb}, beyond 1: {n1} of {d.numel()}, nearest equal {neq}, fast {fast}", flush=True)
+    except Exception as ex:
+        bad += 1
+        print(f"EXC {case.name} x{f} {case.dst} <- {case.src}: {type(ex).__name__} {str(ex)[:160]}", flush=True)
+    if k % 25 == 24: print(f"... {k + 1} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
+print("done", N, "cases,", bad, "bad; tile mix totals", mix_tot)
