@@ -33,35 +33,8 @@
 #pragma once
 #include "pb_kernels_tile.hpp"
 
-#ifndef PB_BIL_WPE  // waves per SIMD the bilinear tile kernels are compiled for (the register budget: 512 / PB_BIL_WPE VGPRs)
-#define PB_BIL_WPE 3
-#endif
-#ifndef PB_BIL_NO_TAB_PLAIN  // A/B builds only: 1 = every table tile on the guarded path
-#define PB_BIL_NO_TAB_PLAIN 0
-#endif
-#ifndef PB_BIL_LDS_AHEAD  // 1: A/B builds only (the LDS reads of the next four pixels issued before four are blended: measured +5..+12 %, more registers)
-#define PB_BIL_LDS_AHEAD 0
-#endif
-#ifndef PB_BIL_POOL_HALVES_FIRST  // 0: A/B builds only (a half-window tile counts like a window tile when the small pool is tried)
-#define PB_BIL_POOL_HALVES_FIRST 1
-#endif
-#ifndef PB_BIL_HALVES_MAX  // bytes both half windows of a PB_TILE_HALVES tile may have in sum
-#define PB_BIL_HALVES_MAX 24576
-#endif
-#ifndef PB_BIL_WPE_DBL  // ... and the double-fisheye kernel (168 VGPRs at 3; forced to 4 it spills 35 registers to scratch)
-#define PB_BIL_WPE_DBL 3
-#endif
-#ifndef PB_BIL_ABL  // timing experiments only (experiments/r4/): bits skip parts of the bilinear tile code (wrong pixels); 0 in the product
-#define PB_BIL_ABL 0
-#endif
-#ifndef PB_BIL_PATHS  // register-pressure experiments only (experiments/r5/): which tile paths are compiled in - 1 window, 2 direct, 4 table; 7 in the product
-#define PB_BIL_PATHS 7
-#endif
-#ifdef PB_MARKS  // ISA reading aid (experiments/r4/isa_count.py): comment markers around the paths of the tile code; never in the product build
-#define PB_MARK(name) asm volatile("; PBMARK " name ::: "memory")
-#else
-#define PB_MARK(name)
-#endif
+#define PB_BIL_WPE 3           // waves per SIMD the bilinear tile kernels are compiled for (the register budget: 512 / PB_BIL_WPE VGPRs)
+#define PB_BIL_HALVES_MAX 24576  // bytes both half windows of a PB_TILE_HALVES tile may have in sum
 
 // ---- float64 passes: tap arithmetic ------------------------------------------------------------------------------------------
 template <int SRC_KIND>
@@ -333,7 +306,6 @@ __device__ __forceinline__ void pb_bil_lds4_issue(const pb_f2 sv[4], unsigned pi
         T.ty[k] = __builtin_amdgcn_fractf(sv[k].x);
         T.tx[k] = __builtin_amdgcn_fractf(sv[k].y);
         T.l0[k] = pb_umad24((unsigned)(int)sv[k].x, pitch, pb_umad24((unsigned)(int)sv[k].y, 3u, a0w));
-        if (PB_BIL_ABL & 2) T.l0[k] = (T.l0[k] & 3u) + (a0w & ~15u) + 64u;  // every lane reads the same dwords: no bank conflicts
         const unsigned b0 = T.l0[k] & ~3u;  // (the pitch is a multiple of 16: both rows share the byte phase)
         const pb_lds_cptr r0 = (pb_lds_cptr)(uintptr_t)b0, r1 = (pb_lds_cptr)(uintptr_t)(b0 + pitch);
         T.w[k][0] = r0[0];
@@ -356,12 +328,7 @@ __device__ __forceinline__ void pb_bil_lds4_blend(const PbLdsTaps& T, unsigned o
             hi1[i] = __builtin_amdgcn_alignbyte(T.w[k + i][5], T.w[k + i][4], T.l0[k + i]);
         }
         const pb_f2 tx2 = {T.tx[k], T.tx[k + 1]}, ty2 = {T.ty[k], T.ty[k + 1]};
-        if (PB_BIL_ABL & 8) {
-            out[k] = lo0[0] ^ hi0[0] ^ lo1[0] ^ hi1[0] ^ __float_as_uint(T.tx[k] + T.ty[k]);
-            out[k + 1] = lo0[1] ^ hi0[1] ^ lo1[1] ^ hi1[1] ^ __float_as_uint(T.tx[k + 1] + T.ty[k + 1]);
-        } else {
-            pb_bil_mix64x2(lo0, hi0, lo1, hi1, tx2, ty2, &out[k]);
-        }
+        pb_bil_mix64x2(lo0, hi0, lo1, hi1, tx2, ty2, &out[k]);
     }
 }
 __device__ __forceinline__ void pb_bil_lds4(const pb_f2 sv[4], unsigned pitch, unsigned a0w, unsigned out[4]) {
@@ -429,7 +396,6 @@ __device__ __forceinline__ PbBilTap pb_bil_table_tap(int qy, int qx, int h, int 
         const unsigned cb = __umul24((unsigned)(qx >> PB_BIL_SHIFT), 3u);
         t.o0 = __umul24((unsigned)max(r0, 0), 3u * (unsigned)w) + cb;
         t.o1 = __umul24((unsigned)min(r0 + 1, h - 1), 3u * (unsigned)w) + cb;
-        if (PB_BIL_ABL & 1024) t.o0 = t.o1 = 3u * (unsigned)((qx >> PB_BIL_SHIFT) & 15);
         t.kind = dead ? -1 : 0;
         t.c1off = 3u;
         return t;
@@ -448,7 +414,6 @@ __device__ __forceinline__ PbBilTap pb_bil_table_tap(int qy, int qx, int h, int 
     c1 = min(max(c1, cmin), cmax - 1);
     t.o0 = 3u * ((unsigned)r0 * (unsigned)w + (unsigned)c0);
     t.o1 = 3u * ((unsigned)r1 * (unsigned)w + (unsigned)c0);
-    if (PB_BIL_ABL & 1024) t.o0 = t.o1 = 3u * (unsigned)(c0 & 15);  // every tap of a table tile in ONE line: what the scattered lines cost
     t.kind = dead ? -1 : (c1 == c0 + 1 ? 0 : (c1 == c0 ? 1 : 2));
     t.c1off = 3u * (unsigned)(c1 - c0);  // (kind 2: negative, as an unsigned wrap-around - added to o0 / o1)
     return t;
@@ -525,7 +490,6 @@ __device__ __forceinline__ void pb_bil_direct_gather(const uint8_t* __restrict__
             wy[m] = __builtin_amdgcn_fractf(sv.x);
             wx[m] = __builtin_amdgcn_fractf(sv.y);
             unsigned g = gbase + (unsigned)(int)sv.x * rowbytes + __umul24((unsigned)(int)sv.y, 3u);  // (s >= 0.5: truncation is floor)
-            if (PB_BIL_ABL & 2048) g = gbase + 3u * ((unsigned)(int)sv.y & 15u);  // every tap of a direct tile in ONE line pair: what its scattered lines cost
             if (WIDE) {
                 unsigned long long t0, t1;
                 __builtin_memcpy(&t0, s + g, 8);
@@ -554,32 +518,6 @@ __device__ __forceinline__ void pb_bil_direct_gather(const uint8_t* __restrict__
             pb_bil_mix64x2(l0, h0, l1, h1, tx2, ty2, o);
             win[park_p + ((2 * (8 * grp + m) + q0) & 31) * park_q] = o[0];
             win[park_p + ((2 * (8 * grp + m + 1) + q0) & 31) * park_q] = o[1];
-        }
-    }
-}
-
-// The window path's sixteen pixels of a lane, four at a time (ALONG_X: the four rows of one column, else the four columns of one row - the
-// order the model is collapsed in), the LDS reads of group g + 1 issued before group g is blended.
-template <bool TD3, bool ALONG_X>
-__device__ __forceinline__ void pb_bil_window_groups(const PbTileEntry* __restrict__ e, const int xg, const int yb, const unsigned pitch, const unsigned a0w,
-                                                     unsigned v[16]) {
-    const pb_f2 half = {0.5f, 0.5f};
-    PbLdsTaps T[2];
-#pragma unroll
-    for (int g = 0; g <= 4; ++g) {
-        if (g < 4) {
-            pb_f2 c[5], sv[4];
-            pb_bil_collapse<TD3>(e, ALONG_X, ALONG_X ? 4 * xg + g : yb + 8 * g, c);
-            c[0] = c[0] - half;  // s = f - 0.5, folded into the constant term (window path and direct path alike)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) sv[m] = pb_bil_eval<TD3>(c, pb_tile_coord(ALONG_X ? yb + 8 * m : 4 * xg + m));
-            pb_bil_lds4_issue(sv, pitch, a0w, T[g & 1]);
-        }
-        if (g > 0) {
-            unsigned o[4];
-            pb_bil_lds4_blend(T[(g - 1) & 1], o);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) v[ALONG_X ? m * 4 + (g - 1) : (g - 1) * 4 + m] = o[m];
         }
     }
 }
@@ -642,31 +580,21 @@ __device__ __forceinline__ void pb_bil_halves_vals(const PbHot& Hd, const PbTile
 }
 
 // The window and the direct-gather path of a plain tile (LEAN / DIRECT), on the full tile model or on its TD3 part.
-// win_state (experiments/r5/pb_pipe_experiment.hpp only; 0 in the product): a LEAN tile's window loads are 0 still to issue, 1 issued, 2 landed.
 template <bool TD3>
 __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileEntry* __restrict__ e, const int flags, const int lane, unsigned* win,
-                                                  const int windows, const uint8_t* __restrict__ s, unsigned v[16], const int win_state = 0) {
+                                                  const int windows, const uint8_t* __restrict__ s, unsigned v[16]) {
     const int xg = lane & 7, yb = lane >> 3;
     const unsigned rowbytes = 3u * (unsigned)Hd.src_w, frame_bytes = rowbytes * (unsigned)Hd.src_h, safe_len = frame_bytes & ~15u;
     const unsigned gbase = (unsigned)e->anchor_r * rowbytes + 3u * (unsigned)e->anchor_c;
     const bool along_x = fabsf(e->c[1][0]) <= fabsf(e->c[5][0]);  // |d row / du| <= |d row / dv|
-    if (!(PB_BIL_PATHS & 1) && (flags & PB_TILE_LEAN) && windows) return;
-    if ((PB_BIL_PATHS & 1) && (flags & PB_TILE_LEAN) && windows) {
+    if ((flags & PB_TILE_LEAN) && windows) {
         const unsigned pitch = 16u * (unsigned)e->win_n16, a0 = (unsigned)e->win_a0;
-        if (!(PB_BIL_ABL & 4) && win_state == 0) pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
-        if (win_state != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pb_issue_window_loads(s, win, lane, gbase, rowbytes, e->win_rows, e->win_n16, safe_len);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pb_wave_sync();
         const pb_f2 half = {0.5f, 0.5f};
         const unsigned a0w = a0 + (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)win;  // (LDS addresses are 32-bit offsets)
-#if PB_BIL_LDS_AHEAD
-        // Two groups of four pixels in flight: the LDS reads of group g + 1 are issued before group g is blended, so a wave's wait for LDS
-        // (16 reads, ~60 % of them bank-conflicted) overlaps its own arithmetic instead of another wave's (the launches hold 3-4 waves
-        // per SIMD; a wave waited for LDS four times per tile with nothing of its own to issue).
-        if (along_x) pb_bil_window_groups<TD3, true>(e, xg, yb, pitch, a0w, v);
-        else pb_bil_window_groups<TD3, false>(e, xg, yb, pitch, a0w, v);
-#else
         if (along_x) {
-            PB_MARK("window_colfirst");
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 pb_f2 b[5], sv[4];
@@ -680,7 +608,6 @@ __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileE
                 for (int jr = 0; jr < 4; ++jr) v[jr * 4 + k] = o[jr];
             }
         } else {
-            PB_MARK("window_rowfirst");
 #pragma unroll
             for (int jr = 0; jr < 4; ++jr) {
                 pb_f2 a[5], sv[4];
@@ -691,8 +618,6 @@ __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileE
                 pb_bil_lds4(sv, pitch, a0w, &v[jr * 4]);
             }
         }
-#endif
-        PB_MARK("end");
         pb_wave_sync();  // every lane has read its taps: the window may be refilled (the other eye, the next path)
         return;
     }
@@ -700,12 +625,10 @@ __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileE
         pb_bil_halves_vals<TD3>(Hd, e, lane, win, s, v);
         return;
     }
-    if (!(PB_BIL_PATHS & 2)) return;
     // direct gathers.  wide: an 8-byte load takes both taps of a row - allowed when even the box's last tap has 8 bytes of frame
     // behind it.
     const bool wide = gbase + (unsigned)(e->win_rows - 1) * rowbytes + 3u * (unsigned)(e->win_cols - 1) + 8u <= frame_bytes;
     const int p = lane & 31, hh = lane >> 5;
-    PB_MARK("direct");
     const float num = along_x ? e->c[1][0] : e->c[5][0], den = along_x ? e->c[5][0] : e->c[1][0];
     const float slope = (den != 0.0f) ? -num / den : 0.0f;
     const int shift = (int)rintf(slope * ((float)p - 15.5f));
@@ -723,7 +646,6 @@ __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileE
     for (int jr = 0; jr < 4; ++jr)
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[jr * 4 + k] = win[(yb + 8 * jr) * 33 + 4 * xg + k];
-    PB_MARK("end");
     pb_wave_sync();
 }
 
@@ -746,17 +668,11 @@ __device__ __forceinline__ void pb_bil_model_vals(const PbHot& Hd, const PbTileE
 template <bool WRAP>
 __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* __restrict__ e, const int flags, const int lane, unsigned* win,
                                             const int windows, const uint8_t* __restrict__ s, const PbBilCoord* __restrict__ bil_xy, const int cmin,
-                                            const int cmax, unsigned v[16], const int win_state = 0) {
+                                            const int cmax, unsigned v[16]) {
     const int xg = lane & 7, yb = lane >> 3;
     const int h = Hd.src_h, w = Hd.src_w;
     const unsigned frame_bytes = 3u * (unsigned)w * (unsigned)h;
-    if ((PB_BIL_ABL & 32) && e->bil_off >= 0) return;                                                 // skip table tiles
-    if ((PB_BIL_ABL & 64) && e->bil_off < 0 && (flags & PB_TILE_LEAN) && windows) return;            // skip window tiles
-    if ((PB_BIL_ABL & 16) && e->bil_off < 0 && (flags & PB_TILE_DIRECT) && !(flags & PB_TILE_HALVES)) return;  // skip direct-gather tiles
-    if ((PB_BIL_ABL & 4096) && e->bil_off < 0 && (flags & PB_TILE_HALVES)) return;                  // skip half-window tiles
-    if (!(PB_BIL_PATHS & 4) && e->bil_off >= 0) return;
-    if ((PB_BIL_PATHS & 4) && e->bil_off >= 0) {
-        PB_MARK("table");
+    if (e->bil_off >= 0) {
         // Lane = one column (or, PB_TILE_TAB_Y, one row) of the tile, 16 pixels down the other direction, SHEARED along the line of
         // constant source row like the direct-gather path: the 32 lanes of a half-wave take 32 neighbouring pixels along the direction
         // in which the source position moves least.  Direction and shear are decided per slot at plan time by
@@ -792,7 +708,6 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
         for (int jr = 0; jr < 4; ++jr)
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[jr * 4 + k] = win[(yb + 8 * jr) * 33 + 4 * xg + k];
-        PB_MARK("end");
         pb_wave_sync();
         return;
     }
@@ -801,12 +716,8 @@ __device__ __forceinline__ void pb_bil_vals(const PbHot& Hd, const PbTileEntry* 
         for (int n = 0; n < 16; ++n) v[n] = 0u;
         return;
     }
-#ifdef PB_BIL_NO_TD3  // A/B builds only (experiments/r5/): the full tile model everywhere
-    if (false) pb_bil_model_vals<true>(Hd, e, flags, lane, win, windows, s, v);
-#else
-    if (flags & PB_TILE_TD3) pb_bil_model_vals<true>(Hd, e, flags, lane, win, windows, s, v, win_state);
-#endif
-    else pb_bil_model_vals<false>(Hd, e, flags, lane, win, windows, s, v, win_state);
+    if (flags & PB_TILE_TD3) pb_bil_model_vals<true>(Hd, e, flags, lane, win, windows, s, v);
+    else pb_bil_model_vals<false>(Hd, e, flags, lane, win, windows, s, v);
 }
 
 // the lane's four 12-byte stores (4 consecutive pixels x 4 rows); tiles on the image's edge are clipped
@@ -820,7 +731,6 @@ __device__ __forceinline__ void pb_bil_store(const unsigned v[16], uint8_t* __re
         const int y = Y0 + yb + 8 * jr;
         if (!inside && y >= H) continue;
         const unsigned long long off = 3ull * ((unsigned long long)y * W + x);
-        if ((PB_BIL_ABL & 1) && v[jr * 4] != 0x12345678u) continue;  // no stores
         if ((inside || x + 3 < W) && (((uintptr_t)d + off) & 3u) == 0) {
             pb_store3<NT>(pb_pack_px4(v[jr * 4], v[jr * 4 + 1], v[jr * 4 + 2], v[jr * 4 + 3]), d + off);
         } else {
@@ -869,11 +779,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_ho
     unsigned v[16];
     // (the wave's LDS region: its slot says where in the workgroup's pool - pb_bilinear_pool_kernel)
     pb_bil_vals<SRC_KIND == PB_KIND_PANO>(Hd, e, flags, lane, pb_dyn_lds + ((unsigned)e->win_r0 >> 2), windows, src, bil_xy, 0, Hd.src_w, v);
-#ifdef PB_BIL_PLAIN_STORES  // A/B builds only
-    pb_bil_store<false>(v, dst, tx * PB_TILE, ty * PB_TILE, lane, Hd.dst_w, Hd.dst_h);
-#else
     pb_bil_store<SRC_KIND == PB_KIND_CAMERA>(v, dst, tx * PB_TILE, ty * PB_TILE, lane, Hd.dst_w, Hd.dst_h);
-#endif
     const int n_fix = e->fix_cnt;
     if (n_fix > 0 && fix_xy && e->bil_off < 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own stores have completed
@@ -1013,7 +919,7 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_kernel(const PbPa
 // table) blends with the faithful factors the nearest mode stores for its pixels (PbDoubleFix).  The fix pixels of either eye's
 // list are redone from their exact coordinates and stored factors after the wave's stores.
 template <int WMODE>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinear_double_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
+__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_double_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
                                                                                      const PbTileEntry* __restrict__ table_r,
                                                                                      const PbTileEntry* __restrict__ ltable,
                                                                                      const PbSepRow* __restrict__ rows,
@@ -1046,8 +952,6 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinea
     const int W = Hd.dst_w, H = Hd.dst_h, eye_w = P.src_eye_w;
     unsigned* win = pb_dyn_lds + ((unsigned)entry.win_r0 >> 2);  // (the wave's LDS region: its slot says where in the workgroup's pool)
     unsigned a[16];
-    if ((PB_BIL_ABL & 128) && (entry.flags & PB_TILE_SOLO)) return;   // skip one-eye tiles
-    if ((PB_BIL_ABL & 256) && !(entry.flags & PB_TILE_SOLO)) return;  // skip two-eye tiles
     // ONE instance of the tile code serves a one-eye tile (one pass: the slot's entry is the live eye's) and both eyes of a two-eye tile
     // (two passes): three inlined instances - one-eye, left, right - kept 200 SGPR spills alive in this kernel (the 64-SGPR entry went
     // through VGPR lanes at every use; profiles/r05_c5_bilinear_final_sq.txt: 1 460 vector instructions per wave against 1 075 at the
@@ -1113,8 +1017,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinea
                     wl = pb_merge_factor(P, t);
                     wr = pb_merge_factor(P, (t * -1.0) + PB_PI);
                 }
-                if (PB_BIL_ABL & 512) a[jr * 4 + k] ^= al[jr * 4 + k];  // no blend arithmetic
-                else a[jr * 4 + k] = pb_sep_blend(al[jr * 4 + k], a[jr * 4 + k], wl, wr);
+                a[jr * 4 + k] = pb_sep_blend(al[jr * 4 + k], a[jr * 4 + k], wl, wr);
             }
         }
     }
@@ -1281,12 +1184,12 @@ __global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const 
     unsigned demoted = 0;
     for (;;) {
         if (need[0] + need[1] + need[2] + need[3] <= pool_bytes) break;
-        // (half-window tiles first: they go back to the direct path they came from, and do not count against the pool - PB_BIL_POOL_HALVES_FIRST)
+        // (half-window tiles first: they go back to the direct path they came from, and do not count against the pool)
         int big = -1;
         bool big_half = false;
         for (int w = 0; w < 4; ++w) {
             if (!solo_lean[w] || need[w] <= (unsigned)PB_DIRECT_LDS_BYTES + 16u) continue;
-            const bool half = PB_BIL_POOL_HALVES_FIRST && (ltable[4u * g + w].flags & PB_TILE_HALVES) != 0;
+            const bool half = (ltable[4u * g + w].flags & PB_TILE_HALVES) != 0;
             if (big < 0 || (half && !big_half) || (half == big_half && need[w] > need[big])) { big = w; big_half = half; }
         }
         if (big < 0) {
@@ -1400,11 +1303,7 @@ __global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __
     const float along = by_rows ? gy : gx, across = by_rows ? gx : gy;
     float slope = across != 0.f ? -along / across : 0.f;
     slope = fminf(fmaxf(slope, -1.9f), 1.9f);
-#ifdef PB_BIL_NO_SHEAR  // A/B builds only
-    const int q = 0;
-#else
     const int q = (off_bits & 4) ? 0 : (int)rintf(slope * 64.0f);
-#endif
     const int packed = slot | ((q & 0xFF) << 20);
     __syncthreads();
     // walk order: entry [a][p] = the coordinate of pixel (p, (a + shift(p)) & 31) (by_rows: of pixel ((a + shift(p)) & 31, p))
@@ -1416,7 +1315,7 @@ __global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __
     if (threadIdx.x == 0) {
         int f = e->flags & ~(PB_TILE_TAB_Y | PB_TILE_TAB_PLAIN);
         if (by_rows) f |= PB_TILE_TAB_Y;
-        if (plain && !PB_BIL_NO_TAB_PLAIN && !(off_bits & 2)) f |= PB_TILE_TAB_PLAIN;
+        if (plain && !(off_bits & 2)) f |= PB_TILE_TAB_PLAIN;
         e->flags = f;
         e->bil_off = packed;
     }
@@ -1468,7 +1367,3 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_fix_kernel(const 
         o[2] = (uint8_t)((v >> 16) & 0xFF);
     }
 }
-
-#ifdef PB_BIL_PIPE_EXPERIMENT  // A/B builds only: the pipelined launch measured and rejected in round 5 (experiments/README.md)
-#include "../../experiments/r5/pb_pipe_experiment.hpp"
-#endif

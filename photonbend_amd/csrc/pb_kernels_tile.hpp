@@ -253,11 +253,7 @@ __device__ __forceinline__ void pb_issue_window_loads(const uint8_t* __restrict_
 }
 
 // One tile of the windowed hot kernel (the four tile classes); returns when the tile's pixels are stored.
-#ifdef PB_PLAIN_STORES  // A/B builds only (experiments/session_r3_aj.sh): plain stores for every source kind
-#define PB_NT_DEFAULT(kind) false
-#else
 #define PB_NT_DEFAULT(kind) ((kind) == PB_KIND_CAMERA)
-#endif
 template <int SRC_KIND, bool NT = PB_NT_DEFAULT(SRC_KIND)>
 __device__ __forceinline__ void pb_win_tile(const PbParams& P, const PbHot& Hd, const PbTileEntry* __restrict__ e, const int flags, const int tx,
                                             const int ty, const int lane, unsigned* win, const uint8_t* __restrict__ src,
@@ -684,7 +680,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
                                                                          const int32_t* __restrict__ idx_tab,
                                                                          const int32_t* __restrict__ fix_px,
                                                                          const int32_t* __restrict__ fix_idx, const unsigned n_frames,
-                                                                         const unsigned ilv, const typename PbFrameTabOf<VEC>::type vtab) {
+                                                                         const typename PbFrameTabOf<VEC>::type vtab) {
     const PbParams& P = *Pp;
     // every kernel argument the tile prologue needs, in one scalar round trip (the compiler would otherwise fetch
     // the table pointer only after the tile index is known: a second dependent trip per wave)
@@ -701,14 +697,6 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES) void pb_hot_win_kernel(const Pb
 #endif
     unsigned wg = blockIdx.x;
     const unsigned wgs_per_frame = groups_per_frame * (4u / wpw);
-#ifdef PB_ABLATION  // PB_ILV=G: the frames of a batch progress TOGETHER - G workgroups of frame 0, the same G of frame 1, ... (G a multiple of 8 dividing a frame's share)
-    if (ilv && n_frames > 1 && wgs_per_frame % ilv == 0) {
-        const unsigned span = ilv * n_frames, chunk = wg / span, rem = wg - chunk * span, f = rem / ilv;
-        wg = chunk * ilv + (rem - f * ilv);
-        src += (unsigned long long)f * src_stride;
-        dst += (unsigned long long)f * dst_stride;
-    } else
-#endif
     if (VEC) {  // a batch of separately allocated frames: the frame's pointers from the kernel-argument table
         const unsigned f = wg / wgs_per_frame;
         wg -= f * wgs_per_frame;
@@ -871,19 +859,6 @@ __global__ void pb_unit_cost_kernel(const PbTileEntry* __restrict__ table, unsig
     const unsigned ty = t / tiles_x, tx = t - ty * tiles_x;
     atomicAdd(&unit_cost[(ty / (unit_tiles_y ? unit_tiles_y : unit_tiles)) * units_x + tx / unit_tiles], (unsigned)(c * 1024.0f + 0.5f));
 }
-#ifdef PB_ABLATION  // experiments only (experiments/r5/xcd_by_source.sh): the mean SOURCE row each super-tile samples
-__global__ void pb_unit_srcrow_kernel(const PbTileEntry* __restrict__ table, unsigned n_tiles, unsigned tiles_x, unsigned unit_tiles, unsigned units_x,
-                                      unsigned long long* __restrict__ sum, unsigned* __restrict__ cnt) {
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const PbTileEntry& e = table[t];
-    if (!(e.flags & (PB_TILE_LEAN | PB_TILE_DIRECT))) return;  // (plain tiles: anchor + the model's constant term = the tile centre's source row)
-    const float r = (float)e.anchor_r + e.c[0][0];
-    const unsigned ty = t / tiles_x, tx = t - ty * tiles_x, u = (ty / unit_tiles) * units_x + tx / unit_tiles;
-    atomicAdd(&sum[u], (unsigned long long)(r < 0.f ? 0.f : r));
-    atomicAdd(&cnt[u], 1u);
-}
-#endif
 __global__ void pb_save_flags_kernel(const PbTileEntry* __restrict__ table, int32_t* __restrict__ saved, unsigned n_tiles) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_tiles) saved[t] = table[t].flags;

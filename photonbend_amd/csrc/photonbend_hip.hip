@@ -32,9 +32,6 @@
 #include "pb_kernels_double.hpp"
 #include "pb_kernels_bilinear.hpp"
 
-#ifndef PB_BIL_NO_TWO  // A/B builds only: 1 = two-eye slots of the bilinear launch table only name their tile (round 4's flow)
-#define PB_BIL_NO_TWO 0
-#endif
 #define PB_DOUBLE_FRAMES_PER_WAVE 1  // frames a double-source wave loops over (the rest of a batch is a grid dimension)
 #define PB_WAVES_PER_WG 4  // waves per workgroup of the hot kernel (LDS is released per workgroup)
 struct pb_plan {
@@ -89,7 +86,6 @@ struct pb_plan {
     unsigned launch_groups_bil = 0;
     int bil_budget = 0;
     unsigned bil_pool_bytes = 0;  // dynamic LDS of a bilinear launch's workgroup: the slots' regions are packed into it (pb_bilinear_pool_kernel)
-    unsigned bil_pipe_wgs = 0;    // always 0 in the product (> 0: the -DPB_BIL_PIPE_EXPERIMENT build's pipelined launch, workgroups per frame)
     PbParams* P_dev = nullptr;   // device copy of P as the hot launches see it (refreshed with every budget change)
     unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
     int walk = 0;                // launch-order rule: 0 = by policy (pb_build_launch_table), 1 = plain, 2 = rows from the heaviest outwards,
@@ -582,7 +578,6 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
         const size_t lds = pb_window_lds_bytes(P) / PB_TILE_WAVES * wpw + (size_t)pb_knob("PB_LDS_PAD", 0);  // (the pad: occupancy experiments, -DPB_ABLATION only)
         const unsigned wpf = gpf * (4u / wpw);
         const int per_launch = (int)(0x7FFFFFFFu / wpf);  // grid limit: absurdly long batches go in several launches
-        static const unsigned ilv = (unsigned)pb_knob("PB_ILV", 0);  // experiments: frames of a batch interleaved every `ilv` workgroups (0: frame-major)
         for (int f0 = 0; f0 < n_frames; f0 += per_launch) {
             const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;
             const dim3 bgrid(wpf * (unsigned)nf);
@@ -590,7 +585,7 @@ static void pb_launch_fast(const pb_plan* pl, const uint8_t* src, uint8_t* dst, 
             uint8_t* df = dst + (unsigned long long)f0 * ds;
 #define PB_LAUNCH_WIN(KIND)                                                                                                   \
     hipLaunchKernelGGL((pb_hot_win_kernel<KIND>), bgrid, wblock, lds, st, (const PbParams*)pl->P_dev, pb_hot_of_host(P), pl->ltable, sf, df, gpf, ss, ds, pl->idx_tab, \
-                       pl->fix_px, pl->fix_idx, (unsigned)nf, ilv, PbNoFrameTab{0})
+                       pl->fix_px, pl->fix_idx, (unsigned)nf, PbNoFrameTab{0})
             if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_WIN(PB_KIND_PANO);
             else PB_LAUNCH_WIN(PB_KIND_CAMERA);
         }
@@ -779,34 +774,6 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
                     ahead[b] += best;
                 }
             }
-#ifdef PB_ABLATION
-        } else if (pb_knob("PB_XCD_BY_SRC", 0) && !bil && ns % 8u == 0) {
-            // VERDICT r4 item 8, ONE bounded experiment: super-tiles dealt to XCDs by the eighth of the SOURCE rows they sample (each XCD's
-            // L2 then sees one band of the source), the walk's order kept inside an XCD
-            std::vector<unsigned long long> sum(ns, 0ull);
-            std::vector<unsigned> cnt(ns, 0u);
-            unsigned long long* sum_dev = nullptr;
-            unsigned* cnt_dev = nullptr;
-            if (hipMalloc((void**)&sum_dev, ns * 8) == hipSuccess && hipMalloc((void**)&cnt_dev, ns * 4) == hipSuccess) {
-                (void)hipMemset(sum_dev, 0, ns * 8);
-                (void)hipMemset(cnt_dev, 0, ns * 4);
-                hipLaunchKernelGGL(pb_unit_srcrow_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->n_tiles, tiles_x, 2u * U, sgx, sum_dev, cnt_dev);
-                (void)hipMemcpy(sum.data(), sum_dev, ns * 8, hipMemcpyDeviceToHost);
-                (void)hipMemcpy(cnt.data(), cnt_dev, ns * 4, hipMemcpyDeviceToHost);
-            }
-            (void)hipFree(sum_dev);
-            (void)hipFree(cnt_dev);
-            std::vector<unsigned> by_row(ns);
-            for (unsigned S = 0; S < ns; ++S) by_row[S] = S;
-            auto row_of = [&](unsigned S) { return cnt[S] ? (double)sum[S] / cnt[S] : 1e18; };  // (units without plain tiles: last)
-            std::stable_sort(by_row.begin(), by_row.end(), [&](unsigned a, unsigned b) { return row_of(a) < row_of(b); });
-            std::vector<int> xcd_of(ns, 0);
-            for (unsigned k = 0; k < ns; ++k) xcd_of[by_row[k]] = (int)(k / (ns / 8u));
-            for (unsigned p = 0; p < ns; ++p) {
-                const int x = xcd_of[seq[p]];
-                unit_of[(size_t)x * units_per_xcd + filled[x]++] = (int)seq[p];
-            }
-#endif
         } else {
             for (unsigned p = 0; p < ns; ++p) unit_of[(size_t)(p & 7u) * units_per_xcd + filled[p & 7u]++] = (int)seq[p];  // XCD = position in the walk, mod 8
         }
@@ -827,7 +794,7 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, fresh, unit_dev, units_per_xcd, n_slots, (int)U,
-                           pl->dbl_ready ? pl->table_r : nullptr, (int)UY, (bil && pl->dbl_ready && !PB_BIL_NO_TWO && !pb_bil_off(8)) ? 1 : 0);
+                           pl->dbl_ready ? pl->table_r : nullptr, (int)UY, (bil && pl->dbl_ready && !pb_bil_off(8)) ? 1 : 0);
         e = hipDeviceSynchronize();
     }
     pb_tmp_free(unit_dev);
@@ -879,30 +846,8 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
 // The bilinear mode's launch-order table: the tiles classified under PB_BIL_WIN_BUDGET, ordered by the bilinear mode's costs.  Leaves
 // the tile tables' flags under THAT budget: pb_apply_budget (the nearest mode's) must follow.  A failure leaves the plan without the
 // table (the bilinear launches then take the float64 kernels), never with a stale one.  Synchronous.
-#ifndef PB_BIL_WIN_BUDGET
 #define PB_BIL_WIN_BUDGET PB_WINLDS_MAX
-#endif
-#ifndef PB_BIL_POOL_SMALL  // the bilinear workgroups' small LDS pool: four of them per CU (160 KiB of LDS)
-#define PB_BIL_POOL_SMALL 40448u
-#endif
-#ifndef PB_BIL_NO_HALVES  // A/B builds only: 1 = no half-window tiles
-#define PB_BIL_NO_HALVES 0
-#endif
-#ifndef PB_BIL_HALVES_TWO  // A/B builds only: 1 = half windows for the eyes of two-eye tiles too
-#define PB_BIL_HALVES_TWO 0
-#endif
-#ifndef PB_BIL_NO_PIPE  // A/B builds only: 1 = never the pipelined launch
-#define PB_BIL_NO_PIPE 0
-#endif
-#ifndef PB_BIL_PIPE_POOL  // the pipelined workgroups' LDS pool: two of them per CU (160 KiB of LDS)
-#define PB_BIL_PIPE_POOL 80896u
-#endif
-#ifndef PB_BIL_NO_POOL  // A/B builds only: 1 = always the full pool (round 4's occupancy)
-#define PB_BIL_NO_POOL 0
-#endif
-#ifndef PB_BIL_LDS_PAD  // occupancy experiments only (experiments/r5/): extra dynamic LDS per workgroup of the bilinear launches (fewer workgroups per CU, same work)
-#define PB_BIL_LDS_PAD 0
-#endif
+#define PB_BIL_POOL_SMALL 40448u  // the bilinear workgroups' small LDS pool: four of them per CU (160 KiB of LDS)
 //  // measured on MI355X (experiments/r4/budget_bil.sh): c1 28.7 us at 7 KiB, 25.2 at 12; c2 68.9 / 62.0; c5 109.8 / 103.4; c3 58.3 / 58.9
 static int pb_build_bilinear_launch(pb_plan* pl) {
     if (!(pl->fast_ready || pl->dbl_ready)) return PB_OK;
@@ -937,49 +882,15 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     const dim3 grid((ng + 127) / 128), block(128);
     unsigned res[2] = {0u, 0u};
     hipError_t e = hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
-    if (e == hipSuccess && !PB_BIL_NO_HALVES && !pb_bil_off(1))  // direct-gather slots that can be served as two half windows
+    if (e == hipSuccess && !pb_bil_off(1))  // direct-gather slots that can be served as two half windows
     {
         hipLaunchKernelGGL(pb_bilinear_halves_kernel, dim3(ng), dim3(256), 0, 0, pl->ltable_bil, 4u * ng, pl->bil_budget, pl->P.src.height, pl->P.src.width,
-                           pl->dbl_ready ? (PB_BIL_HALVES_TWO ? 1 : 3) : 0, counters);
+                           pl->dbl_ready ? 3 : 0, counters);
         // (the eyes of two-eye tiles keep the direct path: as half windows - four serial window loads per wave - c5 measured 113 us
-        // against 106, experiments/README.md round 5; PB_BIL_HALVES_TWO=1 rebuilds that variant)
-        if (pl->table_r_bil && PB_BIL_HALVES_TWO)
-            hipLaunchKernelGGL(pb_bilinear_halves_kernel, dim3((pl->n_tiles + 3u) / 4u), dim3(256), 0, 0, pl->table_r_bil, pl->n_tiles, pl->bil_budget, pl->P.src.height,
-                               pl->P.src.width, 2, counters);
+        // against 106, experiments/README.md round 5)
     }
     unsigned pool = full;
-    pl->bil_pipe_wgs = 0;
-#ifdef PB_BIL_PIPE_EXPERIMENT  // A/B builds only (experiments/r5/pb_pipe_experiment.hpp: measured, rejected)
-    if (e == hipSuccess && !pl->dbl_ready && !PB_BIL_NO_PIPE && !pb_bil_off(32) && ng % 8u == 0u) {
-        // the pipelined launch (two workgroups per CU, each wave PB_BIL_PIPE tiles with the next window in flight) where its pool holds
-        // the windows (few demotions) and the runtime grants a workgroup that much LDS
-        const unsigned n_wgs = 8u * ((ng / 8u + (unsigned)PB_BIL_PIPE - 1u) / (unsigned)PB_BIL_PIPE);
-        const dim3 pgrid((n_wgs + 127) / 128);
-        hipLaunchKernelGGL(pb_bilinear_pipe_pool_kernel, pgrid, block, 0, 0, pl->ltable_bil, ng, n_wgs, (unsigned)PB_BIL_PIPE_POOL, 1, counters);
-        e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
-        bool ok = e == hipSuccess && res[1] == 0u && res[0] * 50u <= pl->n_tiles;
-        if (ok) {
-            const void* fn = pl->P.src.kind == PB_KIND_PANO ? (const void*)pb_bilinear_pipe_kernel<PB_KIND_PANO> : (const void*)pb_bilinear_pipe_kernel<PB_KIND_CAMERA>;
-            ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_BIL_PIPE_POOL + PB_BIL_LDS_PAD) == hipSuccess;
-            if (!ok) (void)hipGetLastError();
-        }
-        if (ok) {
-            e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(pb_bilinear_pipe_pool_kernel, pgrid, block, 0, 0, pl->ltable_bil, ng, n_wgs, (unsigned)PB_BIL_PIPE_POOL, 0, counters);
-                e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
-            }
-            if (e == hipSuccess && res[1] == 0u) {
-                pb_tmp_free(counters);
-                pl->bil_pool_bytes = PB_BIL_PIPE_POOL;
-                pl->bil_pipe_wgs = n_wgs;
-                return PB_OK;
-            }
-        }
-        if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
-    }
-#endif
-    if (e == hipSuccess && small < full && !PB_BIL_NO_POOL && !pb_bil_off(16)) {
+    if (e == hipSuccess && small < full && !pb_bil_off(16)) {
         hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r_bil : nullptr, ng, tiles_x, small, 1, counters);
         e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
         if (e == hipSuccess && res[1] == 0u && res[0] * 50u <= pl->n_tiles) pool = small;  // (at most 2 % of the tiles lose their window)
@@ -1339,7 +1250,7 @@ int pb_plan_bilinear_launch_shape(const pb_plan* plan, int* lds_bytes, int* work
     if (!plan || !lds_bytes || !workgroups_per_frame) return pb_fail(PB_ERR_INVALID, "null argument");
     const bool tiles = (plan->fast_ready || plan->dbl_ready) && plan->ltable_bil && plan->launch_groups_bil > 0;
     *lds_bytes = tiles ? (int)plan->bil_pool_bytes : 0;
-    *workgroups_per_frame = tiles ? (int)(plan->bil_pipe_wgs ? plan->bil_pipe_wgs : plan->launch_groups_bil) : 0;
+    *workgroups_per_frame = tiles ? (int)plan->launch_groups_bil : 0;
     return PB_OK;
 }
 int pb_plan_window_budget(const pb_plan* plan) {
@@ -1474,7 +1385,7 @@ int pb_remap_u8v(const pb_plan* plan, const uint8_t* const* src_dev, uint8_t* co
         } else {
 #define PB_LAUNCH_WIN_V(KIND)                                                                                                              \
     hipLaunchKernelGGL((pb_hot_win_kernel<KIND, true>), grid, block, pb_window_lds_bytes(P), st, (const PbParams*)plan->P_dev, pb_hot_of_host(P), plan->ltable, \
-                       tab.src[0], tab.dst[0], gpf, 0ull, 0ull, plan->idx_tab, plan->fix_px, plan->fix_idx, (unsigned)nf, 0u, tab)
+                       tab.src[0], tab.dst[0], gpf, 0ull, 0ull, plan->idx_tab, plan->fix_px, plan->fix_idx, (unsigned)nf, tab)
             if (P.src.kind == PB_KIND_PANO) PB_LAUNCH_WIN_V(PB_KIND_PANO);
             else PB_LAUNCH_WIN_V(PB_KIND_CAMERA);
 #undef PB_LAUNCH_WIN_V
@@ -1517,7 +1428,7 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
                 const uint8_t* sf = src_dev + (unsigned long long)f0 * src_frame_stride;
                 uint8_t* df = dst_dev + (unsigned long long)f0 * dst_frame_stride;
 #define PB_LAUNCH_BILINEAR_DOUBLE(WMODE)                                                                                                       \
-    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, (size_t)plan->bil_pool_bytes + PB_BIL_LDS_PAD, st, Pb, plan->table, plan->table_r_bil ? plan->table_r_bil : plan->table_r, plan->ltable_bil, rows, \
+    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, (size_t)plan->bil_pool_bytes, st, Pb, plan->table, plan->table_r_bil ? plan->table_r_bil : plan->table_r, plan->ltable_bil, rows, \
                        plan->lat_tab, sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy,  \
                        plan->fix_px, plan->bil_fix_xy, plan->dbl_tile_fix, plan->dbl_px_fix)
                 if (rows) PB_LAUNCH_BILINEAR_DOUBLE(1);
@@ -1549,23 +1460,11 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         const int windows = plan->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
                             ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
         const int per_launch = (int)(0x7FFFFFFFu / gpf);
-#ifdef PB_BIL_PIPE_EXPERIMENT
-#define PB_LAUNCH_BILINEAR_PIPE(KIND)                                                                                                \
-    if (plan->bil_pipe_wgs)                                                                                                          \
-        hipLaunchKernelGGL((pb_bilinear_pipe_kernel<KIND>), dim3(plan->bil_pipe_wgs * (unsigned)nf), block, (size_t)plan->bil_pool_bytes + PB_BIL_LDS_PAD, st, \
-                           pb_hot_of_host(Pb), plan->ltable_bil, src_dev + (unsigned long long)f0 * src_frame_stride,                \
-                           dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, plan->bil_pipe_wgs, (unsigned long long)src_frame_stride, \
-                           (unsigned long long)dst_frame_stride, windows, plan->bil_xy, plan->fix_px, plan->bil_fix_xy);             \
-    else
-#else
-#define PB_LAUNCH_BILINEAR_PIPE(KIND)
-#endif
 #define PB_LAUNCH_BILINEAR(KIND)                                                                                                     \
     do {                                                                                                                             \
         for (int f0 = 0; f0 < n_frames; f0 += per_launch) {                                                                          \
             const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;                                                  \
-            PB_LAUNCH_BILINEAR_PIPE(KIND)                                                                                            \
-            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, (size_t)plan->bil_pool_bytes + PB_BIL_LDS_PAD, st, pb_hot_of_host(Pb), plan->ltable_bil, \
+            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, (size_t)plan->bil_pool_bytes, st, pb_hot_of_host(Pb), plan->ltable_bil, \
                                src_dev + (unsigned long long)f0 * src_frame_stride, dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, \
                                (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy, plan->fix_px, \
                                plan->bil_fix_xy);                                                                                    \
