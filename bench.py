@@ -124,6 +124,8 @@ def parse_args():
                     help="nearest = the reference's truncating sampler (the headline); bilinear = the opt-in 4-tap mode (pb_remap_bilinear_u8; no reference behaviour)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the (independent) launches are dealt to round-robin")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configs measured in the same process)")
+    ap.add_argument("--explain", action="store_true", help="also print the VERBOSE record (every figure with its workload text, timing protocol and notes) to stderr")
+    ap.add_argument("--detail", default=None, help="write the verbose record to this file (default: gpurun_out/bench_detail.json when gpurun_out/ exists)")
     return ap.parse_args()
 
 
@@ -660,6 +662,68 @@ def sharded_workload(lib, nat, parallel, name, per_rank, rank, world, device, co
     return dt, n, digest, mine.start, plan, (d, s, cfg)
 
 
+LINE_LIMIT = 6144  # the driver keeps the parsed core of the line plus a few KB of stdout tail: every figure must fit
+CONFIGS_KEYS = ["kernel_us_per_frame", "frac_of_8TBs_algorithmic_bytes (bilinear rows: 4-tap bytes)", "frac_of_8TBs_must_move_bytes", "plan_create_warm_ms (bilinear rows: null)"]
+
+
+def _us(ms):
+    return None if ms is None else round(ms * 1e3, 2)
+
+
+def compact_line(full):
+    """The ONE line rank 0 prints: every measured figure, numbers only, under LINE_LIMIT bytes.  The verbose record (workload texts, timing
+    protocol, notes, tile mixes, plan info) goes to --detail / --explain; DESIGN.md section 4 says what each key means."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full[k] for k in keep}
+    c = full["config"]
+    out["config"] = {"workload": c["workload"], "name": c["name"], "frames_per_launch": c["frames_per_launch"], "frames_resident_per_gpu": c["frames_resident_per_gpu"],
+                     "streams": c["streams"], "sampling": c["sampling"].split(",")[0].split(" ")[0], "parallelism": f"dp{full['n_gpus']}"}
+    r = full["roofline"]
+    out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "copy_ceiling_gbs", "frac_of_copy_ceiling", "algorithmic_bytes_per_launch",
+                                         "must_move_bytes_per_launch", "attainable_frac", "kernel_ms_mean", "kernel_ms_median", "kernel_ms_p10", "kernel_ms_p90", "window_budget")}
+    if "frac_unamortised" in r:
+        out["roofline"]["frac_unamortised"] = {k: r["frac_unamortised"][k] for k in ("single_image", "faithful_kernel", "break_even_frames")}
+    for k in ("plan_create_ms", "plan_create_warm_ms", "first_frame_ms", "single_image_ms", "faithful_kernel_ms"):
+        if k in full:
+            out[k] = full[k]
+    if "configs" in full:  # all ten entries BEFORE the long optional blocks
+        rows = {}
+        for name, e in full["configs"].items():
+            rows[name] = [_us(e["kernel_ms_per_frame"]), e.get("frac", e.get("frac_4tap")), e.get("frac_must_move", round(e["must_move_bytes_per_frame"] / (e["kernel_ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                          e.get("plan_create_warm_ms")]
+        out["configs_keys"] = CONFIGS_KEYS
+        out["configs"] = rows
+    if "flavours" in full:
+        out["flavours"] = full["flavours"]
+    sb = full.get("scattered_batch")
+    if sb:
+        out["scattered_batch"] = sb if "error" in sb else {"frames_per_launch": sb["frames_per_launch"], "u8v_us_per_frame": _us(sb["u8v_ms_per_frame"]),
+                                                           "single_launches_us_per_frame": _us(sb["single_launches_ms_per_frame"])}
+    if "graph_replay_ms_per_frame" in full:
+        out["graph_replay_us_per_frame"] = _us(full["graph_replay_ms_per_frame"])
+    w = full.get("wall_ms_per_frame_by_streams")
+    if w:
+        out["wall_us_per_frame_by_streams"] = {k: _us(v) for k, v in w.items()}
+    hp = full.get("host_path")
+    if hp:
+        out["host_path"] = hp if "error" in hp else {k: v for k, v in hp.items() if not k.endswith("_note") and k not in ("workload", "torch_in_the_path")}
+    sh = full.get("sharded")
+    if sh:
+        out["sharded"] = {k: ({kk: v[kk] for kk in ("frames_total", "frames_per_gpu", "frames_per_launch", "mpx_per_s", "ms_per_frame_per_gpu", "first_frames_identical_to_rank0")}
+                              if isinstance(v, dict) else v) for k, v in sh.items() if k != "collective"}
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"].split(" (")[0] + f", host {os.cpu_count()} cores"}
+        if "map_cached" in cb:
+            out["cpu_baseline"]["map_cached_mpx_per_s"] = cb["map_cached"]["value"]
+        ac = cb.get("all_cores")
+        if ac and "value" in ac:
+            out["cpu_baseline"]["all_cores"] = {"value": ac["value"], "cores": ac["cores"]}
+    out["ranks_seen"] = full.get("ranks_seen")
+    out["collective_backend"] = full.get("collective_backend")
+    return out
+
+
 def copy_ceiling_gbs(lib, nat, device, stream) -> float:
     """A plain 16-byte-per-lane device copy of 512 MiB (beyond the 256 MiB Infinity Cache), read + write bytes per second."""
     import torch
@@ -862,7 +926,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (per-tile coordinate models certified against the float64 chain at plan creation; u8 samples)",
+            "dtype": "f32",  # (per-tile float32 coordinate models, every index certified against the float64 chain at plan creation; u8 samples)
             "data": "synthetic",
             "config": {
                 "workload": cfg["text"],
@@ -1009,7 +1073,19 @@ def main():
             extra = cpu_baseline_all_cores(args.config, mpx_per_frame)
             if extra:
                 line["cpu_baseline"]["all_cores"] = extra
-        print(json.dumps(line), flush=True)
+        detail = args.detail or (os.path.join(ROOT, "gpurun_out", "bench_detail.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
+        if detail:
+            try:
+                with open(detail, "w") as fh:
+                    json.dump(line, fh, indent=1)
+            except OSError as exc:
+                print(f"bench.py: could not write {detail}: {exc}", file=sys.stderr)
+        if args.explain:
+            print(json.dumps(line), file=sys.stderr, flush=True)
+        text = json.dumps(compact_line(line), separators=(",", ":"))
+        if len(text) >= LINE_LIMIT:
+            print(f"bench.py: the line is {len(text)} bytes (limit {LINE_LIMIT})", file=sys.stderr)
+        print(text, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -140,7 +140,8 @@ int pb_plan_timing(const pb_plan* plan, double* prepare_ms, double* tune_ms);
 /* A prepared plan as a host blob and back, so that a process (the CLI's one-image case) need not pay the
  * per-pixel certification again for a geometry it has seen: pass buf = NULL to query the size.  The blob is
  * valid for this library build only (checked) and carries a checksum; deserialisation uploads the tables to
- * the CURRENT device. */
+ * the CURRENT device.  The blob names the math flavour that made its exact tables: the library of the other flavour
+ * refuses it with PB_ERR_UNSUPPORTED (a blob cache shared by hosts with and without AVX-512 keeps one blob per flavour). */
 int pb_plan_serialize(const pb_plan* plan, void* buf, size_t capacity, size_t* size_out);
 int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out);
 /* Execution mode of a plan.  AUTO (default) and FAST: ONE launch of the hot kernel per call (per-tile

@@ -576,6 +576,67 @@ def gen_libm_flavour():
     print("libm_flavour.json written,", len(out), "cases")
 
 
+def gen_libm_flavour_full(names=None):
+    """tests/golden/libm_flavour_full.json: the five BASELINE geometries at FULL size as the REFERENCE computes them on a
+    host without AVX512_SKX - SHA-256 of every float64 map stage, of the index map(s) and of the output bytes on the synthetic frame, the
+    seeded samples, and whether each equals the first flavour's pin (tests/golden/full.json).  Of the five only c3 can differ: arcsin in
+    the equisolid inverse (lens.py:206-220) and arccos in the rotation (rotation.py:158) are the two calls that reach libm there; c1 / c2 /
+    c5 run neither and must reproduce the first flavour's hashes.  A child process under NPY_DISABLE_CPU_FEATURES; the oracle is asserted
+    equal to the reference on every case there too."""
+    import subprocess
+
+    if os.environ.get("PB_NPMATH_LIBM_CHILD") != "1":
+        env = dict(os.environ, NPY_DISABLE_CPU_FEATURES=NO_AVX512, PB_NPMATH_LIBM_CHILD="1")
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--libm-flavour-full", *(names or [])], env=env, check=True)
+        return
+    try:
+        from numpy._core._multiarray_umath import __cpu_features__ as feats
+    except ImportError:
+        from numpy.core._multiarray_umath import __cpu_features__ as feats
+    assert not feats.get("AVX512_SKX") and not feats.get("AVX512F"), "the AVX-512 kernels are still dispatched"
+    first = json.load(open(os.path.join(GOLD, "full.json")))
+    path = os.path.join(GOLD, "libm_flavour_full.json")
+    out = json.load(open(path))["cases"] if (names and os.path.exists(path)) else {}
+    for case in full_cases():
+        if names and case.name not in names:
+            continue
+        dst, cmap, stages, mats = ref_map(case)
+        kind, h, w, *_ = case.src
+        frame = synth_frame(h, w, frame=0, seed=0, circle_mask=case.mask)
+        src = ref_obj(case.src, frame)
+        idx = ref_index(case, cmap)
+        u8 = src.process_coordinate_map(np.copy(cmap))
+        H, W = u8.shape[:2]
+        pos = np.random.default_rng(12345).integers(0, H * W, size=65536)
+        od, os_ = orc_proj(case.dst), orc_proj(case.src)
+        rots = [tuple(map(to_radians, r)) for r in case.rotations]
+        oidx = orc.remap_index(od, os_, rots)
+        f = first[case.name]
+        rec = {"map_sha256": [canonical_map_sha(st) for st in stages], "u8_sha256": sha(u8), "frame_sha256": sha(frame), "sample_seed": 12345,
+               "u8_samples": [int(v) for v in u8.reshape(-1, 3)[pos[:2048]].ravel()]}
+        del stages
+        if kind == "double":
+            assert np.array_equal(oidx[0], idx[0]) and np.array_equal(oidx[1], idx[1]), case.name
+            rec["idx_l_sha256"], rec["idx_r_sha256"] = sha(idx[0]), sha(idx[1])
+            rec["same_as_first_flavour"] = bool(rec["idx_l_sha256"] == f["idx_l_sha256"] and rec["idx_r_sha256"] == f["idx_r_sha256"] and rec["u8_sha256"] == f["u8_sha256"])
+        else:
+            assert np.array_equal(oidx, idx), case.name
+            rec["idx_sha256"] = sha(idx)
+            rec["idx_samples"] = [int(v) for v in idx.ravel()[pos[:2048]]]
+            rec["in_bounds_samples"] = int((idx >= 0).sum())
+            rec["same_as_first_flavour"] = bool(rec["idx_sha256"] == f["idx_sha256"] and rec["u8_sha256"] == f["u8_sha256"])
+        rec["maps_same_as_first_flavour"] = bool(rec["map_sha256"] == f.get("map_sha256"))
+        assert rec["frame_sha256"] == f["frame_sha256"]
+        del oidx
+        assert np.array_equal(orc.remap(od, os_, frame, rots), u8), case.name
+        out[case.name] = rec
+        print(f"  {case.name}: same index map and bytes as the first flavour: {rec['same_as_first_flavour']}, same float64 maps: {rec['maps_same_as_first_flavour']}", flush=True)
+        del cmap, idx, u8, frame
+    meta = {"numpy": np.__version__, "NPY_DISABLE_CPU_FEATURES": NO_AVX512, "cases": len(out)}
+    json.dump({"meta": meta, "cases": out}, open(path, "w"), indent=0)
+    print("libm_flavour_full.json written,", len(out), "cases")
+
+
 def canonical_map_sha(m):
     """SHA-256 of a float64 coordinate map's bits with every NaN replaced by the one canonical quiet NaN (payloads and signs of NaNs are
     not part of any contract; signed zeros and everything else are)."""
@@ -617,13 +678,16 @@ if __name__ == "__main__":
     ap.add_argument("--npmath", action="store_true", help="NumPy's arcsin / arccos / arctan / tan result bits (tests/golden/npmath.npz)")
     ap.add_argument("--npmath-libm", action="store_true", help="the same four functions as NumPy computes them WITHOUT AVX-512 (libm): tests/golden/npmath_libm.npz")
     ap.add_argument("--libm-flavour", action="store_true", help="map / index / byte hashes of the small and mid cases under the no-AVX-512 dispatch: tests/golden/libm_flavour.json")
+    ap.add_argument("--libm-flavour-full", nargs="*", default=None, metavar="CASE", help="the same for the BASELINE geometries at full size (all five, or the named ones): tests/golden/libm_flavour_full.json")
     ap.add_argument("--maps", action="store_true", help="only add the float64 map hashes of the mid and full cases to mid.json / full.json")
     a = ap.parse_args()
-    if a.npmath_libm or a.libm_flavour:  # (second-flavour fixtures: generated on request only - they re-run this script under another NumPy dispatch)
+    if a.npmath_libm or a.libm_flavour or a.libm_flavour_full is not None:  # (second-flavour fixtures: generated on request only - they re-run this script under another NumPy dispatch)
         if a.npmath_libm:
             gen_npmath_libm()
         if a.libm_flavour:
             gen_libm_flavour()
+        if a.libm_flavour_full is not None:
+            gen_libm_flavour_full(a.libm_flavour_full)
         sys.exit(0)
     everything = not (a.full_bilinear or a.full_raw or a.lens or a.small or a.full or a.mapproj or a.cli or a.real or a.mid or a.generic or a.npmath or a.maps)
     os.makedirs(GOLD, exist_ok=True)

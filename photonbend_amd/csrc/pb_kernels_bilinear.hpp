@@ -34,6 +34,7 @@
 #include "pb_kernels_tile.hpp"
 
 #define PB_BIL_WPE 3           // waves per SIMD the bilinear tile kernels are compiled for (the register budget: 512 / PB_BIL_WPE VGPRs)
+#define PB_BIL_WPE_DBL 4       // ... and the double-fisheye kernel, whose pair layout leaves every wave a single-source tile's state (128 VGPRs)
 #define PB_BIL_HALVES_MAX 24576  // bytes both half windows of a PB_TILE_HALVES tile may have in sum
 
 // ---- float64 passes: tap arithmetic ------------------------------------------------------------------------------------------
@@ -911,17 +912,26 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_kernel(const PbPa
 }
 
 // ---- double-fisheye source -------------------------------------------------------------------------------------------------
-// One wave per tile, launched like pb_hot_double_kernel over the plan's launch-order table (frames of a batch: a grid dimension).
-// A tile that sees ONE eye with weight exactly 1 (PB_TILE_SOLO: its slot carries the live eye's entry) is that eye's bilinear sample
-// - the single-source tile code with the eye's column range.  A two-eye tile samples the left eye, then the right eye (through the
-// same LDS window), each by its own entry's path (table / black / window / direct), and blends with the tile's weight class like the
-// nearest mode: UNIT the integer sum, ROW the row table, LAT the stored latitudes; a FAILED tile (both eyes from the coordinate
-// table) blends with the faithful factors the nearest mode stores for its pixels (PbDoubleFix).  The fix pixels of either eye's
-// list are redone from their exact coordinates and stored factors after the wave's stores.
+// Launched over the plan's PAIR-layout table (pb_kernels_tile.hpp; frames of a batch: a grid dimension), one wave per slot, every slot
+// with ONE eye's entry in scalar registers and its own region of the workgroup's LDS pool - the register state of a single-source tile:
+//   SOLO slot   a tile that sees one eye with weight exactly 1: that eye's bilinear sample, stored (the single-source tile code with the
+//               eye's column range);
+//   pair slots  a tile that samples both eyes: wave R (PB_TILE_PAIR_R) samples the right eye by its entry's path (table / black /
+//               window / direct), parks its sixteen packed pixels per lane in ITS region (dead by then) with the numbers wave L needs
+//               of its entry, and meets the workgroup's barrier; wave L (PB_TILE_TWO) samples the left eye, meets the barrier, reads
+//               R's pixels and blends with the tile's weight class like the nearest mode - UNIT the integer sum, ROW the row table, LAT
+//               the stored latitudes; a FAILED tile (both eyes from the coordinate table) with the faithful factors the nearest mode
+//               stores for its pixels (PbDoubleFix) - stores, and redoes the fix pixels of either eye's list from their exact coordinates
+//               and stored factors.
+// Pair workgroups hold nothing but pair slots (and pads that only meet the barrier): every wave of one reaches the barrier exactly once.
+// Round 5's one wave per two-eye tile sampled the eyes one after the other and held both results: 168 VGPRs, 3 waves per SIMD.
+struct PbDblBlend {  // what the blend needs of the parameter block (projection.py:414-418)
+    double mrg_min, mrg_max_safe, mrg_max, mrg_range;
+    int32_t eye_w, pad;
+};
+#define PB_PAIR_HDR 1024  // dword offset of wave R's header in its region, behind its 64 x 16 packed pixels: fix_cnt, fix_off, aux_off
 template <int WMODE>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_double_hot_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l,
-                                                                                     const PbTileEntry* __restrict__ table_r,
-                                                                                     const PbTileEntry* __restrict__ ltable,
+__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinear_double_hot_kernel(const PbHot Hd, const PbDblBlend B, const PbTileEntry* __restrict__ ltable,
                                                                                      const PbSepRow* __restrict__ rows,
                                                                                      const double* __restrict__ lat_tab,
                                                                                      const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
@@ -931,7 +941,6 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_do
                                                                                      const PbBilCoord* __restrict__ fix_xy,
                                                                                      const PbDoubleFix* __restrict__ tile_fix,
                                                                                      const PbDoubleFix* __restrict__ px_fix) {
-    const PbHot Hd = pb_hot_of(P);
     asm volatile("" ::"s"(ltable), "s"(Hd.dst_w), "s"(Hd.dst_h), "s"(Hd.src_w), "s"(Hd.src_h), "s"(Hd.win_budget), "s"(groups_per_frame));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -945,79 +954,93 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_do
     const unsigned vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)(wg * (unsigned)PB_TILE_WAVES + (unsigned)wave));
     PbTileEntry entry;
     pb_load_entry(ltable + vslot, entry);
-    if (entry.flags & PB_TILE_SKIP) return;
+    const int flags = entry.flags;
+    const bool pair = (flags & (PB_TILE_TWO | PB_TILE_PAIR_R)) != 0, right = (flags & (PB_TILE_PAIR_R | PB_TILE_EYE_R)) != 0;
+    // (a slot that leaves early - a pad, a tile on the plan's float64 list, which pb_bilinear_double_fix_kernel repaints - still owes its
+    // pair workgroup the barrier, and a wave R its header: wave L walks the fix lists it names)
+    if ((flags & PB_TILE_SKIP) || (entry.bil_off >= 0 && !bil_xy)) {
+        if (pair) {
+            if (!(flags & PB_TILE_SKIP) && (flags & PB_TILE_PAIR_R) && lane == 0) {
+                unsigned* hdr = pb_dyn_lds + (((unsigned)entry.win_r0 & 0xFFFFu) >> 2) + PB_PAIR_HDR;
+                hdr[0] = (unsigned)entry.fix_cnt;
+                hdr[1] = (unsigned)entry.fix_off;
+                hdr[2] = (unsigned)entry.aux_off;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int tx = entry.tile_xy & 0xFFFF, ty = (int)((unsigned)entry.tile_xy >> 16);
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
     const int xg = lane & 7, yb = lane >> 3;
-    const int W = Hd.dst_w, H = Hd.dst_h, eye_w = P.src_eye_w;
-    unsigned* win = pb_dyn_lds + ((unsigned)entry.win_r0 >> 2);  // (the wave's LDS region: its slot says where in the workgroup's pool)
+    const int W = Hd.dst_w, H = Hd.dst_h, eye_w = B.eye_w;
+    unsigned* win = pb_dyn_lds + (((unsigned)entry.win_r0 & 0xFFFFu) >> 2);  // (the wave's LDS region: its slot says where in the workgroup's pool)
     unsigned a[16];
-    // ONE instance of the tile code serves a one-eye tile (one pass: the slot's entry is the live eye's) and both eyes of a two-eye tile
-    // (two passes): three inlined instances - one-eye, left, right - kept 200 SGPR spills alive in this kernel (the 64-SGPR entry went
-    // through VGPR lanes at every use; profiles/r05_c5_bilinear_final_sq.txt: 1 460 vector instructions per wave against 1 075 at the
-    // start of the round, vector units 81 % busy).
-    const bool solo = (entry.flags & PB_TILE_SOLO) != 0;
-    const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
-    // Two eyes.  The RIGHT eye's entry is on its way into one vector register (lane i = dword i of the 256-byte entry: one coalesced
-    // load, issued before anything else) while the left eye is sampled; the LEFT eye's entry came with the slot (PB_TILE_TWO).  Round 4
-    // fetched both with dependent scalar loads, one before each eye: three serial round trips per two-eye wave before its first
-    // window load, where a one-eye wave makes one (c5's 4 448 two-eye tiles, 13.6 % of its tiles, cost 36 of 106 us).
-    unsigned rlane = 0;
-    if (!solo) {
-        rlane = reinterpret_cast<const unsigned*>(table_r + tile)[lane];
-        if (!(entry.flags & PB_TILE_TWO)) pb_load_entry(table_l + tile, entry);
-    }
-    const int fl0 = entry.flags & ~PB_TILE_TWO, lat_slot = entry.aux_off, nl = entry.fix_cnt, off_l = entry.fix_off;
-    const bool solo_right = solo && (fl0 & PB_TILE_EYE_R) != 0;
-    int fl = fl0, cmin = solo_right ? eye_w : 0, cmax = (solo && !solo_right) || !solo ? eye_w : Hd.src_w;
-    unsigned al[16];
-    for (int pass = 0;; ++pass) {
-        if (entry.bil_off >= 0 && !bil_xy) return;  // (no coordinate table: on the plan's float64 list)
-        pb_bil_vals<false>(Hd, &entry, fl, lane, win, windows, src, bil_xy, cmin, cmax, a);
-        if (solo || pass == 1) break;
-#pragma unroll
-        for (int n = 0; n < 16; ++n) al[n] = a[n];
-        int* w = reinterpret_cast<int*>(&entry);
-#pragma unroll
-        for (int i = 0; i < 64; ++i) w[i] = __builtin_amdgcn_readlane((int)rlane, i);
-        fl = entry.flags;
-        cmin = eye_w;
-        cmax = Hd.src_w;
-    }
-    if (solo) {
+    pb_bil_vals<false>(Hd, &entry, flags & ~(PB_TILE_TWO | PB_TILE_PAIR_R), lane, win, windows, src, bil_xy, right ? eye_w : 0, right ? Hd.src_w : eye_w, a);
+    if (!pair) {
         pb_bil_store<false>(a, dst, X0, Y0, lane, W, H);
         return;
     }
-    const int nr = entry.fix_cnt, off_r = entry.fix_off;
-    if (fl0 & PB_TILE_FAILED) {
+    if (flags & PB_TILE_PAIR_R) {
+        // (every path of pb_bil_vals ends behind a wave-wide LDS hand-off: no lane still reads the region)
+        uint4* x = reinterpret_cast<uint4*>(win);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q * 64 + lane] = make_uint4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+        if (lane == 0) {
+            win[PB_PAIR_HDR] = (unsigned)entry.fix_cnt;
+            win[PB_PAIR_HDR + 1] = (unsigned)entry.fix_off;
+            win[PB_PAIR_HDR + 2] = (unsigned)entry.aux_off;
+        }
+        __syncthreads();
+        return;
+    }
+    __syncthreads();
+    const unsigned* xr = pb_dyn_lds + ((unsigned)entry.win_r0 >> 18);  // wave R's region: the high half of the slot's offset word (pb_bilinear_pool_kernel)
+    unsigned ar[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 t = reinterpret_cast<const uint4*>(xr)[q * 64 + lane];
+        ar[4 * q] = t.x; ar[4 * q + 1] = t.y; ar[4 * q + 2] = t.z; ar[4 * q + 3] = t.w;
+    }
+    const int nr = __builtin_amdgcn_readfirstlane((int)xr[PB_PAIR_HDR]), off_r = __builtin_amdgcn_readfirstlane((int)xr[PB_PAIR_HDR + 1]);
+    const int nl = entry.fix_cnt, off_l = entry.fix_off;
+    if (flags & PB_TILE_FAILED) {
         // the faithful factors of every pixel of a failed tile (slot = the right-eye entry's aux_off, pb_double_tables_kernel)
-        const PbDoubleFix* __restrict__ slot = tile_fix + (size_t)entry.aux_off * (PB_TILE * PB_TILE);
+        const PbDoubleFix* __restrict__ slot = tile_fix + (size_t)__builtin_amdgcn_readfirstlane((int)xr[PB_PAIR_HDR + 2]) * (PB_TILE * PB_TILE);
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const PbDoubleFix* __restrict__ t = slot + (yb + 8 * jr) * PB_TILE + 4 * xg + k;
-                a[jr * 4 + k] = pb_sep_blend(al[jr * 4 + k], a[jr * 4 + k], t->fl, t->fr);
+                a[jr * 4 + k] = pb_sep_blend(a[jr * 4 + k], ar[jr * 4 + k], t->fl, t->fr);
             }
     } else {
-        const bool by_row = WMODE == 1 && (fl0 & PB_TILE_W_ROW) != 0;
-        const bool by_lat = WMODE == 2 && (fl0 & PB_TILE_W_LAT) != 0;
+        const bool by_row = WMODE == 1 && (flags & PB_TILE_W_ROW) != 0;
+        const bool by_lat = WMODE == 2 && (flags & PB_TILE_W_LAT) != 0;
+        if (!by_row && !by_lat) {  // UNIT: l * 1.0 + r * 1.0 is the exact integer l + r; astype(uint8) keeps its low 8 bits
 #pragma unroll
-        for (int jr = 0; jr < 4; ++jr) {
-            double wl = 1.0, wr = 1.0;
-            if (by_row) {
-                const PbSepRow R = rows[min(Y0 + yb + 8 * jr, H - 1)];
-                wl = R.f_l;
-                wr = R.f_r;
+            for (int n = 0; n < 16; ++n) {
+                const unsigned l = a[n], r = ar[n];
+                a[n] = (((l & 0x00FF00FFu) + (r & 0x00FF00FFu)) & 0x00FF00FFu) | (((l & 0x0000FF00u) + (r & 0x0000FF00u)) & 0x0000FF00u);
             }
+        } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (by_lat) {
-                    const double t = lat_tab[(size_t)lat_slot * PB_LAT_TILE_DOUBLES + (yb + 8 * jr) * PB_TILE + 4 * xg + k];
-                    wl = pb_merge_factor(P, t);
-                    wr = pb_merge_factor(P, (t * -1.0) + PB_PI);
+            for (int jr = 0; jr < 4; ++jr) {
+                double wl = 1.0, wr = 1.0;
+                if (by_row) {
+                    const PbSepRow R = rows[min(Y0 + yb + 8 * jr, H - 1)];
+                    wl = R.f_l;
+                    wr = R.f_r;
                 }
-                a[jr * 4 + k] = pb_sep_blend(al[jr * 4 + k], a[jr * 4 + k], wl, wr);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (by_lat) {
+                        const double t = lat_tab[(size_t)entry.aux_off * PB_LAT_TILE_DOUBLES + (yb + 8 * jr) * PB_TILE + 4 * xg + k];
+                        wl = pb_merge_factor_of(B.mrg_min, B.mrg_max_safe, B.mrg_max, B.mrg_range, t);
+                        wr = pb_merge_factor_of(B.mrg_min, B.mrg_max_safe, B.mrg_max, B.mrg_range, (t * -1.0) + PB_PI);
+                    }
+                    a[jr * 4 + k] = pb_sep_blend(a[jr * 4 + k], ar[jr * 4 + k], wl, wr);
+                }
             }
         }
     }
@@ -1074,10 +1097,10 @@ __global__ void pb_bilinear_tile_list_kernel(PbTileEntry* __restrict__ table_l, 
 // Plan creation: which direct-gather slots of the bilinear launch table can be served as two half windows (PB_TILE_HALVES).  One wave per
 // slot: every pixel's tap coordinate with the hot path's own evaluation (same functions, same order, TD3 or not), the bounding box of the
 // taps of the top and of the bottom half, both at most `budget` bytes of LDS and loadable like a window tile's.  counters[2] counts them.
-// what: 0 the launch table of a single-source plan; 3 the launch table of a double-fisheye plan, its one-eye slots only (the product);
-// 1 the same with the left-eye entries its two-eye slots carry and 2 the bilinear mode's copy of the right-eye table, read by the
-// two-eye waves (both measured slower than the direct path on c5: A/B builds only).
-__global__ __launch_bounds__(256) void pb_bilinear_halves_kernel(PbTileEntry* __restrict__ ltable, unsigned n_slots, int budget, int src_h, int src_w, int what,
+// solo_only: a double-fisheye plan's one-eye slots only (the diagnostic build's PB_BIL_OFF bit 8: no half windows for pair slots).  Round
+// 5's single wave per two-eye tile staged FOUR windows one after the other with half windows (c5 113 us against 106); a pair slot is a
+// one-eye tile like any other.
+__global__ __launch_bounds__(256) void pb_bilinear_halves_kernel(PbTileEntry* __restrict__ ltable, unsigned n_slots, int budget, int src_h, int src_w, int solo_only,
                                                                  unsigned* __restrict__ counters) {
     const unsigned v = blockIdx.x * 4u + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform: the entry is read with scalar loads)
     const int lane = threadIdx.x & 63;
@@ -1088,8 +1111,7 @@ __global__ __launch_bounds__(256) void pb_bilinear_halves_kernel(PbTileEntry* __
     const PbTileEntry* __restrict__ e = &L;
     const int f = e->flags;
     if ((f & PB_TILE_SKIP) || !(f & PB_TILE_DIRECT) || (f & PB_TILE_MASKED) || e->bil_off >= 0) return;
-    if (what == 1 && !(f & (PB_TILE_SOLO | PB_TILE_TWO))) return;
-    if (what == 3 && !(f & PB_TILE_SOLO)) return;
+    if (solo_only && !(f & PB_TILE_SOLO)) return;
     const unsigned rowbytes = 3u * (unsigned)src_w, frame_bytes = rowbytes * (unsigned)src_h, safe_len = frame_bytes & ~15u;
     if (rowbytes & 15u) return;
     const int xg = lane & 7, yb = lane >> 3;
@@ -1144,42 +1166,41 @@ __global__ __launch_bounds__(256) void pb_bilinear_halves_kernel(PbTileEntry* __
 // Here every slot of the bilinear launch table gets the byte offset of ITS region in the workgroup's pool (stored in the slot's win_r0,
 // which plain tiles do not use): regions are packed by their real size, so that a smaller pool - four workgroups per CU, measured
 // -4 % (c1) / -5 % (c3) / -11 % (c5) at fixed work - holds the same windows.  One thread per workgroup.  Where four regions exceed the
-// pool the largest window of a one-source slot is demoted to the direct-gather path (same pixels) until they fit; counters[0] counts the
-// demoted tiles, counters[1] the workgroups that cannot be made to fit (two-eye tiles keep their windows).  dry: count only.
+// pool the largest window is demoted to the direct-gather path (same pixels) until they fit; counters[0] counts the demoted tiles,
+// counters[1] the workgroups that cannot be made to fit.  dry: count only.
+// Pair slots of a double-fisheye plan (round 6) are slots like any other - one eye's entry, one region; a wave R's region also carries
+// its hand-over to wave L (64 x 16 packed pixels + header: PB_PAIR_LDS_BYTES), and wave L's slot learns where it is (the high half of
+// its win_r0: a pool is smaller than 64 KiB).
+#define PB_PAIR_LDS_BYTES (4u * (PB_PAIR_HDR + 4u))
 __device__ __forceinline__ unsigned pb_bil_region_bytes(const PbTileEntry& e, int flags) {
-    if (flags & (PB_TILE_SKIP | PB_TILE_BLACK)) return e.bil_off >= 0 && !(flags & PB_TILE_SKIP) ? (unsigned)PB_DIRECT_LDS_BYTES + 16u : 0u;
-    if (e.bil_off < 0 && (flags & PB_TILE_HALVES)) {  // two half windows, one after the other (and the direct path's buffer for frames LDS-DMA cannot address)
+    const unsigned floor_r = (flags & PB_TILE_PAIR_R) ? PB_PAIR_LDS_BYTES : 0u;
+    unsigned need;
+    if (flags & PB_TILE_SKIP) return 0u;
+    if (flags & PB_TILE_BLACK) {
+        need = e.bil_off >= 0 ? (unsigned)PB_DIRECT_LDS_BYTES + 16u : 0u;
+    } else if (e.bil_off < 0 && (flags & PB_TILE_HALVES)) {  // two half windows, one after the other (and the direct path's buffer for frames LDS-DMA cannot address)
         const unsigned hb = (unsigned)e.bil_off & 0x7FFFFFFFu;
         const unsigned a = PB_HALF_ROWS(e.win_c0) * 16u * PB_HALF_N16(e.win_c0), b = PB_HALF_ROWS(hb) * 16u * PB_HALF_N16(hb);
         const unsigned w = a > b ? a : b;
-        return (w > (unsigned)PB_DIRECT_LDS_BYTES ? w : (unsigned)PB_DIRECT_LDS_BYTES) + 16u;
+        need = (w > (unsigned)PB_DIRECT_LDS_BYTES ? w : (unsigned)PB_DIRECT_LDS_BYTES) + 16u;
+    } else if (e.bil_off >= 0 || !(flags & PB_TILE_LEAN)) {
+        need = (unsigned)PB_DIRECT_LDS_BYTES + 16u;
+    } else {
+        const unsigned w = (unsigned)(e.win_rows * 16 * e.win_n16);  // (frames LDS-DMA cannot address send a window tile down the direct path: its buffer too)
+        need = (w > (unsigned)PB_DIRECT_LDS_BYTES ? w : (unsigned)PB_DIRECT_LDS_BYTES) + 16u;
     }
-    if (e.bil_off >= 0 || !(flags & PB_TILE_LEAN)) return (unsigned)PB_DIRECT_LDS_BYTES + 16u;
-    const unsigned w = (unsigned)(e.win_rows * 16 * e.win_n16);  // (frames LDS-DMA cannot address send a window tile down the direct path: its buffer too)
-    return (w > (unsigned)PB_DIRECT_LDS_BYTES ? w : (unsigned)PB_DIRECT_LDS_BYTES) + 16u;
+    return need > floor_r ? need : floor_r;
 }
-__global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const PbTileEntry* __restrict__ table_l, const PbTileEntry* __restrict__ table_r,
-                                        unsigned n_groups, unsigned tiles_x, unsigned pool_bytes, int dry, unsigned* __restrict__ counters) {
+__global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, unsigned n_groups, unsigned pool_bytes, int dry, unsigned* __restrict__ counters) {
     const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     unsigned need[4];
-    bool solo_lean[4];
+    bool window[4];
     for (int w = 0; w < 4; ++w) {
         const PbTileEntry& e = ltable[4u * g + w];
         const int f = e.flags;
-        solo_lean[w] = false;
-        if (f & PB_TILE_SKIP) { need[w] = 0u; continue; }
-        if (table_r && !(f & PB_TILE_SOLO)) {  // a two-eye tile: both eyes' regions, one after the other in the same place
-            const unsigned t = (unsigned)((unsigned)e.tile_xy >> 16) * tiles_x + (unsigned)(e.tile_xy & 0xFFFF);
-            // (the entries the wave reads: the left eye's from its slot when the slot carries it, the right eye's from the mode's copy)
-            const unsigned a = (f & PB_TILE_TWO) ? pb_bil_region_bytes(e, f & ~PB_TILE_TWO) : pb_bil_region_bytes(table_l[t], table_l[t].flags);
-            const unsigned b = pb_bil_region_bytes(table_r[t], table_r[t].flags);
-            need[w] = a > b ? a : b;
-            if (need[w] < (unsigned)PB_DIRECT_LDS_BYTES + 16u) need[w] = (unsigned)PB_DIRECT_LDS_BYTES + 16u;
-            continue;
-        }
         need[w] = pb_bil_region_bytes(e, f);
-        solo_lean[w] = e.bil_off < 0 && (f & (PB_TILE_LEAN | PB_TILE_HALVES)) != 0;
+        window[w] = !(f & PB_TILE_SKIP) && e.bil_off < 0 && (f & (PB_TILE_LEAN | PB_TILE_HALVES)) != 0;
     }
     unsigned demoted = 0;
     for (;;) {
@@ -1188,7 +1209,7 @@ __global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const 
         int big = -1;
         bool big_half = false;
         for (int w = 0; w < 4; ++w) {
-            if (!solo_lean[w] || need[w] <= (unsigned)PB_DIRECT_LDS_BYTES + 16u) continue;
+            if (!window[w] || need[w] <= (unsigned)PB_DIRECT_LDS_BYTES + 16u) continue;
             const bool half = (ltable[4u * g + w].flags & PB_TILE_HALVES) != 0;
             if (big < 0 || (half && !big_half) || (half == big_half && need[w] > need[big])) { big = w; big_half = half; }
         }
@@ -1197,7 +1218,7 @@ __global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const 
             return;  // (the host falls back to the pool that always fits)
         }
         need[big] = (unsigned)PB_DIRECT_LDS_BYTES + 16u;
-        solo_lean[big] = false;
+        window[big] = false;
         if (!dry) ltable[4u * g + big].flags = (ltable[4u * g + big].flags & ~(PB_TILE_LEAN | PB_TILE_HALVES)) | PB_TILE_DIRECT;
         if (!big_half) ++demoted;
     }
@@ -1206,6 +1227,7 @@ __global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, const 
     unsigned off = 0;
     for (int w = 0; w < 4; ++w) {
         ltable[4u * g + w].win_r0 = (int)off;
+        if (w > 0 && (ltable[4u * g + w].flags & PB_TILE_PAIR_R)) ltable[4u * g + w - 1].win_r0 |= (int)(off << 16);  // wave L's slot: where wave R parks its pixels
         off += need[w];
     }
 }
@@ -1222,24 +1244,13 @@ __device__ __forceinline__ void pb_bil_mix_count(const PbTileEntry& e, int f, un
     else if (f & PB_TILE_BLACK) atomicAdd(&counters[3], 1u);
     if (e.bil_off < 0 && (f & (PB_TILE_LEAN | PB_TILE_DIRECT)) && (f & PB_TILE_TD3)) atomicAdd(&counters[4], 1u);
 }
-// the launch-order table of a plan: a single source (table_r null) has every tile's entry in its slot; a double-fisheye plan's one-eye
-// slots carry the live eye's entry, its two-eye slots the left eye's (PB_TILE_TWO; else the plan's left table) next to the right eye's
-// in the mode's copy of the right table - one count per entry a wave reads
-__global__ void pb_bilinear_mix_kernel(const PbTileEntry* __restrict__ ltable, const PbTileEntry* __restrict__ table_l, const PbTileEntry* __restrict__ table_r,
-                                       unsigned n_slots, unsigned tiles_x, unsigned* __restrict__ counters) {
+// every slot of the launch-order table holds the entry its wave works with (a double-fisheye plan's pair layout: one slot per eye)
+__global__ void pb_bilinear_mix_kernel(const PbTileEntry* __restrict__ ltable, unsigned n_slots, unsigned* __restrict__ counters) {
     const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_slots) return;
     const PbTileEntry& e = ltable[v];
-    const int f = e.flags;
-    if (f & PB_TILE_SKIP) return;
-    if (!table_r || (f & PB_TILE_SOLO)) {
-        pb_bil_mix_count(e, f, counters);
-        return;
-    }
-    const unsigned t = (unsigned)((unsigned)e.tile_xy >> 16) * tiles_x + (unsigned)(e.tile_xy & 0xFFFF);
-    if (f & PB_TILE_TWO) pb_bil_mix_count(e, f & ~PB_TILE_TWO, counters);
-    else pb_bil_mix_count(table_l[t], table_l[t].flags, counters);
-    pb_bil_mix_count(table_r[t], table_r[t].flags, counters);
+    if (e.flags & PB_TILE_SKIP) return;
+    pb_bil_mix_count(e, e.flags & ~(PB_TILE_TWO | PB_TILE_PAIR_R), counters);
 }
 
 // fills the coordinate table: 4 blocks per tile, every tile with a slot (pixels beyond the image repeat the edge: never stored)
@@ -1263,19 +1274,22 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_coord_kernel(const PbPar
 // It also says whether the slot is PLAIN (PB_TILE_TAB_PLAIN, pb_tile.hpp): every live pixel's taps in columns [cmin, cmax) of the frame
 // (an eye's half) without wrap, its rows at most one beyond the image (clamped), an 8-byte load at each tap's two rows inside the buffer.
 // off: 2 = flag no slot plain, 4 = no walk (every slot by columns, no shear) - the diagnostic build's PB_BIL_OFF knob; 0 in the product.
+// saved (may be null): the plan's copy of the certified flags (pb_classify_under_budget re-derives the live flags from it): it takes the
+// walk bits of THIS pass - a deserialized plan's copy comes from the blob, its slots are written here.
+// The gradients are integer sums (1/4096 px per pixel step): the same on every run, whatever order the atomics land in.
 __global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __restrict__ table, PbBilCoord* __restrict__ bil_xy, int h, int w, int cmin,
-                                                                 int cmax, int off_bits) {
+                                                                 int cmax, int off_bits, int32_t* __restrict__ saved) {
     __shared__ PbBilCoord tile[PB_TILE * PB_TILE];
-    __shared__ float acc[4];
+    __shared__ int acc[4];
     PbTileEntry* e = table + blockIdx.x;
     const int off = e->bil_off;
     if (off < 0) return;
     const int slot = off & PB_BIL_SLOT_MASK;
     PbBilCoord* t = bil_xy + (size_t)slot * (PB_TILE * PB_TILE);
-    if (threadIdx.x < 4) acc[threadIdx.x] = 0.0f;
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < PB_TILE * PB_TILE; i += 256) tile[i] = t[i];
     __syncthreads();
-    float sx = 0.f, nx = 0.f, sy = 0.f, ny = 0.f;
+    int sx = 0, nx = 0, sy = 0, ny = 0;  // (|d| < 2^18 over at most 992 pairs: no overflow)
     const int far = 64 << PB_BIL_SHIFT;
     const unsigned frame_bytes = 3u * (unsigned)w * (unsigned)h;
     int plain = (3u * (unsigned)w + 8u <= frame_bytes) ? 1 : 0;  // (a dead pixel loads at offset 0 of both rows)
@@ -1289,16 +1303,16 @@ __global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __
         }
         if (x + 1 < PB_TILE && tile[i + 1].y != PB_BIL_DEAD) {
             const int d = tile[i + 1].y - a.y;
-            if (d > -far && d < far) { sx += (float)d; nx += 1.f; }
+            if (d > -far && d < far) { sx += d; nx += 1; }
         }
         if (y + 1 < PB_TILE && tile[i + PB_TILE].y != PB_BIL_DEAD) {
             const int d = tile[i + PB_TILE].y - a.y;
-            if (d > -far && d < far) { sy += (float)d; ny += 1.f; }
+            if (d > -far && d < far) { sy += d; ny += 1; }
         }
     }
     atomicAdd(&acc[0], sx); atomicAdd(&acc[1], nx); atomicAdd(&acc[2], sy); atomicAdd(&acc[3], ny);
     plain = __syncthreads_and(plain);
-    const float gx = acc[1] > 0.f ? acc[0] / acc[1] : 0.f, gy = acc[3] > 0.f ? acc[2] / acc[3] : 0.f;
+    const float gx = acc[1] > 0 ? (float)acc[0] / (float)acc[1] : 0.f, gy = acc[3] > 0 ? (float)acc[2] / (float)acc[3] : 0.f;
     const bool by_rows = fabsf(gy) < fabsf(gx) && !(off_bits & 4);  // the source row changes less down a column: lanes along y
     const float along = by_rows ? gy : gx, across = by_rows ? gx : gy;
     float slope = across != 0.f ? -along / across : 0.f;
@@ -1318,6 +1332,7 @@ __global__ __launch_bounds__(256) void pb_bilinear_orient_kernel(PbTileEntry* __
         if (plain && !(off_bits & 2)) f |= PB_TILE_TAB_PLAIN;
         e->flags = f;
         e->bil_off = packed;
+        if (saved) saved[blockIdx.x] = (saved[blockIdx.x] & ~(PB_TILE_TAB_Y | PB_TILE_TAB_PLAIN)) | (f & (PB_TILE_TAB_Y | PB_TILE_TAB_PLAIN));
     }
 }
 

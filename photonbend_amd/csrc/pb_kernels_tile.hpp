@@ -780,14 +780,9 @@ __global__ void pb_budget_kernel(PbTileEntry* __restrict__ table, const int32_t*
 // speed only) as that XCD's (B >> 3)-th workgroup; unit_of[xcd * units_per_xcd + k] names the k-th unit (a 4x4 group of
 // workgroups = a 256x256-px super-tile, or -1 = none) the host's ordering gave that XCD; without units (unit_of ==
 // nullptr: grids that do not divide into super-tiles) virtual workgroup B is tile group B.
-__global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
-                                                              PbTileEntry* __restrict__ ltable, const int* __restrict__ unit_of,
-                                                              int units_per_xcd, unsigned n_slots, int unit_side,
-                                                              const PbTileEntry* __restrict__ table_r = nullptr, int unit_side_y = 0,
-                                                              int two_eye_left = 0) {
-    const unsigned v = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (v >= n_slots) return;
-    const unsigned B = v >> 2, wave = v & 3u;
+// -> the 2 x 2 tile group of virtual workgroup B (row-major over the grid of groups), or -1 = none
+__device__ __forceinline__ long long pb_group_of_workgroup(const PbParams& P, unsigned B, const int* __restrict__ unit_of, int units_per_xcd, int unit_side,
+                                                           int unit_side_y) {
     const int gx = (pb_tiles_x(P) + 1) / 2, gy = (pb_tiles_y(P) + 1) / 2;
     long long group = B;
     if (unit_of) {
@@ -797,8 +792,30 @@ __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, 
         const int sgx = gx / (int)U;
         group = S < 0 ? -1 : (long long)((S / sgx) * (int)UY + (int)(inner / U)) * gx + (S % sgx) * (int)U + (int)(inner % U);
     }
+    return (group >= 0 && group < (long long)gx * gy) ? group : -1;
+}
+// Double-fisheye plan (table = the left eye's entries): a tile that sees ONE eye - the other eye's tile BLACK, unit blend weights,
+// nothing on either fix list - is a plain camera-source tile (PB_TILE_SOLO: the single-source tile code with the live eye's entry).
+// fl / fr: the eyes' flags, nl / nr: their fix counts -> 0 both eyes, 1 the left eye alone, 2 the right eye alone
+__device__ __forceinline__ int pb_eye_class(int fl, int fr, int nl, int nr) {
+    const int plain = PB_TILE_LEAN | PB_TILE_DIRECT;
+    const bool solo_ok = (fl & PB_TILE_W_UNIT_BIT) && nl == 0 && nr == 0;
+    const bool solo_l = solo_ok && (fr & PB_TILE_BLACK) && (fl & (plain | PB_TILE_BLACK));
+    const bool solo_r = solo_ok && !solo_l && (fl & PB_TILE_BLACK) && (fr & plain);
+    return solo_l ? 1 : (solo_r ? 2 : 0);
+}
+#define PB_SOLO_KEEP (PB_TILE_LEAN | PB_TILE_DIRECT | PB_TILE_BLACK | PB_TILE_COARSE | PB_TILE_TD3 | PB_TILE_TAB_Y | PB_TILE_TAB_PLAIN)
+__global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, const PbTileEntry* __restrict__ table,
+                                                              PbTileEntry* __restrict__ ltable, const int* __restrict__ unit_of,
+                                                              int units_per_xcd, unsigned n_slots, int unit_side,
+                                                              const PbTileEntry* __restrict__ table_r = nullptr, int unit_side_y = 0) {
+    const unsigned v = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (v >= n_slots) return;
+    const unsigned B = v >> 2, wave = v & 3u;
+    const int gx = (pb_tiles_x(P) + 1) / 2;
+    const long long group = pb_group_of_workgroup(P, B, unit_of, units_per_xcd, unit_side, unit_side_y);
     int tx = -1, ty = -1;
-    if (group >= 0 && group < (long long)gx * gy) {
+    if (group >= 0) {
         const int by = (int)(group / gx), bx = (int)(group - (long long)by * gx);
         tx = 2 * bx + (int)(wave & 1u);
         ty = 2 * by + (int)(wave >> 1);
@@ -811,30 +828,125 @@ __global__ __launch_bounds__(256) void pb_launch_table_kernel(const PbParams P, 
     const int* in = reinterpret_cast<const int*>(table + ((size_t)ty * pb_tiles_x(P) + tx));
     int w = in[lane];
     if (table_r) {
-        // double-fisheye plan (table = the left eye's entries): a tile that sees ONE eye - the other eye's tile BLACK, unit
-        // blend weights, nothing on either fix list - is a plain camera-source tile; its slot carries the live eye's entry
-        // (PB_TILE_SOLO), which the hot kernel takes with scalar loads and runs through the single-source tile code.  Every
-        // other slot only names its tile: the two-eye path reads both entries itself.
+        // double-fisheye plan: a one-eye tile's slot carries the live eye's entry (PB_TILE_SOLO), which the hot kernel takes with
+        // scalar loads and runs through the single-source tile code.  Every other slot only names its tile: the two-eye path reads
+        // both entries itself.
         const int wr = reinterpret_cast<const int*>(table_r + ((size_t)ty * pb_tiles_x(P) + tx))[lane];
         const int FL = offsetof(PbTileEntry, flags) / 4, FC = offsetof(PbTileEntry, fix_cnt) / 4;
-        const int fl = __shfl(w, FL), fr = __shfl(wr, FL), nl = __shfl(w, FC), nr = __shfl(wr, FC);
-        const int plain = PB_TILE_LEAN | PB_TILE_DIRECT;
-        const bool solo_ok = (fl & PB_TILE_W_UNIT_BIT) && nl == 0 && nr == 0;
-        const bool solo_l = solo_ok && (fr & PB_TILE_BLACK) && (fl & (plain | PB_TILE_BLACK));
-        const bool solo_r = solo_ok && !solo_l && (fl & PB_TILE_BLACK) && (fr & plain);
-        if (solo_l || solo_r) {
-            if (solo_r) w = wr;
-            if ((int)lane == FL) w = (w & (plain | PB_TILE_BLACK | PB_TILE_COARSE | PB_TILE_TD3 | PB_TILE_TAB_Y | PB_TILE_TAB_PLAIN)) | PB_TILE_SOLO | (solo_r ? PB_TILE_EYE_R : 0);
-        } else if (two_eye_left) {
-            // (the bilinear mode's table: a two-eye slot carries the LEFT eye's entry - the wave has it with its slot, one dependent
-            // scalar round trip less - marked PB_TILE_TWO; the right eye's the wave prefetches into lanes)
-            if ((int)lane == FL) w |= PB_TILE_TWO;
+        const int cls = pb_eye_class(__shfl(w, FL), __shfl(wr, FL), __shfl(w, FC), __shfl(wr, FC));
+        if (cls) {
+            if (cls == 2) w = wr;
+            if ((int)lane == FL) w = (w & PB_SOLO_KEEP) | PB_TILE_SOLO | (cls == 2 ? PB_TILE_EYE_R : 0);
         } else {
             w = 0;
         }
     }
     if (lane == offsetof(PbTileEntry, tile_xy) / 4) w = (ty << 16) | tx;
     out[lane] = w;
+}
+
+// ---- the PAIR layout: the launch-order table of a double-fisheye plan's bilinear mode (round 6) ---------------------------------
+// A tile that samples BOTH eyes is served by a PAIR of waves of one workgroup - wave L the left eye, wave R the right eye, each with its
+// eye's entry in its own slot, its own LDS region, the register state of a one-eye tile; R hands its sixteen samples per lane to L
+// through LDS, L blends and stores (pb_bilinear_double_hot_kernel).  Round 5's single wave staged the two eyes' windows one after the
+// other and kept both eyes' samples live: 168 VGPRs, three waves per SIMD, 6.6 ns per two-eye tile against 2.0 for a one-eye tile.
+// Workgroups are homogeneous: a PAIR workgroup holds two pairs (slots L R L R; a missing pair = two PB_TILE_SKIP | PB_TILE_TWO pads,
+// which still meet the workgroup's barrier), a SOLO workgroup up to four one-eye tiles - so a pair's barrier never waits for a
+// stranger.  A 2 x 2 tile group with k two-eye tiles becomes ceil(k / 2) pair workgroups followed by one solo workgroup (k < 4),
+// in the XCD's list where the group's single workgroup stood: neighbours in space stay neighbours in time on the same L2.
+//   pb_pair_count_kernel   workgroups per virtual workgroup B of the plain layout (0 - 3)
+//   pb_pair_scan_kernel    wave x: the exclusive scan of those counts over XCD x's list (B = x, x + 8, ...) and its total
+//   pb_pair_table_kernel   one wave per B: writes its workgroups' slots at ((start[B] + j) * 8 + (B & 7)) * 4
+// The table is pre-filled with PB_TILE_SKIP slots (pb_skip_fill_kernel): the XCDs' lists differ in length.
+__device__ __forceinline__ void pb_group_classes(const PbParams& P, const PbTileEntry* __restrict__ table_l, const PbTileEntry* __restrict__ table_r, long long group,
+                                                 int cls[4], int& n_two, int& n_solo) {
+    const int gx = (pb_tiles_x(P) + 1) / 2;
+    n_two = n_solo = 0;
+    const int by = (int)(group / gx), bx = (int)(group - (long long)by * gx);
+    for (int t = 0; t < 4; ++t) {
+        const int tx = 2 * bx + (t & 1), ty = 2 * by + (t >> 1);
+        cls[t] = -1;  // no such tile
+        if (group < 0 || tx >= pb_tiles_x(P) || ty >= pb_tiles_y(P)) continue;
+        const PbTileEntry& l = table_l[(size_t)ty * pb_tiles_x(P) + tx];
+        const PbTileEntry& r = table_r[(size_t)ty * pb_tiles_x(P) + tx];
+        cls[t] = pb_eye_class(l.flags, r.flags, l.fix_cnt, r.fix_cnt);
+        if (cls[t]) ++n_solo; else ++n_two;
+    }
+}
+__global__ void pb_pair_count_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l, const PbTileEntry* __restrict__ table_r,
+                                     const int* __restrict__ unit_of, int units_per_xcd, unsigned n_groups, int unit_side, int unit_side_y,
+                                     unsigned* __restrict__ n_wgs) {
+    const unsigned B = blockIdx.x * blockDim.x + threadIdx.x;
+    if (B >= n_groups) return;
+    int cls[4], n_two, n_solo;
+    pb_group_classes(P, table_l, table_r, pb_group_of_workgroup(P, B, unit_of, units_per_xcd, unit_side, unit_side_y), cls, n_two, n_solo);
+    n_wgs[B] = (unsigned)((n_two + 1) / 2 + (n_solo > 0 ? 1 : 0));
+}
+__global__ __launch_bounds__(512) void pb_pair_scan_kernel(const unsigned* __restrict__ n_wgs, unsigned n_groups, unsigned* __restrict__ start,
+                                                          unsigned* __restrict__ totals) {
+    const unsigned x = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    unsigned running = 0;
+    for (unsigned base = 0; base * 8u < n_groups; base += 64u) {
+        const unsigned B = (base + lane) * 8u + x;
+        const unsigned v = B < n_groups ? n_wgs[B] : 0u;
+        unsigned incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned up = __shfl_up(incl, d);
+            if ((int)lane >= d) incl += up;
+        }
+        if (B < n_groups) start[B] = running + incl - v;
+        running += __shfl(incl, 63);
+    }
+    if (lane == 0) totals[x] = running;
+}
+__global__ void pb_skip_fill_kernel(PbTileEntry* __restrict__ ltable, unsigned n_slots) {
+    const unsigned v = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (v < n_slots) reinterpret_cast<int*>(ltable + v)[lane] = lane == offsetof(PbTileEntry, flags) / 4 ? PB_TILE_SKIP : 0;
+}
+__global__ __launch_bounds__(64) void pb_pair_table_kernel(const PbParams P, const PbTileEntry* __restrict__ table_l, const PbTileEntry* __restrict__ table_r,
+                                                           PbTileEntry* __restrict__ ltable, const int* __restrict__ unit_of, int units_per_xcd, unsigned n_groups,
+                                                           int unit_side, int unit_side_y, const unsigned* __restrict__ start) {
+    const unsigned B = blockIdx.x, lane = threadIdx.x;
+    if (B >= n_groups) return;
+    const long long group = pb_group_of_workgroup(P, B, unit_of, units_per_xcd, unit_side, unit_side_y);
+    int cls[4], n_two, n_solo;
+    pb_group_classes(P, table_l, table_r, group, cls, n_two, n_solo);
+    if (n_two + n_solo == 0) return;
+    const int gx = (pb_tiles_x(P) + 1) / 2;
+    const int by = (int)(group / gx), bx = (int)(group - (long long)by * gx);
+    const int FL = offsetof(PbTileEntry, flags) / 4, TXY = offsetof(PbTileEntry, tile_xy) / 4;
+    const unsigned pair_wgs = (unsigned)((n_two + 1) / 2);
+    int seen_two = 0, seen_solo = 0;
+    for (int t = 0; t < 4; ++t) {
+        if (cls[t] < 0) continue;
+        const int tx = 2 * bx + (t & 1), ty = 2 * by + (t >> 1);
+        const size_t tile = (size_t)ty * pb_tiles_x(P) + tx;
+        const int wl = reinterpret_cast<const int*>(table_l + tile)[lane], wr = reinterpret_cast<const int*>(table_r + tile)[lane];
+        if (cls[t] == 0) {
+            const unsigned wg = start[B] + (unsigned)(seen_two >> 1);
+            int* out = reinterpret_cast<int*>(ltable + ((size_t)(wg * 8u + (B & 7u)) * 4u + 2u * (unsigned)(seen_two & 1)));
+            int l = wl, r = wr;
+            if ((int)lane == FL) { l |= PB_TILE_TWO; r |= PB_TILE_PAIR_R; }
+            if ((int)lane == TXY) l = r = (ty << 16) | tx;
+            out[lane] = l;
+            out[64 + lane] = r;
+            ++seen_two;
+        } else {
+            const unsigned wg = start[B] + pair_wgs;
+            int* out = reinterpret_cast<int*>(ltable + ((size_t)(wg * 8u + (B & 7u)) * 4u + (unsigned)seen_solo));
+            int w = cls[t] == 2 ? wr : wl;
+            if ((int)lane == FL) w = (w & PB_SOLO_KEEP) | PB_TILE_SOLO | (cls[t] == 2 ? PB_TILE_EYE_R : 0);
+            if ((int)lane == TXY) w = (ty << 16) | tx;
+            out[lane] = w;
+            ++seen_solo;
+        }
+    }
+    if (n_two & 1) {  // the last pair workgroup holds one pair: two pads that still meet its barrier
+        const unsigned wg = start[B] + pair_wgs - 1u;
+        int* out = reinterpret_cast<int*>(ltable + ((size_t)(wg * 8u + (B & 7u)) * 4u + 2u));
+        out[lane] = (int)lane == FL ? (PB_TILE_SKIP | PB_TILE_TWO) : 0;
+        out[64 + lane] = (int)lane == FL ? (PB_TILE_SKIP | PB_TILE_TWO) : 0;
+    }
 }
 // bil: the opt-in bilinear mode's launch order - a tile served from the exact coordinate table (bil_off >= 0: four clamped gathers per
 // pixel) is the slowest class there

@@ -330,10 +330,13 @@ struct PbDoubleTap {
     double fl, fr;  // blend factors
 };
 
-__device__ __forceinline__ double pb_merge_factor(const PbParams& P, double lat) {
-    const bool band = (lat >= P.mrg_min) && (lat <= P.mrg_max_safe);  // projection.py:440-443
-    const double f = (lat - P.mrg_max) / P.mrg_range * -1.0;         // projection.py:444
+__device__ __forceinline__ double pb_merge_factor_of(double mrg_min, double mrg_max_safe, double mrg_max, double mrg_range, double lat) {
+    const bool band = (lat >= mrg_min) && (lat <= mrg_max_safe);  // projection.py:440-443
+    const double f = (lat - mrg_max) / mrg_range * -1.0;         // projection.py:444
     return band ? f : 1.0;
+}
+__device__ __forceinline__ double pb_merge_factor(const PbParams& P, double lat) {
+    return pb_merge_factor_of(P.mrg_min, P.mrg_max_safe, P.mrg_max, P.mrg_range, lat);
 }
 
 __device__ __forceinline__ PbDoubleTap pb_src_double_taps(const PbParams& P, const PbCoord& c) {

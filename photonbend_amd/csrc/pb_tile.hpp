@@ -58,7 +58,11 @@
 // full model.
 #define PB_TILE_TD3 8192
 #define PB_TILE_TAB_Y 16384  // bilinear mode, tiles served from the exact coordinate table: the slot is stored transposed and walked by rows (pb_bilinear_orient_kernel)
-#define PB_TILE_TWO 32768  // launch-order table of a double-fisheye plan's bilinear mode only: a two-eye slot that carries the LEFT eye's entry
+// launch-order table of a double-fisheye plan's bilinear mode only (the PAIR layout, pb_kernels_tile.hpp): a two-eye tile takes two
+// slots of one workgroup - TWO: the LEFT eye's entry (its wave blends and stores), PAIR_R: the RIGHT eye's entry (its wave hands its
+// samples over through LDS); PB_TILE_SKIP | PB_TILE_TWO: an empty slot of a pair workgroup (it still meets the workgroup's barrier)
+#define PB_TILE_TWO 32768
+#define PB_TILE_PAIR_R 262144
 // HALVES (bilinear launch table only, round 5): a plain tile whose source box exceeds the window budget but whose TOP and BOTTOM halves
 // (output rows 0-15 / 16-31) each fit: the wave stages the two half windows one after the other in its LDS region and samples 8 pixels
 // per lane from each - the window path's cost per pixel instead of the direct-gather path's (c2: 4 392 of its ~5 000 direct tiles).

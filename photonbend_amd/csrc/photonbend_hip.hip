@@ -82,7 +82,6 @@ struct pb_plan {
     // bilinear mode two 8-byte loads per pixel, the nearest mode one dword - its best budget is larger) and ordered by its own costs;
     // built once per plan (pb_build_bilinear_launch), untouched by pb_plan_set_window_budget
     PbTileEntry* ltable_bil = nullptr;
-    PbTileEntry* table_r_bil = nullptr;  // double-fisheye plans: the right eye's tile table as classified under the bilinear mode's budget (the two-eye waves read it)
     unsigned launch_groups_bil = 0;
     int bil_budget = 0;
     unsigned bil_pool_bytes = 0;  // dynamic LDS of a bilinear launch's workgroup: the slots' regions are packed into it (pb_bilinear_pool_kernel)
@@ -114,7 +113,7 @@ static bool pb_test_alloc_fails() {
 }
 
 // -DPB_ABLATION only: PB_BIL_OFF=<bits> switches SPEED-ONLY features of the opt-in bilinear mode off at plan creation (tests: the pixels
-// must not depend on them) - 1 half windows, 2 unguarded table tiles, 4 the table tiles' walk, 8 left entries in two-eye slots, 16 the small LDS pool
+// must not depend on them) - 1 half windows, 2 unguarded table tiles, 4 the table tiles' walk, 8 half windows in pair slots, 16 the small LDS pool
 static inline bool pb_bil_off(int bit) { return (pb_knob("PB_BIL_OFF", 0) & bit) != 0; }
 
 static thread_local std::string g_err;
@@ -376,10 +375,10 @@ static int pb_build_bilinear_list(pb_plan* pl) {
             // which way each slot is walked (lanes along the direction the source position moves least), slots walked by rows transposed
             // ... and whether its taps need the guards at all (PB_TILE_TAB_PLAIN); an eye's taps stay in its half of the frame
             hipLaunchKernelGGL(pb_bilinear_orient_kernel, dim3(pl->n_tiles), dim3(256), 0, 0, pl->table, pl->bil_xy, P.src.height, P.src.width, 0,
-                               dbl ? P.src_eye_w : P.src.width, pb_knob("PB_BIL_OFF", 0));
+                               dbl ? P.src_eye_w : P.src.width, pb_knob("PB_BIL_OFF", 0), pl->saved_l);
             if (dbl)
                 hipLaunchKernelGGL(pb_bilinear_orient_kernel, dim3(pl->n_tiles), dim3(256), 0, 0, pl->table_r, pl->bil_xy, P.src.height, P.src.width, P.src_eye_w,
-                                   P.src.width, pb_knob("PB_BIL_OFF", 0));
+                                   P.src.width, pb_knob("PB_BIL_OFF", 0), pl->saved_r);
             e = hipDeviceSynchronize();
         }
     }
@@ -781,21 +780,46 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
     // the new table is built aside and replaces the plan's only when it is complete: a failure leaves the plan WITHOUT a
     // launch table (ltable == nullptr, launch_groups == 0 - its launches then take the direct-gather kernels), never with a
     // half-written one or one classified under another budget
-    const unsigned n_slots = 4u * n_groups;
     (void)hipFree(out_table);
     out_table = nullptr;
     out_groups = 0;
     PbTileEntry* fresh = nullptr;
     int* unit_dev = nullptr;
-    hipError_t e = (!bil && pb_test_alloc_fails()) ? hipErrorOutOfMemory : hipMalloc((void**)&fresh, (size_t)n_slots * sizeof(PbTileEntry));  // (the test hook counts the nearest mode's tables)
-    if (e == hipSuccess && units) {
+    hipError_t e = hipSuccess;
+    if (units) {
         e = pb_tmp_alloc((void**)&unit_dev, unit_of.size() * sizeof(int));
         if (e == hipSuccess) e = hipMemcpy(unit_dev, unit_of.data(), unit_of.size() * sizeof(int), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, fresh, unit_dev, units_per_xcd, n_slots, (int)U,
-                           pl->dbl_ready ? pl->table_r : nullptr, (int)UY, (bil && pl->dbl_ready && !pb_bil_off(8)) ? 1 : 0);
-        e = hipDeviceSynchronize();
+    if (bil && pl->dbl_ready) {
+        // the PAIR layout (pb_kernels_tile.hpp): a two-eye tile takes two slots of a pair workgroup, so the XCDs' lists grow by what
+        // their tile groups need - counted, scanned per XCD and written in place of the plain layout's one workgroup per group
+        unsigned* scan = nullptr;  // n_wgs[n_groups], start[n_groups], totals[8]
+        unsigned totals[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (e == hipSuccess) e = pb_tmp_alloc((void**)&scan, (2 * (size_t)n_groups + 8) * sizeof(unsigned));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(pb_pair_count_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, 0, P, pl->table, pl->table_r, unit_dev, units_per_xcd, n_groups, (int)U, (int)UY, scan);
+            hipLaunchKernelGGL(pb_pair_scan_kernel, dim3(1), dim3(512), 0, 0, scan, n_groups, scan + n_groups, scan + 2 * (size_t)n_groups);
+            e = hipMemcpy(totals, scan + 2 * (size_t)n_groups, sizeof(totals), hipMemcpyDeviceToHost);
+        }
+        const unsigned per_xcd = *std::max_element(totals, totals + 8), pair_groups = 8u * per_xcd;
+        if (e == hipSuccess && pair_groups == 0) e = hipErrorInvalidValue;  // (a plan without tiles does not get here)
+        if (e == hipSuccess) e = hipMalloc((void**)&fresh, (size_t)pair_groups * 4u * sizeof(PbTileEntry));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(pb_skip_fill_kernel, dim3(pair_groups), dim3(256), 0, 0, fresh, 4u * pair_groups);
+            hipLaunchKernelGGL(pb_pair_table_kernel, dim3(n_groups), dim3(64), 0, 0, P, pl->table, pl->table_r, fresh, unit_dev, units_per_xcd, n_groups, (int)U, (int)UY,
+                               scan + n_groups);
+            e = hipDeviceSynchronize();
+        }
+        pb_tmp_free(scan);
+        n_groups = pair_groups;
+    } else {
+        const unsigned n_slots = 4u * n_groups;
+        if (e == hipSuccess) e = (!bil && pb_test_alloc_fails()) ? hipErrorOutOfMemory : hipMalloc((void**)&fresh, (size_t)n_slots * sizeof(PbTileEntry));  // (the test hook counts the nearest mode's tables)
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, fresh, unit_dev, units_per_xcd, n_slots, (int)U,
+                               pl->dbl_ready ? pl->table_r : nullptr, (int)UY);
+            e = hipDeviceSynchronize();
+        }
     }
     pb_tmp_free(unit_dev);
     if (e != hipSuccess) {
@@ -858,46 +882,29 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     int rc = pb_classify_under_budget(pl, pl->bil_budget, nullptr);
     if (rc == PB_OK) rc = pb_build_launch_table(pl, true);
     if (rc != PB_OK) return rc;
-    (void)hipFree(pl->table_r_bil);
-    pl->table_r_bil = nullptr;
-    if (pl->dbl_ready) {
-        // a two-eye wave reads its right eye's entry by tile: from a copy of the table AS CLASSIFIED NOW (round 4 read the live table, which
-        // pb_apply_budget re-classifies under the nearest mode's smaller budget: the right eyes of c5's seam tiles took the direct path)
-        const size_t bytes = (size_t)pl->n_tiles * sizeof(PbTileEntry);
-        if (hipMalloc((void**)&pl->table_r_bil, bytes) != hipSuccess || hipMemcpy(pl->table_r_bil, pl->table_r, bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
-            (void)hipFree(pl->table_r_bil);
-            pl->table_r_bil = nullptr;
-            (void)hipFree(pl->ltable_bil);
-            pl->ltable_bil = nullptr;
-            pl->launch_groups_bil = 0;
-            return pb_fail(PB_ERR_HIP, "bilinear launch table: out of device memory");
-        }
-    }
     // the workgroups' LDS pool: four workgroups per CU where the slots' real regions allow it (few demotions), else the round-4 size
     // (four full-budget regions: always fits, three workgroups per CU)
     const unsigned full = 4u * ((unsigned)pl->bil_budget + 32u), small = PB_BIL_POOL_SMALL;
     unsigned* counters = nullptr;
-    PB_HIP(pb_tmp_alloc((void**)&counters, 4 * sizeof(unsigned)));
-    const unsigned ng = pl->launch_groups_bil, tiles_x = (pl->P.dst.width + PB_TILE - 1) / PB_TILE;
+    const unsigned ng = pl->launch_groups_bil;
     const dim3 grid((ng + 127) / 128), block(128);
     unsigned res[2] = {0u, 0u};
-    hipError_t e = hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
+    hipError_t e = pb_tmp_alloc((void**)&counters, 4 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
     if (e == hipSuccess && !pb_bil_off(1))  // direct-gather slots that can be served as two half windows
     {
         hipLaunchKernelGGL(pb_bilinear_halves_kernel, dim3(ng), dim3(256), 0, 0, pl->ltable_bil, 4u * ng, pl->bil_budget, pl->P.src.height, pl->P.src.width,
-                           pl->dbl_ready ? 3 : 0, counters);
-        // (the eyes of two-eye tiles keep the direct path: as half windows - four serial window loads per wave - c5 measured 113 us
-        // against 106, experiments/README.md round 5)
+                           pb_bil_off(8) ? 1 : 0, counters);
     }
     unsigned pool = full;
     if (e == hipSuccess && small < full && !pb_bil_off(16)) {
-        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r_bil : nullptr, ng, tiles_x, small, 1, counters);
+        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, ng, small, 1, counters);
         e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
         if (e == hipSuccess && res[1] == 0u && res[0] * 50u <= pl->n_tiles) pool = small;  // (at most 2 % of the tiles lose their window)
     }
     if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, pl->table, pl->dbl_ready ? pl->table_r_bil : nullptr, ng, tiles_x, pool, 0, counters);
+        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, ng, pool, 0, counters);
         e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
     }
     if (e != hipSuccess) (void)hipDeviceSynchronize();
@@ -1201,7 +1208,6 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->saved_r);
     (void)hipFree(plan->ltable);
     (void)hipFree(plan->ltable_bil);
-    (void)hipFree(plan->table_r_bil);
     (void)hipFree(plan->P_dev);
     (void)hipFree(plan->bil_tiles);
     (void)hipFree(plan->bil_xy);
@@ -1235,8 +1241,7 @@ int pb_plan_bilinear_tile_mix(const pb_plan* plan, long long mix[8]) {
     hipError_t e = hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), 0);
     if (e == hipSuccess) {
         const unsigned n_slots = 4u * plan->launch_groups_bil;
-        hipLaunchKernelGGL(pb_bilinear_mix_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, 0, plan->ltable_bil, plan->table,
-                           plan->dbl_ready ? (plan->table_r_bil ? plan->table_r_bil : plan->table_r) : nullptr, n_slots, (unsigned)((plan->P.dst.width + PB_TILE - 1) / PB_TILE), counters);
+        hipLaunchKernelGGL(pb_bilinear_mix_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, 0, plan->ltable_bil, n_slots, counters);
         unsigned res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
         for (int k = 0; k < 8; ++k) mix[k] = res[k];
@@ -1417,8 +1422,9 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         if (plan->dbl_ready && plan->ltable_bil && plan->launch_groups_bil > 0 && plan->bil_tiles && plan->mode != PB_MODE_FAITHFUL) {
             // the per-eye tile models of the nearest mode's plan + the exact coordinate tables: one wave per tile, ONE launch
             const unsigned gpf = plan->launch_groups_bil;
-            PbParams Pb = P;  // (the kernel takes the block by value: the bilinear mode's window budget travels in it)
-            Pb.win_budget = plan->bil_budget;
+            PbHot Hb = pb_hot_of_host(P);  // (the bilinear mode's window budget travels in it)
+            Hb.win_budget = plan->bil_budget;
+            const PbDblBlend Bl = {P.mrg_min, P.mrg_max_safe, P.mrg_max, P.mrg_range, P.src_eye_w, 0};
             const int windows = plan->mode != PB_MODE_FAST_DIRECT && ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
             const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
             const int per_launch = (int)(0x7FFFFFFFu / gpf);
@@ -1428,7 +1434,7 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
                 const uint8_t* sf = src_dev + (unsigned long long)f0 * src_frame_stride;
                 uint8_t* df = dst_dev + (unsigned long long)f0 * dst_frame_stride;
 #define PB_LAUNCH_BILINEAR_DOUBLE(WMODE)                                                                                                       \
-    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, (size_t)plan->bil_pool_bytes, st, Pb, plan->table, plan->table_r_bil ? plan->table_r_bil : plan->table_r, plan->ltable_bil, rows, \
+    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, (size_t)plan->bil_pool_bytes, st, Hb, Bl, plan->ltable_bil, rows, \
                        plan->lat_tab, sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy,  \
                        plan->fix_px, plan->bil_fix_xy, plan->dbl_tile_fix, plan->dbl_px_fix)
                 if (rows) PB_LAUNCH_BILINEAR_DOUBLE(1);
@@ -1813,7 +1819,7 @@ struct PbBlobHeader {
     uint64_t checksum;  // of everything after the header
 };
 const uint32_t PB_BLOB_MAGIC = 0x4C504250u;  // "PBPL"
-const uint32_t PB_BLOB_VERSION = 4;  // 4: tile flags carry PB_TILE_COARSE
+const uint32_t PB_BLOB_VERSION = 5;  // 4: tile flags carry PB_TILE_COARSE; 5: ... and the walk bits of the bilinear table slots; the header names the math flavour
 
 struct PbSection {
     void** ptr;
@@ -1870,7 +1876,7 @@ int pb_plan_serialize(const pb_plan* plan_c, void* buf, size_t capacity, size_t*
     h.version = PB_BLOB_VERSION;
     h.params_size = (uint32_t)sizeof(PbParams);
     h.entry_size = (uint32_t)sizeof(PbTileEntry);
-    h.fast_ready = pl->fast_ready; h.sep_ready = pl->sep_ready; h.dbl_ready = pl->dbl_ready; h.reserved = pl->walk;
+    h.fast_ready = pl->fast_ready; h.sep_ready = pl->sep_ready; h.dbl_ready = pl->dbl_ready; h.reserved = pl->walk | (PB_MATH_FLAVOUR << 8);
     h.n_tiles = pl->n_tiles; h.n_fail_tiles = pl->n_fail_tiles; h.n_fix_px = pl->n_fix_px; h.n_lean_tiles = pl->n_lean_tiles;
     h.n_black_tiles = pl->n_black_tiles; h.n_direct_tiles = pl->n_direct_tiles; h.n_row_weight_tiles = pl->n_row_weight_tiles;
     h.n_lat_tiles = pl->n_lat_tiles; h.diff_pixels = pl->diff_pixels;
@@ -1901,12 +1907,16 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
         return pb_fail(PB_ERR_INVALID, "serialized plan is not from this library build (magic / version / struct sizes)");
     if (h.checksum != pb_fnv1a(in + sizeof(PbBlobHeader), size - sizeof(PbBlobHeader)))
         return pb_fail(PB_ERR_INVALID, "serialized plan is corrupt (checksum)");
+    // the blob's exact tables, thresholds and certified flags are products of ONE math flavour's asin / acos / atan / tan
+    if (((h.reserved >> 8) & 0xFF) != PB_MATH_FLAVOUR)
+        return pb_fail(PB_ERR_UNSUPPORTED, PB_MATH_FLAVOUR ? "serialized plan was made by libphotonbend_hip.so (the AVX-512 / SVML math flavour); this is libphotonbend_hip_libm.so"
+                                                            : "serialized plan was made by libphotonbend_hip_libm.so (glibc's asin / acos / atan / tan); this is libphotonbend_hip.so");
     pb_plan* pl = new (std::nothrow) pb_plan();
     if (!pl) return pb_fail(PB_ERR_INVALID, "out of host memory");
     memcpy(&pl->P, in + sizeof(PbBlobHeader), sizeof(PbParams));
     pl->fast_ready = h.fast_ready; pl->sep_ready = h.sep_ready; pl->dbl_ready = h.dbl_ready;
     pb_sep_setup(pl);
-    pl->walk = (h.reserved >= 0 && h.reserved <= 3) ? h.reserved : 0;
+    pl->walk = ((h.reserved & 0xFF) <= 3) ? (h.reserved & 0xFF) : 0;
     pl->n_tiles = h.n_tiles; pl->n_fail_tiles = h.n_fail_tiles; pl->n_fix_px = h.n_fix_px; pl->n_lean_tiles = h.n_lean_tiles;
     pl->n_black_tiles = h.n_black_tiles; pl->n_direct_tiles = h.n_direct_tiles; pl->n_row_weight_tiles = h.n_row_weight_tiles;
     pl->n_lat_tiles = h.n_lat_tiles; pl->diff_pixels = h.diff_pixels;

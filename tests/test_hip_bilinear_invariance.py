@@ -1,5 +1,5 @@
 """The SPEED-ONLY features of the opt-in bilinear mode must not move a bit (round 5): half windows (PB_TILE_HALVES), unguarded table
-tiles (PB_TILE_TAB_PLAIN), the table tiles' walk order, left entries in two-eye slots (PB_TILE_TWO) and the small LDS pool decide HOW a
+tiles (PB_TILE_TAB_PLAIN), the table tiles' walk order, half windows in the pair slots of a stitch and the small LDS pool decide HOW a
 tile's taps reach the lanes, never which taps or weights.  The diagnostic build (-DPB_ABLATION, loaded through PB_LIB_PATH; the product
 reads no environment) switches them off at plan creation with PB_BIL_OFF; two child processes - everything on, everything off - remap
 the same noise frames at the benchmark geometries and at mid-size ones, and every output must have the same SHA-256.  The run with the
