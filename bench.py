@@ -124,6 +124,8 @@ def parse_args():
                     help="nearest = the reference's truncating sampler (the headline); bilinear = the opt-in 4-tap mode (pb_remap_bilinear_u8; no reference behaviour)")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the (independent) launches are dealt to round-robin")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configs measured in the same process)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC pass (profiles/traffic_*.json) instead of two rocprofv3 --pmc child runs of this script")
+    ap.add_argument("--flavour-probe", action="store_true", help="(child mode) print {plan_create_warm_ms, single_image_ms, faithful_kernel_ms} of --config for the math flavour this process loads (PB_MATH_FLAVOUR) and exit")
     ap.add_argument("--explain", action="store_true", help="also print the VERBOSE record (every figure with its workload text, timing protocol and notes) to stderr")
     ap.add_argument("--detail", default=None, help="write the verbose record to this file (default: gpurun_out/bench_detail.json when gpurun_out/ exists)")
     return ap.parse_args()
@@ -401,6 +403,43 @@ def traffic_for(name, info):
     if diff:
         return None, f"{os.path.relpath(tpath, ROOT)} was taken on another tile mix ({', '.join(f'{k}: {theirs.get(k)} vs {info.get(k)}' for k in diff)})"
     return tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
+
+
+def live_traffic(args, batch, kernel_prefix, timeout_s=180):
+    """HBM bytes per launch of the dominant kernel, MEASURED for this run: FETCH_SIZE and WRITE_SIZE, each in its own
+    `rocprofv3 --kernel-trace --pmc <counter>` pass of a short child run of this script (same config, sampling, budget, batch; 12 launches),
+    corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x 2, WRITE_SIZE as reported; both in KiB).  -> (bytes or None, source)"""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pb_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--config", args.config,
+               "--sampling", args.sampling, "--batch", str(batch), "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--no-configs", "--no-events", "--no-live-traffic"]
+        if args.budget:
+            cmd += ["--budget", str(args.budget)]
+        try:
+            res = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == ctr and row["Kernel_Name"].split("(")[0].replace("void ", "").startswith(kernel_prefix):
+                        vals.append(float(row["Counter_Value"]))
+            if res.returncode != 0 or not vals:
+                return None, f"rocprofv3 --pmc {ctr}: rc {res.returncode}, {len(vals)} dispatches of {kernel_prefix}: {res.stderr[-200:]!r}"
+            got[ctr] = (sum(vals) / len(vals), len(vals))
+        except Exception as exc:  # a measurement extra: the committed pass stands in
+            return None, f"rocprofv3 --pmc {ctr}: {exc!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    hbm = int(2 * got["FETCH_SIZE"][0] * 1024 + got["WRITE_SIZE"][0] * 1024)
+    return hbm, f"live: rocprofv3 --pmc FETCH_SIZE ({got['FETCH_SIZE'][1]} dispatches) x 2 + WRITE_SIZE ({got['WRITE_SIZE'][1]}), separate passes of this command with --steps 12"
 
 
 def headline_extras(lib, nat, d, rots, s, cfg, device, stream, budget):
@@ -681,6 +720,7 @@ def compact_line(full):
     r = full["roofline"]
     out["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "copy_ceiling_gbs", "frac_of_copy_ceiling", "algorithmic_bytes_per_launch",
                                          "must_move_bytes_per_launch", "attainable_frac", "kernel_ms_mean", "kernel_ms_median", "kernel_ms_p10", "kernel_ms_p90", "window_budget")}
+    out["roofline"]["traffic_live"] = r.get("traffic_live", False)
     if "frac_unamortised" in r:
         out["roofline"]["frac_unamortised"] = {k: r["frac_unamortised"][k] for k in ("single_image", "faithful_kernel", "break_even_frames")}
     for k in ("plan_create_ms", "plan_create_warm_ms", "first_frame_ms", "single_image_ms", "faithful_kernel_ms"):
@@ -752,8 +792,51 @@ def copy_ceiling_gbs(lib, nat, device, stream) -> float:
     return 2 * n / (best * 1e-3) / 1e9
 
 
+def flavour_probe(args):
+    """Child mode: what ONE math flavour costs on a geometry - warm plan preparation (thresholds, models, certification against
+    this flavour's float64 chain, tables) and the float64 kernel per frame.  The flavour is the library the process loads (PB_MATH_FLAVOUR)."""
+    import torch
+
+    from photonbend_amd import _native as nat
+
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    lib = nat.load()
+    cfg = CONFIGS[args.config]
+    d, rots, s = build_projs(cfg)
+    times = []
+    for _ in range(4):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        plan = nat.Plan(d, rots, s, budget=BENCH_BUDGET[args.config])
+        torch.cuda.synchronize(device)
+        times.append((time.perf_counter() - t0) * 1e3)
+        del plan
+    single_ms, faithful_ms = headline_extras(lib, nat, d, rots, s, cfg, device, 0, BENCH_BUDGET[args.config])
+    print(json.dumps({"flavour": nat.MATH_FLAVOUR, "lib": os.path.basename(nat.LIB_PATH), "config": args.config, "plan_create_warm_ms": round(min(times[1:]), 3),
+                      "single_image_ms": single_ms, "faithful_kernel_ms": faithful_ms}), flush=True)
+
+
+def flavours_block(config="c3", timeout_s=150):
+    """plan_create_warm_ms / faithful_kernel_ms of `config` under BOTH math flavours: two child runs of this script (a process loads one library)."""
+    out = {"config": config, "keys": ["plan_create_warm_ms", "single_image_ms", "faithful_kernel_ms"]}
+    for fl in ("svml", "libm"):
+        env = dict(os.environ, PB_MATH_FLAVOUR=fl)
+        env.pop("PB_LIB_PATH", None)
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--flavour-probe", "--config", config], env=env, capture_output=True, text=True, timeout=timeout_s)
+            j = json.loads(res.stdout.strip().splitlines()[-1])
+            assert j["flavour"] == fl
+            out[fl] = [j["plan_create_warm_ms"], j["single_image_ms"], j["faithful_kernel_ms"]]
+        except Exception as exc:  # a measurement extra: never fail the line over it
+            out[fl] = repr(exc)[:120]
+    return out
+
+
 def main():
     args = parse_args()
+    if args.flavour_probe:
+        return flavour_probe(args)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -915,6 +998,14 @@ def main():
         ceiling = copy_ceiling_gbs(lib, nat, device, sts[0])
         info = plan.info()
         traffic, traffic_src = (None, "bilinear run: the committed PMC passes are the nearest kernel's") if bilinear else traffic_for(args.config, info)
+        if world == 1 and not args.no_live_traffic:
+            kern = ("pb_bilinear_double_hot_kernel" if cfg["src"][0] == "double" else "pb_bilinear_hot_kernel") if bilinear else ("pb_hot_double_kernel" if cfg["src"][0] == "double" else "pb_hot_win_kernel")
+            live, live_src = live_traffic(args, batch, kern)
+            if live is not None:
+                committed = traffic
+                traffic, traffic_src = live, live_src + (f"; committed pass (profiles/): {committed}" if committed else "")
+            else:
+                traffic_src = f"{traffic_src}; live pass failed: {live_src}"
         line = {
             "metric": "Mpixels/s remapped, 8K equirect->equidistant" if cfg["pin"] == "c2" else f"Mpixels/s remapped ({args.config})",
             "value": round(value, 1),
@@ -949,6 +1040,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_live": bool(world == 1 and not args.no_live_traffic and traffic is not None and str(traffic_src).startswith("live")),
                 "copy_ceiling_gbs": round(ceiling, 1),
                 "frac_of_copy_ceiling": round(achieved / ceiling, 4),
                 "algorithmic_bytes_per_launch": alg_launch,
@@ -1008,6 +1100,7 @@ def main():
             for name in ("c1", "c2", "c3", "c5"):
                 block[name + "_bilinear"] = measure_config(lib, nat, name, device, sts[0], steps=60, warmup=8, bilinear=True)
             line["configs"] = block
+            line["flavours"] = flavours_block("c3")
             try:
                 line["host_path"] = host_path(cfg, d, rots, s)
             except Exception as exc:  # a measurement extra: never fail the line over it

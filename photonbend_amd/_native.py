@@ -162,7 +162,7 @@ _lock = threading.Lock()
 
 def load() -> C.CDLL:
     """dlopen the in-tree HIP library and bind every declared symbol."""
-    global _lib
+    global _lib, MATH_FLAVOUR
     if _lib is not None:
         return _lib
     with _lock:
@@ -180,8 +180,14 @@ def load() -> C.CDLL:
             fn.argtypes = args
         if lib.pb_abi_version() != ABI_VERSION:
             raise PbError(f"ABI version mismatch: library says {lib.pb_abi_version()}, binding expects {ABI_VERSION}")
-        if not os.environ.get("PB_LIB_PATH") and lib.pb_math_flavour() != (1 if MATH_FLAVOUR == "libm" else 0):
-            raise PbError(f"{LIB_PATH} is not the {MATH_FLAVOUR} flavour of the library")
+        # the flavour a process runs in is the LIBRARY's: the plan cache's key and the fixtures the tests pick follow it.  A product library
+        # must be the host's flavour; a library named by PB_LIB_PATH (A/B builds, the diagnostic build) says itself which one it is - and
+        # must agree with an explicit PB_MATH_FLAVOUR.
+        theirs = "libm" if lib.pb_math_flavour() == 1 else "svml"
+        if theirs != MATH_FLAVOUR:
+            if not os.environ.get("PB_LIB_PATH") or os.environ.get("PB_MATH_FLAVOUR", "").lower() in ("svml", "libm"):
+                raise PbError(f"{LIB_PATH} is the {theirs} flavour of the library, this process wants {MATH_FLAVOUR}")
+            MATH_FLAVOUR = theirs
         _lib = lib
     return _lib
 

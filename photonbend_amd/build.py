@@ -94,7 +94,24 @@ def build_diagnostic(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(DIAG_LIB_PATH) and not _stale_against(DIAG_LIB_PATH):
         return DIAG_LIB_PATH
     os.makedirs(os.path.dirname(DIAG_LIB_PATH), exist_ok=True)
-    return build_library(force=True, verbose=verbose, out=DIAG_LIB_PATH, defines=("PB_ABLATION",))
+    # (in the HOST's math flavour, like the product library the tests compare it with - ADVICE r5)
+    return build_library(force=True, verbose=verbose, out=DIAG_LIB_PATH, defines=("PB_ABLATION",) + (("PB_MATH_LIBM",) if _host_flavour() == "libm" else ()))
+
+
+def _host_flavour() -> str:
+    """"svml" or "libm": what this host's NumPy dispatches np.arcsin / arccos / arctan / tan to (_native.host_math_flavour, without importing it:
+    _native imports this module)."""
+    env = os.environ.get("PB_MATH_FLAVOUR", "").lower()
+    if env in ("svml", "libm"):
+        return env
+    try:
+        try:
+            from numpy._core._multiarray_umath import __cpu_features__ as feats
+        except ImportError:
+            from numpy.core._multiarray_umath import __cpu_features__ as feats
+    except Exception:
+        return "svml"
+    return "svml" if feats.get("AVX512_SKX") else "libm"
 
 
 def _stale_against(path: str) -> bool:
@@ -106,7 +123,7 @@ def _stale_against(path: str) -> bool:
 
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
-    if "--libm" in sys.argv:
+    if "--libm" in sys.argv or _host_flavour() == "libm":  # (a host without AVX512_SKX loads the second flavour: build it without being asked)
         print(build_libm_flavour(force=True, verbose=True))
     if "--diag" in sys.argv:
         print(build_diagnostic(force=True, verbose=True))

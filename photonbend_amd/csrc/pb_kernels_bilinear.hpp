@@ -212,52 +212,50 @@ __device__ __forceinline__ PbBilCoord pb_bil_coord_of(const PbParams& P, const P
 
 // ---- the arithmetic of one pixel -------------------------------------------------------------------------------------------
 // Two horizontally adjacent taps are 6 consecutive bytes; (lo, hi) = the 8 bytes from the left tap's first byte on.  The four weights
-// (1-tx)(1-ty), tx(1-ty), (1-tx)ty, tx ty are formed once; channels 0 and 1 run as one float2 (v_pk_mul / v_pk_fma_f32), every byte is
-// converted straight from its place (v_cvt_f32_ubyteN), and the result is rounded half-to-even, clamped and packed by
-// v_cvt_pk_u8_f32 (checked on MI355X: experiments/r4/exp_isa.hip).  (The definition nests three lerps in float64; the weighted sum
-// in float32 differs from it by ~1e-5 LSB, i.e. only where the exact value sits that close to x.5.)
-__device__ __forceinline__ unsigned pb_bil_mix64(unsigned lo0, unsigned hi0, unsigned lo1, unsigned hi1, float tx, float ty) {
-    const pb_f2 a = {(float)(lo0 & 0xFFu), (float)((lo0 >> 8) & 0xFFu)}, b = {(float)(lo0 >> 24), (float)(hi0 & 0xFFu)};
-    const pb_f2 c = {(float)(lo1 & 0xFFu), (float)((lo1 >> 8) & 0xFFu)}, d = {(float)(lo1 >> 24), (float)(hi1 & 0xFFu)};
-    const float a2 = (float)((lo0 >> 16) & 0xFFu), b2 = (float)((hi0 >> 8) & 0xFFu);
-    const float c2 = (float)((lo1 >> 16) & 0xFFu), d2 = (float)((hi1 >> 8) & 0xFFu);
-    const float ux = 1.0f - tx, uy = 1.0f - ty;
-    const float w00 = ux * uy, w01 = tx * uy, w10 = ux * ty, w11 = tx * ty;
-    const pb_f2 ww = {w00, w00};
-    pb_f2 v = a * ww;
-    v = pb_fma2(b, w01, v);
-    v = pb_fma2(c, w10, v);
-    v = pb_fma2(d, w11, v);
-    const float v2 = fmaf(d2, w11, fmaf(c2, w10, fmaf(b2, w01, a2 * w00)));
-    unsigned out = __builtin_amdgcn_cvt_pk_u8_f32(v.x, 0u, 0u);
-    out = __builtin_amdgcn_cvt_pk_u8_f32(v.y, 1u, out);
-    return __builtin_amdgcn_cvt_pk_u8_f32(v2, 2u, out);
+// (1-tx)(1-ty), tx(1-ty), (1-tx)ty, tx ty are formed once per pixel in float32.  (The definition nests three lerps in float64.)
+//
+// Round 6: the weighted sum runs in INTEGERS.  The four weights, formed in float32 as before, become 16-bit fixed point (v_cvt_pknorm_u16_f32
+// packs two per instruction; the factor 65536 / 65535 rides on the (1 - ty, ty) pair so that a weight w comes out as round(65536 w)),
+// a channel's two taps of a row are lifted into one dword of two 16-bit lanes by ONE v_perm_b32 straight from the 8 bytes, and
+// v_dot2_u32_u16 takes a row's two products and the running sum in one instruction: per pixel 6 v_perm + 6 v_dot2 + 2 v_perm to pack
+// where the float32 form took 12 byte-to-float conversions, 6 packed multiply-adds and 3 pack-converts - a quarter of a window tile's
+// vector instructions, and the tile code is bound by vector issue.  The sum is exact in 32 bits (255 x 65538 < 2^24);
+// +0.5 rides in the accumulator, the channel is bits 16-23.  Against the float32 form: the weights carry 16 bits instead of 24 - a value
+// error of at most 0.008 LSB before rounding (typically 0.001) - and an exact tie rounds up instead of to even.
+typedef unsigned short pb_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pb_udot2(unsigned a, unsigned b, unsigned c) {
+    pb_us2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    return __builtin_amdgcn_udot2(x, y, c, false);
 }
-// Two pixels at once: the weights of both are formed packed, channels 0 / 1 of each pixel run as one float2 against that pixel's
-// weights (broadcast from the pair), and the two pixels' third channels share a float2: 18 packed instructions per pair where two
-// single calls take 26.
+__device__ __forceinline__ unsigned pb_pknorm_u16(float lo, float hi) {
+    const pb_us2 w = __builtin_amdgcn_cvt_pknorm_u16(lo, hi);
+    unsigned u;
+    __builtin_memcpy(&u, &w, 4);
+    return u;
+}
+#define PB_BIL_WSCALE (65536.0f / 65535.0f)
+// one pixel: (lo, hi) of the two rows, W0 = (w00, w01), W1 = (w10, w11) as 16-bit fixed point
+__device__ __forceinline__ unsigned pb_bil_dot(unsigned lo0, unsigned hi0, unsigned lo1, unsigned hi1, unsigned W0, unsigned W1) {
+    // v_perm_b32(S0, S1, sel): selector 0-3 = bytes of S1, 4-7 = bytes of S0, 0x0c = 0x00: (tap a's byte, 0, tap b's byte, 0)
+    const unsigned s0 = pb_udot2(__builtin_amdgcn_perm(hi1, lo1, 0x0c030c00u), W1, pb_udot2(__builtin_amdgcn_perm(hi0, lo0, 0x0c030c00u), W0, 0x8000u));
+    const unsigned s1 = pb_udot2(__builtin_amdgcn_perm(hi1, lo1, 0x0c040c01u), W1, pb_udot2(__builtin_amdgcn_perm(hi0, lo0, 0x0c040c01u), W0, 0x8000u));
+    const unsigned s2 = pb_udot2(__builtin_amdgcn_perm(hi1, lo1, 0x0c050c02u), W1, pb_udot2(__builtin_amdgcn_perm(hi0, lo0, 0x0c050c02u), W0, 0x8000u));
+    return __builtin_amdgcn_perm(s2, __builtin_amdgcn_perm(s1, s0, 0x0c0c0602u), 0x0c060100u);  // bytes 2 of the three sums
+}
+__device__ __forceinline__ unsigned pb_bil_mix64(unsigned lo0, unsigned hi0, unsigned lo1, unsigned hi1, float tx, float ty) {
+    const float ux = 1.0f - tx, uy = fmaf(-ty, PB_BIL_WSCALE, PB_BIL_WSCALE), vy = ty * PB_BIL_WSCALE;
+    return pb_bil_dot(lo0, hi0, lo1, hi1, pb_pknorm_u16(ux * uy, tx * uy), pb_pknorm_u16(ux * vy, tx * vy));
+}
+// Two pixels at once: their weights are formed packed (v_pk_*).
 __device__ __forceinline__ void pb_bil_mix64x2(const unsigned lo0[2], const unsigned hi0[2], const unsigned lo1[2], const unsigned hi1[2], const pb_f2 tx,
                                                const pb_f2 ty, unsigned out[2]) {
-    const pb_f2 one = {1.0f, 1.0f};
-    const pb_f2 ux = one - tx, uy = one - ty;
-    const pb_f2 w00 = ux * uy, w01 = tx * uy, w10 = ux * ty, w11 = tx * ty;
-    pb_f2 v[2];
+    const pb_f2 one = {1.0f, 1.0f}, k = {PB_BIL_WSCALE, PB_BIL_WSCALE};
+    const pb_f2 ux = one - tx, uy = __builtin_elementwise_fma(-ty, k, k), vy = ty * k;
+    const pb_f2 w00 = ux * uy, w01 = tx * uy, w10 = ux * vy, w11 = tx * vy;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const pb_f2 a = {(float)(lo0[i] & 0xFFu), (float)((lo0[i] >> 8) & 0xFFu)}, b = {(float)(lo0[i] >> 24), (float)(hi0[i] & 0xFFu)};
-        const pb_f2 c = {(float)(lo1[i] & 0xFFu), (float)((lo1[i] >> 8) & 0xFFu)}, d = {(float)(lo1[i] >> 24), (float)(hi1[i] & 0xFFu)};
-        const pb_f2 q00 = {w00[i], w00[i]}, q01 = {w01[i], w01[i]}, q10 = {w10[i], w10[i]}, q11 = {w11[i], w11[i]};
-        v[i] = __builtin_elementwise_fma(d, q11, __builtin_elementwise_fma(c, q10, __builtin_elementwise_fma(b, q01, a * q00)));
-    }
-    const pb_f2 a2 = {(float)((lo0[0] >> 16) & 0xFFu), (float)((lo0[1] >> 16) & 0xFFu)}, b2 = {(float)((hi0[0] >> 8) & 0xFFu), (float)((hi0[1] >> 8) & 0xFFu)};
-    const pb_f2 c2 = {(float)((lo1[0] >> 16) & 0xFFu), (float)((lo1[1] >> 16) & 0xFFu)}, d2 = {(float)((hi1[0] >> 8) & 0xFFu), (float)((hi1[1] >> 8) & 0xFFu)};
-    const pb_f2 v2 = __builtin_elementwise_fma(d2, w11, __builtin_elementwise_fma(c2, w10, __builtin_elementwise_fma(b2, w01, a2 * w00)));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        unsigned o = __builtin_amdgcn_cvt_pk_u8_f32(v[i].x, 0u, 0u);
-        o = __builtin_amdgcn_cvt_pk_u8_f32(v[i].y, 1u, o);
-        out[i] = __builtin_amdgcn_cvt_pk_u8_f32(v2[i], 2u, o);
-    }
+    for (int i = 0; i < 2; ++i) out[i] = pb_bil_dot(lo0[i], hi0[i], lo1[i], hi1[i], pb_pknorm_u16(w00[i], w01[i]), pb_pknorm_u16(w10[i], w11[i]));
 }
 // the same from four separate taps (low 3 bytes of each)
 __device__ __forceinline__ unsigned pb_bil_mix4(unsigned p00, unsigned p01, unsigned p10, unsigned p11, float tx, float ty) {
@@ -925,22 +923,29 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_bilinear_double_kernel(const PbPa
 //               and stored factors.
 // Pair workgroups hold nothing but pair slots (and pads that only meet the barrier): every wave of one reaches the barrier exactly once.
 // Round 5's one wave per two-eye tile sampled the eyes one after the other and held both results: 168 VGPRs, 3 waves per SIMD.
-struct PbDblBlend {  // what the blend needs of the parameter block (projection.py:414-418)
+// What only SOME waves need - the blend's tables and constants (projection.py:414-418), the fix lists - lives in ONE plan-resident block
+// behind a pointer, fetched by the waves that use it (a by-row / by-latitude / failed tile, a tile with fix pixels).  As kernel arguments
+// (round 5: the whole 1216-byte parameter block by value, then six pointers and four doubles) they sat in scalar registers for the
+// life of EVERY wave next to its 64-register tile entry: the kernel ran at the edge of the 102 SGPRs, and whether the compiler kept the
+// entry there or moved it through VGPR lanes (1 400 v_readlane in the tile code, +40 % vector instructions per wave, c5 80 -> 91 us)
+// changed with the spelling of an unrelated `if` (experiments/README.md round 6).  experiments/r6/isa_stats.py prints the lane traffic.
+struct PbDblTables {
     double mrg_min, mrg_max_safe, mrg_max, mrg_range;
-    int32_t eye_w, pad;
+    const PbSepRow* rows;
+    const double* lat_tab;
+    const int32_t* fix_px;
+    const PbBilCoord* fix_xy;
+    const PbDoubleFix* tile_fix;
+    const PbDoubleFix* px_fix;
 };
 #define PB_PAIR_HDR 1024  // dword offset of wave R's header in its region, behind its 64 x 16 packed pixels: fix_cnt, fix_off, aux_off
 template <int WMODE>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinear_double_hot_kernel(const PbHot Hd, const PbDblBlend B, const PbTileEntry* __restrict__ ltable,
-                                                                                     const PbSepRow* __restrict__ rows,
-                                                                                     const double* __restrict__ lat_tab,
+__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinear_double_hot_kernel(const PbHot Hd, const int eye_w, const PbTileEntry* __restrict__ ltable,
+                                                                                     const PbDblTables* __restrict__ X,
                                                                                      const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                                      const unsigned groups_per_frame, unsigned long long src_stride,
                                                                                      unsigned long long dst_stride, int windows,
-                                                                                     const PbBilCoord* __restrict__ bil_xy, const int32_t* __restrict__ fix_px,
-                                                                                     const PbBilCoord* __restrict__ fix_xy,
-                                                                                     const PbDoubleFix* __restrict__ tile_fix,
-                                                                                     const PbDoubleFix* __restrict__ px_fix) {
+                                                                                     const PbBilCoord* __restrict__ bil_xy) {
     asm volatile("" ::"s"(ltable), "s"(Hd.dst_w), "s"(Hd.dst_h), "s"(Hd.src_w), "s"(Hd.src_h), "s"(Hd.win_budget), "s"(groups_per_frame));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -958,7 +963,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinea
     const bool pair = (flags & (PB_TILE_TWO | PB_TILE_PAIR_R)) != 0, right = (flags & (PB_TILE_PAIR_R | PB_TILE_EYE_R)) != 0;
     // (a slot that leaves early - a pad, a tile on the plan's float64 list, which pb_bilinear_double_fix_kernel repaints - still owes its
     // pair workgroup the barrier, and a wave R its header: wave L walks the fix lists it names)
-    if ((flags & PB_TILE_SKIP) || (entry.bil_off >= 0 && !bil_xy)) {
+    const bool leave = (flags & PB_TILE_SKIP) || (entry.bil_off >= 0 && !bil_xy);
+    if (leave) {
         if (pair) {
             if (!(flags & PB_TILE_SKIP) && (flags & PB_TILE_PAIR_R) && lane == 0) {
                 unsigned* hdr = pb_dyn_lds + (((unsigned)entry.win_r0 & 0xFFFFu) >> 2) + PB_PAIR_HDR;
@@ -973,7 +979,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinea
     const int tx = entry.tile_xy & 0xFFFF, ty = (int)((unsigned)entry.tile_xy >> 16);
     const int X0 = tx * PB_TILE, Y0 = ty * PB_TILE;
     const int xg = lane & 7, yb = lane >> 3;
-    const int W = Hd.dst_w, H = Hd.dst_h, eye_w = B.eye_w;
+    const int W = Hd.dst_w, H = Hd.dst_h;
     unsigned* win = pb_dyn_lds + (((unsigned)entry.win_r0 & 0xFFFFu) >> 2);  // (the wave's LDS region: its slot says where in the workgroup's pool)
     unsigned a[16];
     pb_bil_vals<false>(Hd, &entry, flags & ~(PB_TILE_TWO | PB_TILE_PAIR_R), lane, win, windows, src, bil_xy, right ? eye_w : 0, right ? Hd.src_w : eye_w, a);
@@ -1006,7 +1012,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinea
     const int nl = entry.fix_cnt, off_l = entry.fix_off;
     if (flags & PB_TILE_FAILED) {
         // the faithful factors of every pixel of a failed tile (slot = the right-eye entry's aux_off, pb_double_tables_kernel)
-        const PbDoubleFix* __restrict__ slot = tile_fix + (size_t)__builtin_amdgcn_readfirstlane((int)xr[PB_PAIR_HDR + 2]) * (PB_TILE * PB_TILE);
+        const PbDoubleFix* __restrict__ slot = X->tile_fix + (size_t)__builtin_amdgcn_readfirstlane((int)xr[PB_PAIR_HDR + 2]) * (PB_TILE * PB_TILE);
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr)
 #pragma unroll
@@ -1024,6 +1030,9 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinea
                 a[n] = (((l & 0x00FF00FFu) + (r & 0x00FF00FFu)) & 0x00FF00FFu) | (((l & 0x0000FF00u) + (r & 0x0000FF00u)) & 0x0000FF00u);
             }
         } else {
+            const PbSepRow* __restrict__ rows = X->rows;
+            const double* __restrict__ lat_tab = X->lat_tab;
+            const double mrg_min = X->mrg_min, mrg_max_safe = X->mrg_max_safe, mrg_max = X->mrg_max, mrg_range = X->mrg_range;
 #pragma unroll
             for (int jr = 0; jr < 4; ++jr) {
                 double wl = 1.0, wr = 1.0;
@@ -1036,8 +1045,8 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinea
                 for (int k = 0; k < 4; ++k) {
                     if (by_lat) {
                         const double t = lat_tab[(size_t)entry.aux_off * PB_LAT_TILE_DOUBLES + (yb + 8 * jr) * PB_TILE + 4 * xg + k];
-                        wl = pb_merge_factor_of(B.mrg_min, B.mrg_max_safe, B.mrg_max, B.mrg_range, t);
-                        wr = pb_merge_factor_of(B.mrg_min, B.mrg_max_safe, B.mrg_max, B.mrg_range, (t * -1.0) + PB_PI);
+                        wl = pb_merge_factor_of(mrg_min, mrg_max_safe, mrg_max, mrg_range, t);
+                        wr = pb_merge_factor_of(mrg_min, mrg_max_safe, mrg_max, mrg_range, (t * -1.0) + PB_PI);
                     }
                     a[jr * 4 + k] = pb_sep_blend(a[jr * 4 + k], ar[jr * 4 + k], wl, wr);
                 }
@@ -1045,9 +1054,12 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinea
         }
     }
     pb_bil_store<false>(a, dst, X0, Y0, lane, W, H);
-    if (nl + nr > 0 && fix_xy) {
+    if (nl + nr > 0 && bil_xy) {  // (the fix list's coordinates exist with the coordinate table)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own stores have completed
         const unsigned frame_bytes = 3u * (unsigned)Hd.src_w * (unsigned)Hd.src_h;
+        const int32_t* __restrict__ fix_px = X->fix_px;
+        const PbBilCoord* __restrict__ fix_xy = X->fix_xy;
+        const PbDoubleFix* __restrict__ px_fix = X->px_fix;
         for (int base = 0; base < nl + nr; base += 64) {
             const int n = base + lane;
             if (n < nl + nr) {

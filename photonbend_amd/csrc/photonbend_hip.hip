@@ -84,6 +84,7 @@ struct pb_plan {
     PbTileEntry* ltable_bil = nullptr;
     unsigned launch_groups_bil = 0;
     int bil_budget = 0;
+    PbDblTables* bil_dbl_tables = nullptr;  // double-fisheye plans: what only some waves of the bilinear launch need, behind one pointer (pb_kernels_bilinear.hpp)
     unsigned bil_pool_bytes = 0;  // dynamic LDS of a bilinear launch's workgroup: the slots' regions are packed into it (pb_bilinear_pool_kernel)
     PbParams* P_dev = nullptr;   // device copy of P as the hot launches see it (refreshed with every budget change)
     unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
@@ -871,7 +872,9 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
 // the tile tables' flags under THAT budget: pb_apply_budget (the nearest mode's) must follow.  A failure leaves the plan without the
 // table (the bilinear launches then take the float64 kernels), never with a stale one.  Synchronous.
 #define PB_BIL_WIN_BUDGET PB_WINLDS_MAX
+#ifndef PB_BIL_POOL_SMALL
 #define PB_BIL_POOL_SMALL 40448u  // the bilinear workgroups' small LDS pool: four of them per CU (160 KiB of LDS)
+#endif
 //  // measured on MI355X (experiments/r4/budget_bil.sh): c1 28.7 us at 7 KiB, 25.2 at 12; c2 68.9 / 62.0; c5 109.8 / 103.4; c3 58.3 / 58.9
 static int pb_build_bilinear_launch(pb_plan* pl) {
     if (!(pl->fast_ready || pl->dbl_ready)) return PB_OK;
@@ -914,6 +917,17 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
         pl->ltable_bil = nullptr;
         pl->launch_groups_bil = 0;
         return pb_fail(PB_ERR_HIP, e != hipSuccess ? std::string("bilinear LDS pool: ") + hipGetErrorString(e) : std::string("bilinear LDS pool: a workgroup does not fit"));
+    }
+    if (pl->dbl_ready) {
+        const PbDblTables T = {pl->P.mrg_min, pl->P.mrg_max_safe, pl->P.mrg_max, pl->P.mrg_range, pl->sep_ready ? pl->sep_rows : nullptr, pl->lat_tab, pl->fix_px,
+                               pl->bil_fix_xy, pl->dbl_tile_fix, pl->dbl_px_fix};
+        if ((!pl->bil_dbl_tables && hipMalloc((void**)&pl->bil_dbl_tables, sizeof(PbDblTables)) != hipSuccess) ||
+            hipMemcpy(pl->bil_dbl_tables, &T, sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(pl->ltable_bil);
+            pl->ltable_bil = nullptr;
+            pl->launch_groups_bil = 0;
+            return pb_fail(PB_ERR_HIP, "bilinear launch: out of device memory");
+        }
     }
     pl->bil_pool_bytes = pool;
     return PB_OK;
@@ -1208,6 +1222,7 @@ void pb_plan_destroy(pb_plan* plan) {
     (void)hipFree(plan->saved_r);
     (void)hipFree(plan->ltable);
     (void)hipFree(plan->ltable_bil);
+    (void)hipFree(plan->bil_dbl_tables);
     (void)hipFree(plan->P_dev);
     (void)hipFree(plan->bil_tiles);
     (void)hipFree(plan->bil_xy);
@@ -1419,12 +1434,11 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
         return pb_fail(PB_ERR_INVALID, "src_frame_stride smaller than a frame");
     hipStream_t st = (hipStream_t)stream;
     if (P.src.kind == PB_KIND_DOUBLE) {
-        if (plan->dbl_ready && plan->ltable_bil && plan->launch_groups_bil > 0 && plan->bil_tiles && plan->mode != PB_MODE_FAITHFUL) {
+        if (plan->dbl_ready && plan->ltable_bil && plan->launch_groups_bil > 0 && plan->bil_tiles && plan->bil_dbl_tables && plan->mode != PB_MODE_FAITHFUL) {
             // the per-eye tile models of the nearest mode's plan + the exact coordinate tables: one wave per tile, ONE launch
             const unsigned gpf = plan->launch_groups_bil;
             PbHot Hb = pb_hot_of_host(P);  // (the bilinear mode's window budget travels in it)
             Hb.win_budget = plan->bil_budget;
-            const PbDblBlend Bl = {P.mrg_min, P.mrg_max_safe, P.mrg_max, P.mrg_range, P.src_eye_w, 0};
             const int windows = plan->mode != PB_MODE_FAST_DIRECT && ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
             const PbSepRow* rows = plan->sep_ready ? plan->sep_rows : nullptr;
             const int per_launch = (int)(0x7FFFFFFFu / gpf);
@@ -1434,9 +1448,8 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
                 const uint8_t* sf = src_dev + (unsigned long long)f0 * src_frame_stride;
                 uint8_t* df = dst_dev + (unsigned long long)f0 * dst_frame_stride;
 #define PB_LAUNCH_BILINEAR_DOUBLE(WMODE)                                                                                                       \
-    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, (size_t)plan->bil_pool_bytes, st, Hb, Bl, plan->ltable_bil, rows, \
-                       plan->lat_tab, sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy,  \
-                       plan->fix_px, plan->bil_fix_xy, plan->dbl_tile_fix, plan->dbl_px_fix)
+    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, (size_t)plan->bil_pool_bytes, st, Hb, P.src_eye_w, plan->ltable_bil, plan->bil_dbl_tables, \
+                       sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy)
                 if (rows) PB_LAUNCH_BILINEAR_DOUBLE(1);
                 else if (plan->n_lat_tiles) PB_LAUNCH_BILINEAR_DOUBLE(2);
                 else PB_LAUNCH_BILINEAR_DOUBLE(0);

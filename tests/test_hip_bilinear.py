@@ -143,7 +143,7 @@ def test_bilinear_full_size_against_definition(case):
     frame = nat.synth_frame(h, w, frame=0, seed=0, circle_mask=case.mask)
     out = plan.remap(frame, interpolation="bilinear")
     Hd, Wd = case.dst[1], case.dst[2]
-    limit = 2 if case.src[0] == "double" else 1
+    limit = 1  # (double sources too: measured on every pixel of c5 at 180 and 195 degrees - experiments/r6/quality_census.py - no pixel beyond 1)
 
     def diff(got, want):
         d = np.abs(got.astype(np.int16) - want.astype(np.int16))

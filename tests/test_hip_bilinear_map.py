@@ -155,7 +155,8 @@ def test_tile_kernels_within_one_lsb_of_the_definition_on_every_pixel_at_full_si
     frame: 255 LSB per pixel of coordinate error): the tile kernels (pb_remap_bilinear_u8) against the per-pixel definition kernel
     (pb_sample_map_bilinear_u8, equal to oracle.remap_bilinear to the bit: the test above).  No pixel beyond 1 LSB (the double blend's
     cast wraps mod 256 like the reference's), no pixel black in one and sampled in the other, at most 1 % of the pixels different at all
-    (measured round 5: 0.03-0.5 %; the tile kernels evaluate float32 coordinate models certified to 1/1024 px and blend in float32)."""
+    (measured round 6: 0.29-0.65 %; the tile kernels evaluate float32 coordinate models certified to 1/1024 px and blend with 16-bit
+    fixed-point weights - round 5's float32 blend: 0.03-0.5 %; experiments/r6/quality_census.py)."""
     from photonbend_amd import _native as nat
 
     _, h, w, *_ = case.src
@@ -173,5 +174,5 @@ def test_tile_kernels_within_one_lsb_of_the_definition_on_every_pixel_at_full_si
     d = d.amax(dim=2)
     flips = (got == 0).all(dim=2) != (want == 0).all(dim=2)
     assert int((d > 1).sum()) == 0, f"{int((d > 1).sum())} pixels beyond 1 LSB (max {int(d.max())})"
-    assert int((flips & (d > 1)).sum()) == 0 and int(flips.sum()) <= 16, f"{int(flips.sum())} pixels black in one output and not in the other"
+    assert int(flips.sum()) == 0, f"{int(flips.sum())} pixels black in one output and not in the other"
     assert int((d > 0).sum()) * 100 <= d.numel(), f"{int((d > 0).sum())} of {d.numel()} pixels differ"

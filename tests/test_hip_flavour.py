@@ -96,3 +96,76 @@ def test_first_flavour_library_refuses_the_libm_flag():
     assert nat.load().pb_plan_create_ex(C.byref(d), None, 0, C.byref(s), nat.PLAN_DEFER | nat.PLAN_MATH_LIBM, 0, C.byref(h)) == -3
     assert nat.load().pb_plan_create_ex(C.byref(d), None, 0, C.byref(s), nat.PLAN_DEFER | nat.PLAN_MATH_SVML, 0, C.byref(h)) == 0
     nat.load().pb_plan_destroy(h)
+
+
+_FULL_WORKER = r"""
+import hashlib, json, sys, time
+import numpy as np
+import torch
+from photonbend_amd import _native as nat
+from tests import helpers as H
+from tests.cases import full_cases
+assert nat.MATH_FLAVOUR == "libm" and nat.load().pb_math_flavour() == 1 and nat.LIB_PATH.endswith("libphotonbend_hip_libm.so")
+sha = lambda t: hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest()
+names = sys.argv[2:]
+out = {}
+for case in full_cases():
+    if case.name not in names:
+        continue
+    rec = {"map_sha256": []}
+    for m in H.pb_map_stages(case):          # the float64 map API, stage by stage (pb_coordmap_f64 / pb_rotate_f64)
+        rec["map_sha256"].append(H.canonical_map_sha(m))
+        del m
+    plan = H.pb_plan_private(case)            # prepared plan: tile models certified against THIS flavour's float64 chain
+    idx = plan.index_map()
+    if case.src[0] == "double":
+        rec["idx_l_sha256"], rec["idx_r_sha256"] = sha(idx[0]), sha(idx[1])
+    else:
+        rec["idx_sha256"] = sha(idx)
+    del idx
+    frame = nat.synth_frame(case.src[1], case.src[2], frame=0, seed=0, circle_mask=case.mask)
+    rec["frame_sha256"] = sha(frame)
+    rec["u8_fast_sha256"] = sha(plan.remap(frame))
+    plan.set_mode(nat.MODE_FAITHFUL)          # the float64 kernel: what a deferred plan runs per frame
+    rec["u8_faithful_sha256"] = sha(plan.remap(frame))
+    out[case.name] = rec
+    del plan, frame
+    torch.cuda.empty_cache()
+json.dump(out, open(sys.argv[1], "w"))
+"""
+
+
+@pytest.mark.gpu
+def test_libm_flavour_library_at_baseline_size(tmp_path):
+    """the BASELINE geometries at FULL size through libphotonbend_hip_libm.so against what the REFERENCE returns under the
+    no-AVX-512 dispatch (tests/golden/libm_flavour_full.json, oracle/make_goldens.py --libm-flavour-full).  Of the five only c3 reaches the
+    two calls that differ between the flavours (arcsin in the equisolid inverse, lens.py:206-220; arccos in the rotation, rotation.py:158):
+    its float64 maps hash differently from the first flavour's (last bits), its index map and bytes - 16.8 M truncations - do not move;
+    c1 and c5 run neither call.  Every float64 map stage, the index map of the prepared plan and the bytes of BOTH the prepared plan and the
+    float64 kernel must equal the reference's."""
+    from photonbend_amd.build import LIBM_LIB_PATH
+
+    if not os.path.exists(LIBM_LIB_PATH):
+        pytest.skip("needs the second-flavour build (python -m photonbend_amd.build --libm)")
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "libm_flavour_full.json")))["cases"]
+    first = json.load(open(os.path.join(ROOT, "tests", "golden", "full.json")))
+    names = ["c1", "c3", "c5_195"]
+    res_path = str(tmp_path / "res.json")
+    env = dict(os.environ, PB_MATH_FLAVOUR="libm")
+    env.pop("PB_LIB_PATH", None)
+    res = subprocess.run([sys.executable, "-c", _FULL_WORKER, res_path, *names], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    got = json.load(open(res_path))
+    assert sorted(got) == sorted(names)
+    for name in names:
+        g, w = got[name], want[name]
+        assert g["frame_sha256"] == w["frame_sha256"]
+        assert g["map_sha256"] == w["map_sha256"], f"{name}: a float64 map stage differs from the reference's under the no-AVX-512 dispatch"
+        for key in ("idx_sha256", "idx_l_sha256", "idx_r_sha256"):
+            if key in w:
+                assert g[key] == w[key], f"{name}: {key}"
+        assert g["u8_fast_sha256"] == w["u8_sha256"], f"{name}: the prepared plan's bytes"
+        assert g["u8_faithful_sha256"] == w["u8_sha256"], f"{name}: the float64 kernel's bytes"
+    # the fixture really is the other flavour's: c3's maps differ from the first flavour's pins, its truncations do not
+    assert want["c3"]["map_sha256"] != first["c3"]["map_sha256"] and want["c3"]["idx_sha256"] == first["c3"]["idx_sha256"]
+    assert want["c1"]["map_sha256"] == first["c1"]["map_sha256"]
