@@ -616,7 +616,7 @@ def host_path(cfg, d, rots, s):
     ring = (time.perf_counter() - t0) / n * 1e3
     once = [pool[k % n_pool].copy() for k in range(n)]
     t0 = time.perf_counter()
-    cnt += sum(1 for _ in batch.remap_frames(plan, iter(once)))
+    cnt += sum(1 for _ in batch.remap_frames(plan, once))  # (a list: frames that already exist are page-locked one ahead of their upload)
     staged = (time.perf_counter() - t0) / n * 1e3
     assert cnt == 2 * n
     del once
@@ -638,13 +638,13 @@ def host_path(cfg, d, rots, s):
     return {
         "workload": cfg["text"] + " - uint8 ndarray in host memory in, fresh uint8 ndarray out",
         "ms_per_frame_single_call": fresh,
-        "ms_per_frame_single_call_note": "remap of an ndarray never seen before (upload staged through page-locked chunks on a few threads) -> fresh ndarray (page-locked, written by the download DMA directly)",
+        "ms_per_frame_single_call_note": "remap of an ndarray never seen before (frame-sized: page-locked in place, 0.2-0.35 ms, then ONE upload DMA) -> fresh ndarray (page-locked, written by the download DMA directly)",
         "ms_per_frame_single_call_reused_buffer": reused,
-        "ms_per_frame_single_call_reused_buffer_note": "the caller refills ONE buffer: page-locked in place on its second sighting, then one DMA straight out of the caller's memory",
+        "ms_per_frame_single_call_reused_buffer_note": "the caller refills ONE buffer: page-locked in place when first seen, then one DMA straight out of the caller's memory per call",
         "ms_per_frame_streamed": round(max(ring, staged), 3),
         "ms_per_frame_streamed_ring_of_caller_buffers": round(ring, 3),
         "ms_per_frame_streamed_never_seen_arrays": round(staged, 3),
-        "ms_per_frame_streamed_note": "batch.remap_frames: upload of frame k + 1, kernel of frame k and download of frame k - 1 on three streams; `ms_per_frame_streamed` is the slower of the two source kinds",
+        "ms_per_frame_streamed_note": "batch.remap_frames: the upload DMA of frame k + 1 beside the remap kernel of frame k, which stores over PCIe straight into its page-locked result ndarray (the two DMA directions side by side take 2.41 ms on this pool's boxes, an upload DMA beside a storing kernel 2.06: experiments/r6/pcie_paths.py); `ms_per_frame_streamed` is the slower of the two source kinds",
         **dma,
         "bytes_up": int(np.prod(sh)), "bytes_down": int(np.prod(dh)),
         "mpx_per_s_streamed": round(d.height * d.width / 1e6 / (max(ring, staged) * 1e-3), 1),

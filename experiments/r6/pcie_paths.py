@@ -46,3 +46,30 @@ try:
     print("remap into host memory is the device result:", bool(np.array_equal(hout.reshape(want.shape), want)))
 except Exception as exc:
     print("remap kernel into host memory:", exc)
+
+# ---- what an ndarray the library has never seen costs to get across: page-lock it in place (hipHostRegister) + one DMA, against the chunked staging copy
+from photonbend_amd import _hostpipe
+pipe = _hostpipe.pipe_for()
+rng = np.random.default_rng(3)
+arrs = [rng.integers(0, 256, size=(4096, 8192, 3), dtype=np.uint8) for _ in range(6)]
+ts = []
+for a in arrs[:3]:
+    t0 = time.perf_counter(); nat.check(lib.pb_host_register(a.ctypes.data, a.nbytes)); t1 = time.perf_counter()
+    nat.check(lib.pb_memcpy_h2d(din.data_ptr(), a.ctypes.data, up, s1.handle)); s1.sync(); t2 = time.perf_counter()
+    nat.check(lib.pb_host_unregister(a.ctypes.data)); t3 = time.perf_counter()
+    ts.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+print("register / DMA / unregister of a fresh 100.7 MB ndarray (ms):", [tuple(round(x, 3) for x in t) for t in ts])
+ts = []
+for a in arrs[3:]:
+    t0 = time.perf_counter(); pipe.upload(a, din, s1); s1.sync(); ts.append((time.perf_counter() - t0) * 1e3)
+print("chunked staged upload of a fresh 100.7 MB ndarray (ms):", [round(x, 3) for x in ts])
+
+# ---- does page-locking wait for the device?  (register a fresh frame while a kernel stores over PCIe / while an upload DMA runs)
+more = [rng.integers(0, 256, size=(4096, 8192, 3), dtype=np.uint8) for _ in range(4)]
+for label, busy in (("idle", lambda: None), ("while the remap kernel stores into host memory", lambda: launch(s2)), ("while an upload DMA runs", lambda: h2d(s1))):
+    a = more.pop()
+    busy()
+    t0 = time.perf_counter(); nat.check(lib.pb_host_register(a.ctypes.data, a.nbytes)); t1 = time.perf_counter()
+    s1.sync(); s2.sync()
+    nat.check(lib.pb_host_unregister(a.ctypes.data))
+    print("register a fresh 100.7 MB ndarray, device %s: %.3f ms" % (label, (t1 - t0) * 1e3))

@@ -194,15 +194,20 @@ PINNED = _PinnedPool()
 
 
 class _Registrations:
-    """Page-locking of the CALLER's arrays (pb_host_register): an array whose memory is seen a second time - a capture buffer
-    the caller refills - is registered, and from then on its upload is ONE DMA straight out of the caller's memory.  The
+    """Page-locking of the CALLER's arrays (pb_host_register): a frame-sized array (>= FIRST_SIGHT_BYTES) at its FIRST sighting, a smaller
+    one when its memory is seen a second time (a capture buffer the caller refills) - from then on its upload is ONE DMA straight out of
+    the caller's memory.  (Round 6, measured on the MI355X box: page-locking a fresh 100.7 MB ndarray in place costs 0.21-0.35 ms and
+    releasing it 0.02 ms, against 0.7-1.5 ms more for the chunked copy through staging buffers - experiments/r6/pcie_paths.py.)  The
     registration is tied to the object that owns the memory (unregistered before that object frees it) and re-checked against
     the owner's address on every use; at most `max_count` buffers / `max_bytes` stay registered (least recently used first out).
     Memory we cannot tie to an owning ndarray (a view of something else) is never registered: it takes the staged copy."""
 
+    FIRST_SIGHT_BYTES = 32 << 20
+
     def __init__(self, max_count: int = 8, max_bytes: int = 4 << 30):
         self._seen = OrderedDict()  # (addr, nbytes) -> sightings
         self._reg = OrderedDict()   # addr -> (nbytes, weakref to owner)
+        self._late = {}             # addr -> owner: evicted, its release is queued on the worker thread
         self._lock = threading.Lock()
         self._max_count, self._max_bytes = max_count, max_bytes
 
@@ -213,14 +218,37 @@ class _Registrations:
             o = o.base
         return o if (o.base is None and o.flags.owndata) else None
 
-    def _drop(self, addr: int) -> None:
+    def _drop(self, addr: int, later: bool = False) -> None:
+        """Ends a registration.  later: an LRU eviction - the release (0.5-0.7 ms for a c2 frame when it follows DMAs, measured) runs on a
+        worker thread, which holds the owning array until it is through; a finaliser (the owner is going away) releases at once."""
         with self._lock:
             ent = self._reg.pop(addr, None)
-        if ent is not None:
-            try:
-                _lib().pb_host_unregister(addr)
-            except Exception:
-                pass
+        if ent is None:
+            return
+        own = ent[1]() if later else None
+        if own is not None:
+            with self._lock:
+                self._late[addr] = own  # (kept alive, and found by its finaliser-in-waiting, until the worker is through)
+            _WORKER.submit(self._release_later, addr)
+            return
+        self._release(addr)
+
+    @staticmethod
+    def _release(addr: int) -> None:
+        try:
+            _lib().pb_host_unregister(addr)
+        except Exception:
+            pass
+
+    def _release_later(self, addr: int) -> None:
+        self._release(addr)
+        with self._lock:
+            own = self._late.pop(addr, None)
+        del own  # (outside the lock: dropping the last reference runs the owner's finaliser, which takes it)
+
+    def settle(self) -> None:
+        """Waits for the releases queued by evictions (tests; before a buffer that was evicted is registered again)."""
+        _WORKER.submit(lambda: None).result()
 
     def is_registered(self, a: np.ndarray) -> bool:
         """True when `a`'s bytes lie inside a live registration (then a DMA may read them directly)."""
@@ -239,19 +267,23 @@ class _Registrations:
             self._seen.move_to_end(key)
             while len(self._seen) > 64:
                 self._seen.popitem(last=False)
-            again = self._seen[key] >= 2
+            again = self._seen[key] >= 2 or size >= self.FIRST_SIGHT_BYTES
         if ent is not None:  # same address, another object or size: the old registration is stale
             self._drop(base)
         if not again or size < (1 << 20):
             return False
-        # second sighting of this buffer: register it (make room first)
+        # a frame-sized buffer, or the second sighting of a smaller one: register it (make room first)
         while True:
             with self._lock:
                 total = sum(v[0] for v in self._reg.values())
                 victim = next(iter(self._reg)) if (len(self._reg) >= self._max_count or total + size > self._max_bytes) and self._reg else None
             if victim is None:
                 break
-            self._drop(victim)
+            self._drop(victim, later=True)
+        with self._lock:
+            pending = base in self._late
+        if pending:  # this very buffer was evicted a moment ago: its release must be through before it is registered again
+            self.settle()
         try:
             _check(_lib().pb_host_register(base, size))
         except Exception:
@@ -262,6 +294,7 @@ class _Registrations:
         return True
 
 
+_WORKER = __import__("concurrent.futures").futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="pb-host-release")
 REGISTERED = _Registrations()
 
 

@@ -4,10 +4,15 @@ ndarray out (core/__init__.py:66-92), so for a user who just swaps imports a rem
 What each direction costs and how it is kept down (measured on the MI355X box, c2 = 100.7 MB in, 50.3 MB out):
   download  the result ndarray IS page-locked memory from a recycling pool (``_device.PINNED``): the DMA writes it directly, no
             staging copy; the block returns to the pool when the caller drops the array.
-  upload    memory the caller owns is pageable.  An array seen for the SECOND time (a capture buffer that is refilled) is
-            page-locked in place (pb_host_register, tied to the owning object's lifetime) and from then on uploads with ONE DMA
-            straight out of the caller's memory.  Anything else is copied through page-locked staging buffers in 16 MiB chunks on
-            a few threads, each chunk's DMA running while the next chunk is being copied.
+  upload    memory the caller owns is pageable.  A frame-sized array (>= 32 MiB) is page-locked in place at its first sighting, a
+            smaller one at its second (pb_host_register, tied to the owning object's lifetime: 0.2-0.35 ms for a c2 frame), and
+            uploads with ONE DMA straight out of the caller's memory.  Anything else (views, small arrays seen once) is copied
+            through page-locked staging buffers in 16 MiB chunks on a few threads, each chunk's DMA running while the next chunk
+            is being copied.
+  streams   (remap_frames) the two DMA directions do not run at full rate side by side on this box (1.77 ms up + 0.89 ms down take
+            2.41 ms on two streams), but an upload DMA and a KERNEL that stores over PCIe do (2.06 ms): the remap kernel of frame k
+            writes its output straight into the page-locked result ndarray while frame k + 1 uploads - no device output buffer,
+            no download (experiments/r6/pcie_paths.py).
 No PyTorch anywhere in this module.
 """
 
@@ -118,31 +123,30 @@ def remap_ndarray(plan: nat.Plan, image: np.ndarray, interpolation: str = "neare
 
 
 def remap_frames(plan: nat.Plan, frames: Iterable[np.ndarray], depth: int = 3, interpolation: str = "nearest") -> Iterator[np.ndarray]:
-    """Streams host-resident frames through one plan: while frame k is being remapped on the compute stream, frame k + 1 uploads
-    on the H2D stream and frame k - 1 downloads on the D2H stream, through `depth` rotating device buffers.  Yields uint8
-    (H, W, 3) ndarrays in order (page-locked, recycled when dropped)."""
+    """Streams host-resident frames through one plan: while frame k + 1 uploads on the H2D stream, the remap kernel of frame k stores its
+    output over PCIe straight into frame k's result ndarray (page-locked, device-visible), through `depth` rotating device input
+    buffers.  Yields uint8 (H, W, 3) ndarrays in order (page-locked, recycled when dropped)."""
     nat.require_gpu()
     depth = max(2, int(depth))
     dev = nat.current_device()
     pipe = pipe_for(dev)
     sh = (plan.src.height, plan.src.width, 3)
     dh = (plan.dst.height, plan.dst.width, 3)
-    n_in, n_out = int(np.prod(sh)), int(np.prod(dh))
+    n_in = int(np.prod(sh))
     d_in = [DeviceArray((n_in,), np.uint8) for _ in range(depth)]
-    d_out = [DeviceArray((n_out,), np.uint8) for _ in range(depth)]
-    s_up, s_run, s_down = Stream(), Stream(), Stream()
+    s_up, s_run = Stream(), Stream()
     uploaded = [Event() for _ in range(depth)]
     computed = [Event() for _ in range(depth)]
-    downloaded = [Event() for _ in range(depth)]
     results = [None] * depth
-    pending: list = []  # slots whose download has been queued, oldest first
+    pending: list = []  # slots whose kernel has been queued, oldest first
 
     def drain_one():
         slot = pending.pop(0)
-        downloaded[slot].sync()
+        computed[slot].sync()  # (the kernel has completed: its stores into the host array are visible)
         out, results[slot] = results[slot], None
         return out
 
+    ahead = frames if isinstance(frames, (list, tuple)) else None
     k = 0
     for frame in frames:
         a = np.asarray(frame)
@@ -154,15 +158,17 @@ def remap_frames(plan: nat.Plan, frames: Iterable[np.ndarray], depth: int = 3, i
         # (the slot's previous remap has finished: its result was delivered, or is being waited for above)
         direct = pipe.upload(a, d_in[slot], s_up)
         uploaded[slot].record(s_up)
-        if direct:
-            uploaded[slot].sync()  # the DMA reads the caller's own buffer: it must be through before the caller refills it
         s_run.wait(uploaded[slot])
-        plan.launch(d_in[slot].data_ptr(), d_out[slot].data_ptr(), 1, s_run.handle, interpolation)
+        out = results[slot] = PINNED.ndarray(dh, np.uint8)
+        plan.launch(d_in[slot].data_ptr(), out.ctypes.data, 1, s_run.handle, interpolation)
         computed[slot].record(s_run)
-        s_down.wait(computed[slot])
-        results[slot] = pipe.download(d_out[slot], dh, np.uint8, s_down)
-        downloaded[slot].record(s_down)
         pending.append(slot)
+        if direct:
+            # frames that already exist (a list, a tuple): page-lock the NEXT one while this one's DMA runs (0.2-0.35 ms off the critical
+            # path; an iterator is never looked ahead into - it may refill the buffer the DMA is reading)
+            if ahead is not None and k + 1 < len(ahead) and isinstance(ahead[k + 1], np.ndarray):
+                REGISTERED.is_registered(ahead[k + 1])
+            uploaded[slot].sync()  # the DMA reads the caller's own buffer: it must be through before the caller refills it
         k += 1
     while pending:
         yield drain_one()

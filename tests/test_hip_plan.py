@@ -86,7 +86,7 @@ def test_every_small_case_has_consistent_plan_stats():
 
 
 def test_streaming_batch_overlaps_and_matches():
-    """batch.remap_frames (H2D / remap / D2H on three streams) == the per-frame facade, in order."""
+    """batch.remap_frames (upload DMA of frame k + 1 beside the remap of frame k into its page-locked result) == the per-frame facade, in order."""
     import photonbend_amd as pb
     from photonbend_amd import batch
     from oracle.synth import synth_frame
@@ -103,6 +103,32 @@ def test_streaming_batch_overlaps_and_matches():
         want = pb.PanoramaImage(f).process_coordinate_map(rot.rotate_coordinate_map(dst.get_coordinate_map()))
         assert np.array_equal(out, want)
     assert list(batch.remap_frames(plan, iter([]))) == []
+
+
+@pytest.mark.parametrize("name,interpolation", [("c2", "nearest"), ("c3", "nearest"), ("c5_195", "nearest"), ("c3", "bilinear"), ("c5_195", "bilinear")])
+def test_streamed_results_written_over_pcie_equal_the_device_results_at_full_size(name, interpolation):
+    """Round 6: batch.remap_frames has the remap kernel store straight into the page-locked result ndarray (no device output buffer, no
+    download DMA).  At BASELINE size - failed tiles, fix pixels re-stored by their tile's wave, the pair waves of the stitch, both
+    samplers - every streamed frame equals the same frame remapped into device memory, byte for byte; frame-sized inputs the library has
+    never seen are page-locked in place and uploaded with one DMA each."""
+    import torch
+
+    from photonbend_amd import _device, batch
+    from tests.cases import full_cases
+
+    case = next(c for c in full_cases() if c.name == name)
+    plan = H.pb_plan_private(case)
+    _, h, w, *_ = case.src
+    dev_frames = [nat.synth_frame(h, w, frame=40 + f, seed=2, circle_mask=case.mask) for f in range(3)]
+    host_frames = [f.cpu().numpy().copy() for f in dev_frames]  # fresh ndarrays that own their memory
+    before = len(_device.REGISTERED._reg)
+    got = list(batch.remap_frames(plan, iter(host_frames), depth=2, interpolation=interpolation))
+    assert len(got) == 3 and len(_device.REGISTERED._reg) >= min(before + 3, _device.REGISTERED._max_count) - 1
+    for f, out in zip(dev_frames, got):
+        want = plan.remap(f, interpolation=interpolation).cpu().numpy()
+        assert out.shape == want.shape and np.array_equal(out, want), f"{name} {interpolation}: {int((out != want).any(axis=2).sum())} pixels differ"
+    del got, host_frames
+    torch.cuda.empty_cache()
 
 
 CONCURRENT_CASES = [
