@@ -263,9 +263,10 @@ def byte_accounting(plan, src_hw, device):
     return out_bytes + 3 * int(valid.numel()), out_bytes + LINE * int(touched.sum().item())
 
 
-def measure_config(lib, nat, name, device, stream, steps=120, warmup=20, batch=0, pool_bytes=0, bilinear=False):
+def measure_config(lib, nat, name, device, stream, steps=200, warmup=20, batch=0, pool_bytes=0, bilinear=False):
     """One config measured like the headline, inside this process: its plan at the pinned budget, a pool of distinct frames
-    larger than the 256 MiB Infinity Cache, `steps` launches in groups of 4 between HIP event pairs on the launch stream.
+    larger than the 256 MiB Infinity Cache, `warmup` untimed and `steps` timed launches (SURVEY 8d's protocol: >= 20 and >= 200) in
+    groups of 4 between HIP event pairs on the launch stream.
     Returns the entry of the line's ``configs`` block."""
     import torch
 
@@ -1098,7 +1099,7 @@ def main():
             for name in ("c1", "c3", "c5", "c4shard", "c5shard"):
                 block[name] = measure_config(lib, nat, name, device, sts[0])
             for name in ("c1", "c2", "c3", "c5"):
-                block[name + "_bilinear"] = measure_config(lib, nat, name, device, sts[0], steps=60, warmup=8, bilinear=True)
+                block[name + "_bilinear"] = measure_config(lib, nat, name, device, sts[0], bilinear=True)
             line["configs"] = block
             line["flavours"] = flavours_block("c3")
             try:

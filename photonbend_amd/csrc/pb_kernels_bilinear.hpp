@@ -744,14 +744,28 @@ __device__ __forceinline__ void pb_bil_store(const unsigned v[16], uint8_t* __re
     }
 }
 
+// The launch table is laid out in VIRTUAL workgroups of four slots, virtual workgroup B on XCD B & 7 (pb_launch_table_kernel).  A REAL
+// workgroup is WAVES waves - FOUR (a whole virtual workgroup) or TWO (round 6), chosen per plan with its LDS pool (pb_build_bilinear_launch):
+// two-wave workgroups release their LDS and their wave slots in finer grain (a wave that has finished waits for one neighbour, not
+// three; the chip's last workgroups are half as long) and a pair of a stitch meets a barrier of its own - c2 50.2 -> 47.8 us, c5 78.5 ->
+// 77.2 - but pool their regions over two slots instead of four, which costs c1 its small pool (it keeps four waves).  Real workgroup w of
+// a frame runs on XCD w & 7 (round-robin dispatch: speed only) and takes part (w >> 3) % PARTS of that XCD's (w >> 3) / PARTS-th
+// virtual workgroup, PARTS = 4 / WAVES: a slot keeps the XCD the plan gave it.
+template <int WAVES>
+__device__ __forceinline__ unsigned pb_bil_slot_of(unsigned wg, unsigned wave) {
+    constexpr unsigned PARTS = 4u / (unsigned)WAVES;
+    const unsigned idx = wg >> 3, B = ((idx / PARTS) << 3) | (wg & 7u), part = idx % PARTS;
+    return B * 4u + part * (unsigned)WAVES + wave;
+}
+
 // One wave per tile, launched like pb_hot_win_kernel: `table` is the plan's LAUNCH-ORDER table (the entry says which tile it is),
 // frames of a batch are a grid dimension.  The tile's fix pixels - the model's truncation differs from the faithful one: mostly a
 // coordinate a hair from an integer, harmless here, but also the genuine discontinuities a polynomial cannot follow inside an
 // otherwise modelled tile (the edge of a lens inverse's domain, a validity or image boundary) - are redone from their exact
 // coordinates by the tile's wave after its stores, like the nearest mode's.  bil_xy == nullptr: the plan has no coordinate table
 // (it would not fit); tiles that need one, and the fix pixels, are then left to pb_bilinear_fix_kernel.
-template <int SRC_KIND>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_hot_kernel(const PbHot Hd, const PbTileEntry* __restrict__ table,
+template <int SRC_KIND, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, PB_BIL_WPE) void pb_bilinear_hot_kernel(const PbHot Hd, const PbTileEntry* __restrict__ table,
                                                                               const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                               const unsigned groups_per_frame, unsigned long long src_stride,
                                                                               unsigned long long dst_stride, int windows,
@@ -761,14 +775,14 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE) void pb_bilinear_ho
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned wg = blockIdx.x;
-    if (wg >= groups_per_frame) {  // a batch: which frame
+    if (wg >= groups_per_frame) {  // a batch: which frame (groups_per_frame: REAL workgroups per frame)
         const unsigned f = wg / groups_per_frame;
         wg -= f * groups_per_frame;
         src += (unsigned long long)f * src_stride;
         dst += (unsigned long long)f * dst_stride;
     }
     PbTileEntry entry;
-    const unsigned vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)(wg * (unsigned)PB_TILE_WAVES + (unsigned)wave));  // four waves per workgroup: the launch table's slot order
+    const unsigned vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)pb_bil_slot_of<WAVES>(wg, (unsigned)wave));
     pb_load_entry(table + vslot, entry);
     const PbTileEntry* __restrict__ e = &entry;
     const int flags = e->flags;
@@ -939,8 +953,8 @@ struct PbDblTables {
     const PbDoubleFix* px_fix;
 };
 #define PB_PAIR_HDR 1024  // dword offset of wave R's header in its region, behind its 64 x 16 packed pixels: fix_cnt, fix_off, aux_off
-template <int WMODE>
-__global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinear_double_hot_kernel(const PbHot Hd, const int eye_w, const PbTileEntry* __restrict__ ltable,
+template <int WMODE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, PB_BIL_WPE_DBL) void pb_bilinear_double_hot_kernel(const PbHot Hd, const int eye_w, const PbTileEntry* __restrict__ ltable,
                                                                                      const PbDblTables* __restrict__ X,
                                                                                      const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                                      const unsigned groups_per_frame, unsigned long long src_stride,
@@ -956,7 +970,7 @@ __global__ __launch_bounds__(64 * PB_TILE_WAVES, PB_BIL_WPE_DBL) void pb_bilinea
         src += (unsigned long long)f * src_stride;
         dst += (unsigned long long)f * dst_stride;
     }
-    const unsigned vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)(wg * (unsigned)PB_TILE_WAVES + (unsigned)wave));
+    const unsigned vslot = (unsigned)__builtin_amdgcn_readfirstlane((int)pb_bil_slot_of<WAVES>(wg, (unsigned)wave));
     PbTileEntry entry;
     pb_load_entry(ltable + vslot, entry);
     const int flags = entry.flags;
@@ -1203,43 +1217,73 @@ __device__ __forceinline__ unsigned pb_bil_region_bytes(const PbTileEntry& e, in
     }
     return need > floor_r ? need : floor_r;
 }
-__global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, unsigned n_groups, unsigned pool_bytes, int dry, unsigned* __restrict__ counters) {
-    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_groups) return;
+// Before the regions are packed: the four one-eye slots of a virtual workgroup are dealt to its two real workgroups so that their LDS needs
+// balance - (largest, smallest) and the two in between - instead of in tile order; pair slots stay where the pair layout put them.  One wave
+// per virtual workgroup (an entry is 64 dwords: one per lane).  Speed only: which wave of which workgroup serves a tile moves no bit.
+__global__ __launch_bounds__(64) void pb_bilinear_balance_kernel(PbTileEntry* __restrict__ ltable, unsigned n_groups) {
+    if (blockIdx.x >= n_groups) return;
+    PbTileEntry* slots = ltable + 4u * (size_t)blockIdx.x;
+    const int lane = threadIdx.x;
     unsigned need[4];
-    bool window[4];
+    bool pair = false;
     for (int w = 0; w < 4; ++w) {
-        const PbTileEntry& e = ltable[4u * g + w];
-        const int f = e.flags;
-        need[w] = pb_bil_region_bytes(e, f);
-        window[w] = !(f & PB_TILE_SKIP) && e.bil_off < 0 && (f & (PB_TILE_LEAN | PB_TILE_HALVES)) != 0;
+        need[w] = pb_bil_region_bytes(slots[w], slots[w].flags);
+        pair = pair || (slots[w].flags & (PB_TILE_TWO | PB_TILE_PAIR_R)) != 0;
+    }
+    if (pair) return;
+    int order[4] = {0, 1, 2, 3};  // by need, descending (a stable insertion sort: every lane computes the same)
+    for (int i = 1; i < 4; ++i)
+        for (int j = i; j > 0 && need[order[j]] > need[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    const int dest[4] = {order[0], order[3], order[1], order[2]};  // slots 0-1: largest + smallest, slots 2-3: the middle two
+    if (dest[0] == 0 && dest[1] == 1 && dest[2] == 2 && dest[3] == 3) return;
+    int v[4];
+    for (int w = 0; w < 4; ++w) v[w] = reinterpret_cast<const int*>(slots + dest[w])[lane];
+    for (int w = 0; w < 4; ++w) reinterpret_cast<int*>(slots + w)[lane] = v[w];  // (every lane holds its dword of all four entries: no hazard)
+}
+__global__ void pb_bilinear_pool_kernel(PbTileEntry* __restrict__ ltable, unsigned n_groups, unsigned pool_bytes, int dry, unsigned* __restrict__ counters,
+                                        int waves) {
+    // one thread per REAL workgroup: `waves` (4 or 2) consecutive slots of the table (a pair's L and R are neighbours: never split)
+    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups * (4u / (unsigned)waves)) return;
+    PbTileEntry* slots = ltable + (size_t)g * (unsigned)waves;
+    unsigned need[4] = {0u, 0u, 0u, 0u}, total = 0;
+    bool window[4] = {false, false, false, false};
+    for (int w = 0; w < waves; ++w) {
+        const int f = slots[w].flags;
+        need[w] = pb_bil_region_bytes(slots[w], f);
+        window[w] = !(f & PB_TILE_SKIP) && slots[w].bil_off < 0 && (f & (PB_TILE_LEAN | PB_TILE_HALVES)) != 0;
+        total += need[w];
     }
     unsigned demoted = 0;
-    for (;;) {
-        if (need[0] + need[1] + need[2] + need[3] <= pool_bytes) break;
+    while (total > pool_bytes) {
         // (half-window tiles first: they go back to the direct path they came from, and do not count against the pool)
         int big = -1;
         bool big_half = false;
-        for (int w = 0; w < 4; ++w) {
+        unsigned big_need = 0;
+        for (int w = 0; w < waves; ++w) {
             if (!window[w] || need[w] <= (unsigned)PB_DIRECT_LDS_BYTES + 16u) continue;
-            const bool half = (ltable[4u * g + w].flags & PB_TILE_HALVES) != 0;
-            if (big < 0 || (half && !big_half) || (half == big_half && need[w] > need[big])) { big = w; big_half = half; }
+            const bool half = (slots[w].flags & PB_TILE_HALVES) != 0;
+            if (big < 0 || (half && !big_half) || (half == big_half && need[w] > big_need)) { big = w; big_half = half; big_need = need[w]; }
         }
         if (big < 0) {
             atomicAdd(&counters[1], 1u);
             return;  // (the host falls back to the pool that always fits)
         }
-        need[big] = (unsigned)PB_DIRECT_LDS_BYTES + 16u;
-        window[big] = false;
-        if (!dry) ltable[4u * g + big].flags = (ltable[4u * g + big].flags & ~(PB_TILE_LEAN | PB_TILE_HALVES)) | PB_TILE_DIRECT;
+        for (int w = 0; w < waves; ++w)
+            if (w == big) {
+                total -= need[w] - ((unsigned)PB_DIRECT_LDS_BYTES + 16u);
+                need[w] = (unsigned)PB_DIRECT_LDS_BYTES + 16u;
+                window[w] = false;
+                if (!dry) slots[w].flags = (slots[w].flags & ~(PB_TILE_LEAN | PB_TILE_HALVES)) | PB_TILE_DIRECT;
+            }
         if (!big_half) ++demoted;
     }
     if (demoted) atomicAdd(&counters[0], demoted);
     if (dry) return;
     unsigned off = 0;
-    for (int w = 0; w < 4; ++w) {
-        ltable[4u * g + w].win_r0 = (int)off;
-        if (w > 0 && (ltable[4u * g + w].flags & PB_TILE_PAIR_R)) ltable[4u * g + w - 1].win_r0 |= (int)(off << 16);  // wave L's slot: where wave R parks its pixels
+    for (int w = 0; w < waves; ++w) {
+        slots[w].win_r0 = (int)off;
+        if (w > 0 && (slots[w].flags & PB_TILE_PAIR_R)) slots[w - 1].win_r0 |= (int)(off << 16);  // wave L's slot: where wave R parks its pixels
         off += need[w];
     }
 }

@@ -85,6 +85,7 @@ struct pb_plan {
     unsigned launch_groups_bil = 0;
     int bil_budget = 0;
     PbDblTables* bil_dbl_tables = nullptr;  // double-fisheye plans: what only some waves of the bilinear launch need, behind one pointer (pb_kernels_bilinear.hpp)
+    int bil_waves = 4;            // waves per REAL workgroup of a bilinear launch (4 or 2: chosen with the pool, pb_build_bilinear_launch)
     unsigned bil_pool_bytes = 0;  // dynamic LDS of a bilinear launch's workgroup: the slots' regions are packed into it (pb_bilinear_pool_kernel)
     PbParams* P_dev = nullptr;   // device copy of P as the hot launches see it (refreshed with every budget change)
     unsigned launch_groups = 0;  // virtual workgroups (of four waves) per frame, a multiple of 8
@@ -873,7 +874,7 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
 // table (the bilinear launches then take the float64 kernels), never with a stale one.  Synchronous.
 #define PB_BIL_WIN_BUDGET PB_WINLDS_MAX
 #ifndef PB_BIL_POOL_SMALL
-#define PB_BIL_POOL_SMALL 40448u  // the bilinear workgroups' small LDS pool: four of them per CU (160 KiB of LDS)
+#define PB_BIL_POOL_SMALL 40448u  // a four-wave bilinear workgroup's small LDS pool: four of them, sixteen waves, per CU (160 KiB of LDS); two waves: half
 #endif
 //  // measured on MI355X (experiments/r4/budget_bil.sh): c1 28.7 us at 7 KiB, 25.2 at 12; c2 68.9 / 62.0; c5 109.8 / 103.4; c3 58.3 / 58.9
 static int pb_build_bilinear_launch(pb_plan* pl) {
@@ -885,12 +886,13 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     int rc = pb_classify_under_budget(pl, pl->bil_budget, nullptr);
     if (rc == PB_OK) rc = pb_build_launch_table(pl, true);
     if (rc != PB_OK) return rc;
-    // the workgroups' LDS pool: four workgroups per CU where the slots' real regions allow it (few demotions), else the round-4 size
-    // (four full-budget regions: always fits, three workgroups per CU)
-    const unsigned full = 4u * ((unsigned)pl->bil_budget + 32u), small = PB_BIL_POOL_SMALL;
+    // Workgroup size and LDS pool, chosen together (a pool is accepted when at most 2 % of the tiles lose their window to it), best first:
+    //   two waves, 19.75 KiB   sixteen waves per CU (four per SIMD: what the tile code's 117-120 VGPRs allow) in eight workgroups
+    //   four waves, 39.5 KiB   sixteen waves in four workgroups: regions pooled over four slots fit where two slots do not (c1)
+    //   two waves, 22.8 KiB    fourteen waves per CU
+    //   two waves, 2 x budget  always fits: twelve waves per CU
     unsigned* counters = nullptr;
     const unsigned ng = pl->launch_groups_bil;
-    const dim3 grid((ng + 127) / 128), block(128);
     unsigned res[2] = {0u, 0u};
     hipError_t e = pb_tmp_alloc((void**)&counters, 4 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
@@ -899,15 +901,33 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
         hipLaunchKernelGGL(pb_bilinear_halves_kernel, dim3(ng), dim3(256), 0, 0, pl->ltable_bil, 4u * ng, pl->bil_budget, pl->P.src.height, pl->P.src.width,
                            pb_bil_off(8) ? 1 : 0, counters);
     }
-    unsigned pool = full;
-    if (e == hipSuccess && small < full && !pb_bil_off(16)) {
-        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, ng, small, 1, counters);
-        e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && res[1] == 0u && res[0] * 50u <= pl->n_tiles) pool = small;  // (at most 2 % of the tiles lose their window)
+    const unsigned budget32 = (unsigned)pl->bil_budget + 32u;
+    int waves = 2;
+    unsigned pool = 2u * budget32;
+    if (e == hipSuccess && !pb_bil_off(16)) {
+        // (the one-eye slots of a virtual workgroup dealt to its two halves so that their LDS needs balance: largest with smallest)
+        hipLaunchKernelGGL(pb_bilinear_balance_kernel, dim3(ng), dim3(64), 0, 0, pl->ltable_bil, ng);
+        const struct { int waves; unsigned bytes; } tiers[3] = {{2, PB_BIL_POOL_SMALL / 2u}, {4, PB_BIL_POOL_SMALL}, {2, (163840u / 7u) & ~15u}};
+        for (int t = 0; t < 3 && e == hipSuccess; ++t) {
+            if (tiers[t].bytes >= (unsigned)tiers[t].waves * budget32) continue;
+            e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(pb_bilinear_pool_kernel, dim3((ng * (4u / (unsigned)tiers[t].waves) + 127) / 128), dim3(128), 0, 0, pl->ltable_bil, ng, tiers[t].bytes, 1, counters,
+                               tiers[t].waves);
+            e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
+            if (e == hipSuccess && res[1] == 0u && res[0] * 50u <= pl->n_tiles) {
+                waves = tiers[t].waves;
+                pool = tiers[t].bytes;
+                break;
+            }
+        }
+    } else {
+        waves = 4;  // (the diagnostic build's "no small pool": round 4's shape)
+        pool = 4u * budget32;
     }
     if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(pb_bilinear_pool_kernel, grid, block, 0, 0, pl->ltable_bil, ng, pool, 0, counters);
+        hipLaunchKernelGGL(pb_bilinear_pool_kernel, dim3((ng * (4u / (unsigned)waves) + 127) / 128), dim3(128), 0, 0, pl->ltable_bil, ng, pool, 0, counters, waves);
         e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
     }
     if (e != hipSuccess) (void)hipDeviceSynchronize();
@@ -930,6 +950,7 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
         }
     }
     pl->bil_pool_bytes = pool;
+    pl->bil_waves = waves;
     return PB_OK;
 }
 
@@ -1270,7 +1291,7 @@ int pb_plan_bilinear_launch_shape(const pb_plan* plan, int* lds_bytes, int* work
     if (!plan || !lds_bytes || !workgroups_per_frame) return pb_fail(PB_ERR_INVALID, "null argument");
     const bool tiles = (plan->fast_ready || plan->dbl_ready) && plan->ltable_bil && plan->launch_groups_bil > 0;
     *lds_bytes = tiles ? (int)plan->bil_pool_bytes : 0;
-    *workgroups_per_frame = tiles ? (int)plan->launch_groups_bil : 0;
+    *workgroups_per_frame = tiles ? (int)(plan->launch_groups_bil * (4u / (unsigned)plan->bil_waves)) : 0;
     return PB_OK;
 }
 int pb_plan_window_budget(const pb_plan* plan) {
@@ -1436,7 +1457,7 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
     if (P.src.kind == PB_KIND_DOUBLE) {
         if (plan->dbl_ready && plan->ltable_bil && plan->launch_groups_bil > 0 && plan->bil_tiles && plan->bil_dbl_tables && plan->mode != PB_MODE_FAITHFUL) {
             // the per-eye tile models of the nearest mode's plan + the exact coordinate tables: one wave per tile, ONE launch
-            const unsigned gpf = plan->launch_groups_bil;
+            const unsigned gpf = plan->launch_groups_bil * (4u / (unsigned)plan->bil_waves);  // real workgroups per frame
             PbHot Hb = pb_hot_of_host(P);  // (the bilinear mode's window budget travels in it)
             Hb.win_budget = plan->bil_budget;
             const int windows = plan->mode != PB_MODE_FAST_DIRECT && ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
@@ -1444,11 +1465,15 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
             const int per_launch = (int)(0x7FFFFFFFu / gpf);
             for (int f0 = 0; f0 < n_frames; f0 += per_launch) {
                 const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;
-                const dim3 grid(gpf * (unsigned)nf), block(64 * PB_TILE_WAVES);
+                const dim3 grid(gpf * (unsigned)nf), block(64 * plan->bil_waves);
                 const uint8_t* sf = src_dev + (unsigned long long)f0 * src_frame_stride;
                 uint8_t* df = dst_dev + (unsigned long long)f0 * dst_frame_stride;
 #define PB_LAUNCH_BILINEAR_DOUBLE(WMODE)                                                                                                       \
-    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE>), grid, block, (size_t)plan->bil_pool_bytes, st, Hb, P.src_eye_w, plan->ltable_bil, plan->bil_dbl_tables, \
+    if (plan->bil_waves == 2)                                                                                                                  \
+        hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE, 2>), grid, block, (size_t)plan->bil_pool_bytes, st, Hb, P.src_eye_w, plan->ltable_bil, plan->bil_dbl_tables, \
+                           sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy);    \
+    else                                                                                                                                       \
+    hipLaunchKernelGGL((pb_bilinear_double_hot_kernel<WMODE, 4>), grid, block, (size_t)plan->bil_pool_bytes, st, Hb, P.src_eye_w, plan->ltable_bil, plan->bil_dbl_tables, \
                        sf, df, gpf, (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy)
                 if (rows) PB_LAUNCH_BILINEAR_DOUBLE(1);
                 else if (plan->n_lat_tiles) PB_LAUNCH_BILINEAR_DOUBLE(2);
@@ -1472,10 +1497,10 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
     if (pb_use_fast(plan) && plan->ltable_bil && plan->launch_groups_bil > 0 && plan->bil_tiles) {
         // launched like the nearest hot kernel: the mode's launch-order table, frames of a batch as a grid dimension, ONE launch;
         // LEAN tiles take their taps from LDS windows, except for frames LDS-DMA cannot address (not 16-byte aligned)
-        const unsigned gpf = plan->launch_groups_bil;
+        const unsigned gpf = plan->launch_groups_bil * (4u / (unsigned)plan->bil_waves);  // real workgroups per frame
         PbParams Pb = P;
         Pb.win_budget = plan->bil_budget;
-        const dim3 block(64 * PB_TILE_WAVES);
+        const dim3 block(64 * plan->bil_waves);
         const int windows = plan->mode != PB_MODE_FAST_DIRECT && P.src.width < 32768 && P.src.height < 32768 &&
                             ((((uintptr_t)src_dev) | src_frame_stride) & 15u) == 0;
         const int per_launch = (int)(0x7FFFFFFFu / gpf);
@@ -1483,7 +1508,13 @@ int pb_remap_bilinear_u8(const pb_plan* plan, const uint8_t* src_dev, uint8_t* d
     do {                                                                                                                             \
         for (int f0 = 0; f0 < n_frames; f0 += per_launch) {                                                                          \
             const int nf = n_frames - f0 < per_launch ? n_frames - f0 : per_launch;                                                  \
-            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND>), dim3(gpf * (unsigned)nf), block, (size_t)plan->bil_pool_bytes, st, pb_hot_of_host(Pb), plan->ltable_bil, \
+            if (plan->bil_waves == 2)                                                                                                \
+                hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, 2>), dim3(gpf * (unsigned)nf), block, (size_t)plan->bil_pool_bytes, st, pb_hot_of_host(Pb), plan->ltable_bil, \
+                                   src_dev + (unsigned long long)f0 * src_frame_stride, dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, \
+                                   (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy, plan->fix_px, \
+                                   plan->bil_fix_xy);                                                                                \
+            else                                                                                                                     \
+            hipLaunchKernelGGL((pb_bilinear_hot_kernel<KIND, 4>), dim3(gpf * (unsigned)nf), block, (size_t)plan->bil_pool_bytes, st, pb_hot_of_host(Pb), plan->ltable_bil, \
                                src_dev + (unsigned long long)f0 * src_frame_stride, dst_dev + (unsigned long long)f0 * dst_frame_stride, gpf, \
                                (unsigned long long)src_frame_stride, (unsigned long long)dst_frame_stride, windows, plan->bil_xy, plan->fix_px, \
                                plan->bil_fix_xy);                                                                                    \

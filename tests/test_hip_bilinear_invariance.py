@@ -63,7 +63,7 @@ def test_speed_only_features_do_not_move_a_bit(tmp_path):
     # the features were really exercised in one run and really absent in the other
     assert sum(r["mix"]["half_windows"] for r in on.values()) > 1000 and sum(r["mix"]["table_plain"] for r in on.values()) > 1000
     assert sum(r["mix"]["half_windows"] for r in off.values()) == 0 and sum(r["mix"]["table_plain"] for r in off.values()) == 0
-    assert any(r["shape"]["lds_bytes"] == 40448 for r in on.values()) and all(r["shape"]["lds_bytes"] != 40448 for r in off.values())  # (the small LDS pool)
+    assert any(r["shape"]["lds_bytes"] in (40448, 20224, 23392) for r in on.values()) and all(r["shape"]["lds_bytes"] not in (40448, 20224, 23392) for r in off.values())  # (the small LDS pool)
     for name in ("c2", "c3"):
         assert on[name]["mix"]["half_windows"] > 0 and on[name]["mix"]["window"] > off[name]["mix"]["window"], (name, on[name]["mix"], off[name]["mix"])
 
