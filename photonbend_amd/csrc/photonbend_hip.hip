@@ -873,6 +873,7 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
 // the tile tables' flags under THAT budget: pb_apply_budget (the nearest mode's) must follow.  A failure leaves the plan without the
 // table (the bilinear launches then take the float64 kernels), never with a stale one.  Synchronous.
 #define PB_BIL_WIN_BUDGET PB_WINLDS_MAX
+#define PB_BIL_POOL_RULE 50u  // a pool is accepted when at most 1 / PB_BIL_POOL_RULE of the tiles lose their window to it
 #ifndef PB_BIL_POOL_SMALL
 #define PB_BIL_POOL_SMALL 40448u  // a four-wave bilinear workgroup's small LDS pool: four of them, sixteen waves, per CU (160 KiB of LDS); two waves: half
 #endif
@@ -915,7 +916,7 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
             hipLaunchKernelGGL(pb_bilinear_pool_kernel, dim3((ng * (4u / (unsigned)tiers[t].waves) + 127) / 128), dim3(128), 0, 0, pl->ltable_bil, ng, tiers[t].bytes, 1, counters,
                                tiers[t].waves);
             e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
-            if (e == hipSuccess && res[1] == 0u && res[0] * 50u <= pl->n_tiles) {
+            if (e == hipSuccess && res[1] == 0u && res[0] * PB_BIL_POOL_RULE <= pl->n_tiles) {
                 waves = tiers[t].waves;
                 pool = tiers[t].bytes;
                 break;
