@@ -128,10 +128,18 @@ void pb_plan_destroy(pb_plan* plan);
  * have: pb_plan_create_ex returns PB_ERR_UNSUPPORTED from the library of the other flavour instead of silently giving other bits. */
 #define PB_PLAN_MATH_SVML 4u
 #define PB_PLAN_MATH_LIBM 8u
+/* THE OPT-IN BILINEAR MODE'S TABLES (flag values added in round 6; ABI 5 unchanged).  A prepared plan carries, besides what the reference's
+ * nearest sampler needs, the opt-in bilinear mode's state (exact coordinate tables, its own launch table and LDS pool: 0.2-0.3 ms of a
+ * c2 plan's 0.85 ms).  PB_PLAN_NO_BILINEAR (pb_plan_create_ex) leaves it out - for callers of pb_remap_u8, the reference's path;
+ * PB_PLAN_BILINEAR (pb_plan_prepare, synchronous, no launch of the plan in flight) builds it later.  pb_remap_bilinear_u8 on a plan
+ * without it is still correct - it runs the mode's per-pixel float64 kernels, several times slower - and pb_plan_bilinear_float64_tiles
+ * says so (every tile).  A deferred plan (PB_PLAN_DEFER) remembers either choice for its preparation.  Default (neither flag): as before. */
+#define PB_PLAN_NO_BILINEAR 16u
+#define PB_PLAN_BILINEAR 32u
 int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const pb_proj* src, unsigned flags,
                       int win_budget, pb_plan** out);
-/* Builds the fast path of a deferred plan on the current device (flags: 0 or PB_PLAN_TUNE).  On a prepared plan
- * it only applies win_budget (when > 0).  Synchronous. */
+/* Builds the fast path of a deferred plan on the current device (flags: 0, PB_PLAN_TUNE, PB_PLAN_BILINEAR).  On a prepared plan
+ * it applies win_budget (when > 0) and, with PB_PLAN_BILINEAR, builds the bilinear mode's tables if the plan lacks them.  Synchronous. */
 int pb_plan_prepare(pb_plan* plan, unsigned flags, int win_budget);
 /* Re-classifies the tiles of a prepared plan under another window budget (synchronous, cheap: one small kernel). */
 int pb_plan_set_window_budget(pb_plan* plan, int win_budget);

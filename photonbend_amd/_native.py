@@ -51,7 +51,7 @@ LIB_PATH = os.environ.get("PB_LIB_PATH") or (_build.LIBM_LIB_PATH if MATH_FLAVOU
 
 ABI_VERSION = 5
 PB_MAX_ROTATIONS = 8
-PLAN_DEFER, PLAN_TUNE, PLAN_MATH_SVML, PLAN_MATH_LIBM = 1, 2, 4, 8
+PLAN_DEFER, PLAN_TUNE, PLAN_MATH_SVML, PLAN_MATH_LIBM, PLAN_NO_BILINEAR, PLAN_BILINEAR = 1, 2, 4, 8, 16, 32
 MODE_AUTO, MODE_FAITHFUL, MODE_FAST, MODE_FAST_DIRECT = 0, 1, 2, 3
 KIND_CAMERA, KIND_DOUBLE, KIND_PANO = 0, 1, 2
 LENS_IDS = {
@@ -299,20 +299,23 @@ def _on(x):
 class Plan:
     """Owner of one pb_plan (dst projection, rotations, src projection)."""
 
-    def __init__(self, dst: pb_proj, rotations, src: pb_proj, *, defer: bool = False, tune: bool = False, budget: int = 0):
+    def __init__(self, dst: pb_proj, rotations, src: pb_proj, *, defer: bool = False, tune: bool = False, budget: int = 0, bilinear: bool = False):
         """``defer``: no device work now - launches run the faithful kernel until ``prepare()``;
         ``tune``: pick the LDS window budget by timing (opt-in, allocates scratch frames);
-        ``budget``: explicit window budget in bytes (0 = library default)."""
+        ``budget``: explicit window budget in bytes (0 = library default);
+        ``bilinear``: build the opt-in bilinear mode's tables now (0.2-0.3 ms of a c2 plan's 0.85) instead of at the first bilinear use
+        (``ensure_bilinear``, called by ``remap`` / ``launch`` / the mode's diagnostics)."""
         lib = load()
         rots = np.ascontiguousarray(np.asarray(list(rotations), dtype=np.float64).reshape(-1, 9))
         if rots.shape[0] > PB_MAX_ROTATIONS:
             raise PbError(f"at most {PB_MAX_ROTATIONS} chained rotations are supported")
         self._h = _VP()
         rp = rots.ctypes.data_as(C.POINTER(C.c_double)) if rots.shape[0] else None
-        flags = (PLAN_DEFER if defer else 0) | (PLAN_TUNE if tune else 0)
+        flags = (PLAN_DEFER if defer else 0) | (PLAN_TUNE if tune else 0) | (0 if bilinear else PLAN_NO_BILINEAR)
         check(lib.pb_plan_create_ex(C.byref(dst), rp, rots.shape[0], C.byref(src), flags, int(budget), C.byref(self._h)))
         self.dst, self.src, self.n_rot = dst, src, rots.shape[0]
         self.double_src = src.kind == KIND_DOUBLE
+        self._bilinear, self._deferred, self._bil_lock = bool(bilinear), bool(defer), threading.Lock()
 
     @classmethod
     def _adopt(cls, handle, dst: pb_proj, src: pb_proj, n_rot: int) -> "Plan":
@@ -320,11 +323,25 @@ class Plan:
         self._h = handle
         self.dst, self.src, self.n_rot = dst, src, n_rot
         self.double_src = src.kind == KIND_DOUBLE
+        self._bilinear, self._deferred, self._bil_lock = True, False, threading.Lock()  # (a restored plan rebuilds the mode's tables with everything else)
         return self
 
     def prepare(self, tune: bool = False, budget: int = 0) -> None:
         """Builds the fast path of a deferred plan on the current device (or re-applies ``budget``)."""
-        check(load().pb_plan_prepare(self._h, PLAN_TUNE if tune else 0, int(budget)))
+        check(load().pb_plan_prepare(self._h, (PLAN_TUNE if tune else 0) | (PLAN_BILINEAR if self._bilinear else 0), int(budget)))
+        self._deferred = False
+
+    def ensure_bilinear(self) -> None:
+        """The opt-in bilinear mode's tables, built once when the mode is first used (synchronous; no launch of this plan may be in
+        flight on another stream, as for ``set_window_budget``).  A deferred plan stays deferred - its launches run the float64
+        kernels of either mode - and remembers the wish for ``prepare()``."""
+        if self._bilinear:
+            return
+        with self._bil_lock:
+            if not self._bilinear:
+                if not self._deferred:
+                    check(load().pb_plan_prepare(self._h, PLAN_BILINEAR, 0))
+                self._bilinear = True
 
     def set_window_budget(self, budget: int) -> None:
         check(load().pb_plan_set_window_budget(self._h, int(budget)))
@@ -388,12 +405,14 @@ class Plan:
 
     def bilinear_launch_shape(self) -> dict:
         """The bilinear launch's workgroup LDS (bytes) and workgroups per frame - diagnostic."""
+        self.ensure_bilinear()
         lds, wgs = C.c_int(), C.c_int()
         check(load().pb_plan_bilinear_launch_shape(self._h, C.byref(lds), C.byref(wgs)))
         return {"lds_bytes": lds.value, "workgroups": wgs.value}
 
     def bilinear_tile_mix(self) -> dict:
         """How the opt-in bilinear mode serves the plan's tiles (diagnostic, synchronous)."""
+        self.ensure_bilinear()
         m = (C.c_longlong * 8)()
         check(load().pb_plan_bilinear_tile_mix(self._h, m))
         return dict(zip(("window", "direct", "table", "black", "td3", "entries", "half_windows", "table_plain"), (int(x) for x in m)))
@@ -407,6 +426,8 @@ class Plan:
     def launch(self, src_ptr: int, dst_ptr: int, n_frames: int = 1, stream: int | None = None, interpolation: str = "nearest",
                src_stride: int = 0, dst_stride: int = 0) -> None:
         """The raw call: n_frames frames at src_ptr / dst_ptr (device addresses, strides in bytes, 0 = packed) on `stream`."""
+        if interpolation != "nearest":
+            self.ensure_bilinear()
         fn = load().pb_remap_u8 if interpolation == "nearest" else load().pb_remap_bilinear_u8
         check(fn(self._h, src_ptr, dst_ptr, int(n_frames), int(src_stride), int(dst_stride), current_stream() if stream is None else stream))
 

@@ -85,6 +85,7 @@ struct pb_plan {
     unsigned launch_groups_bil = 0;
     int bil_budget = 0;
     PbDblTables* bil_dbl_tables = nullptr;  // double-fisheye plans: what only some waves of the bilinear launch need, behind one pointer (pb_kernels_bilinear.hpp)
+    int bil_wanted = 1;           // 0: created with PB_PLAN_NO_BILINEAR - the opt-in mode's tables are built when pb_plan_prepare(PB_PLAN_BILINEAR) asks for them
     int bil_waves = 4;            // waves per REAL workgroup of a bilinear launch (4 or 2: chosen with the pool, pb_build_bilinear_launch)
     unsigned bil_pool_bytes = 0;  // dynamic LDS of a bilinear launch's workgroup: the slots' regions are packed into it (pb_bilinear_pool_kernel)
     PbParams* P_dev = nullptr;   // device copy of P as the hot launches see it (refreshed with every budget change)
@@ -481,7 +482,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             pl->n_fix_px = res[0] > cap ? cap : res[0];
             pl->n_fail_tiles = res[1];
             pl->diff_pixels = res[2];
-            if (pb_build_bilinear_list(pl) != PB_OK) { rc = PB_ERR_HIP; break; }
+            if (pl->bil_wanted && pb_build_bilinear_list(pl) != PB_OK) { rc = PB_ERR_HIP; break; }
             pl->dbl_ready = 1;
             break;
         }
@@ -535,7 +536,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                 if (hipDeviceSynchronize() != hipSuccess) { rc = PB_ERR_HIP; break; }
             }
         }
-        if (pb_build_bilinear_list(pl) != PB_OK) { rc = PB_ERR_HIP; break; }
+        if (pl->bil_wanted && pb_build_bilinear_list(pl) != PB_OK) { rc = PB_ERR_HIP; break; }
         pl->fast_ready = 1;
     } while (0);
     if (rc != PB_OK) {
@@ -1095,7 +1096,19 @@ static double pb_now_ms() {
 // the default for experiments); PB_PLAN_TUNE times candidates instead
 static int pb_plan_prepare_full(pb_plan* pl, unsigned flags, int win_budget) {
     if (pl->fast_ready || pl->dbl_ready || pl->sep_ready || pl->device >= 0) {
-        // already prepared: only the budget may change
+        // already prepared: the budget may change, and the opt-in bilinear mode's tables may be asked for (PB_PLAN_BILINEAR) by a plan
+        // that was created without them
+        if ((flags & PB_PLAN_BILINEAR) && (pl->fast_ready || pl->dbl_ready) && !pl->bil_tiles) {
+            pl->bil_wanted = 1;
+            int rc = pb_build_bilinear_list(pl);
+            if (rc == PB_OK) rc = pb_build_bilinear_launch(pl);
+            // (pb_build_bilinear_launch leaves the tile flags under the MODE's budget: the nearest mode's classification follows)
+            const int rc2 = pb_apply_budget(pl, win_budget > 0 ? win_budget : pl->P.win_budget);
+            if (rc != PB_OK) return rc;
+            if (rc2 != PB_OK) return rc2;
+            PB_HIP(hipDeviceSynchronize());
+            return PB_OK;
+        }
         if (win_budget > 0) return pb_apply_budget(pl, win_budget);
         return PB_OK;
     }
@@ -1108,7 +1121,7 @@ static int pb_plan_prepare_full(pb_plan* pl, unsigned flags, int win_budget) {
     }
     int budget = win_budget > 0 ? win_budget : PB_DEFAULT_WIN_BUDGET;
     if (win_budget <= 0 && pb_knob("PB_WIN_BUDGET", 0) > 0) budget = pb_knob("PB_WIN_BUDGET", 0);
-    rc = pb_build_bilinear_launch(pl);
+    if (pl->bil_wanted) rc = pb_build_bilinear_launch(pl);
     if (rc != PB_OK) return rc;
     rc = pb_apply_budget(pl, budget);
     if (rc != PB_OK) return rc;
@@ -1156,7 +1169,7 @@ int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const
     if (!pb_end_ok(dst, why, PB_ROLE_DST) || !pb_end_ok(src, why, PB_ROLE_SRC)) return pb_fail(PB_ERR_INVALID, why);
     if (n_rot < 0 || n_rot > PB_MAX_ROTATIONS) return pb_fail(PB_ERR_INVALID, "n_rot outside [0, PB_MAX_ROTATIONS]");
     if (n_rot > 0 && !rot3x3) return pb_fail(PB_ERR_INVALID, "null rotation matrices");
-    if (flags & ~(unsigned)(PB_PLAN_DEFER | PB_PLAN_TUNE | PB_PLAN_MATH_SVML | PB_PLAN_MATH_LIBM)) return pb_fail(PB_ERR_INVALID, "unknown plan flags");
+    if (flags & ~(unsigned)(PB_PLAN_DEFER | PB_PLAN_TUNE | PB_PLAN_MATH_SVML | PB_PLAN_MATH_LIBM | PB_PLAN_NO_BILINEAR)) return pb_fail(PB_ERR_INVALID, "unknown plan flags");
     if ((flags & PB_PLAN_MATH_SVML) && (flags & PB_PLAN_MATH_LIBM)) return pb_fail(PB_ERR_INVALID, "a plan has one math flavour");
     if (((flags & PB_PLAN_MATH_SVML) && PB_MATH_FLAVOUR != 0) || ((flags & PB_PLAN_MATH_LIBM) && PB_MATH_FLAVOUR != 1))
         return pb_fail(PB_ERR_UNSUPPORTED, PB_MATH_FLAVOUR ? "this is libphotonbend_hip_libm.so (the float64 chain runs glibc's asin / acos / atan / tan): load libphotonbend_hip.so for the AVX-512 (SVML) flavour"
@@ -1170,6 +1183,7 @@ int pb_plan_create_ex(const pb_proj* dst, const double* rot3x3, int n_rot, const
     pl->P.exp_flags = PB_DEFAULT_EXP;
     pl->P.exp_flags = pb_knob("PB_EXP", PB_DEFAULT_EXP);
     pl->mode = PB_MODE_AUTO;
+    pl->bil_wanted = (flags & PB_PLAN_NO_BILINEAR) ? 0 : 1;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
     (void)hipGetLastError();
@@ -1200,8 +1214,9 @@ int pb_plan_create(const pb_proj* dst, const double* rot3x3, int n_rot, const pb
 
 int pb_plan_prepare(pb_plan* plan, unsigned flags, int win_budget) {
     if (!plan) return pb_fail(PB_ERR_INVALID, "null argument");
-    if (flags & ~(unsigned)PB_PLAN_TUNE) return pb_fail(PB_ERR_INVALID, "unknown plan flags");
+    if (flags & ~(unsigned)(PB_PLAN_TUNE | PB_PLAN_BILINEAR)) return pb_fail(PB_ERR_INVALID, "unknown plan flags");
     if (win_budget < 0) return pb_fail(PB_ERR_INVALID, "negative window budget");
+    if (flags & PB_PLAN_BILINEAR) plan->bil_wanted = 1;  // (a deferred plan: its preparation now includes the mode's tables)
     if (plan->device >= 0) {
         int dev = -1;
         PB_HIP(hipGetDevice(&dev));
@@ -1260,6 +1275,7 @@ int pb_plan_dst_shape(const pb_plan* plan, int* height, int* width) {
 }
 int pb_plan_bilinear_float64_tiles(const pb_plan* plan) {
     if (!plan || !(plan->fast_ready || plan->dbl_ready)) return 0;
+    if (!plan->bil_tiles) return (int)plan->n_tiles;  // (created with PB_PLAN_NO_BILINEAR and not asked since: pb_remap_bilinear_u8 runs the per-pixel float64 kernels)
     if (plan->bil_xy) return 0;  // every tile the models cannot serve has its exact coordinates in the plan's table
     return (int)(plan->n_fail_tiles + (plan->bil_tiles ? plan->n_bil_tiles : 0u));
 }

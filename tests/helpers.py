@@ -143,4 +143,5 @@ def pb_plan_private(case: Case, **kw):
     from photonbend_amd import _native as nat
 
     src, cmap = pb_chain(case, image=np.zeros((case.src[1], case.src[2], 3), np.uint8))
+    kw.setdefault("bilinear", True)  # (most private plans are the bilinear tests': the mode's tables at creation, as the C ABI's default does)
     return nat.Plan(cmap.dst_proj, cmap.rotations, src._proj(), **kw)
