@@ -217,8 +217,10 @@ def test_bilinear_tiles_on_noise_frames(case):
     pixel of offset), on sixteen random geometries of 70-1000 px (small images: 32-px tiles span tens of degrees).  Round 3:
     certification measures each tile model against the faithful pre-truncation coordinate and the bilinear kernels leave tiles beyond
     1/1024 px (PB_TILE_COARSE) to exact coordinates.  Round 5: against the per-pixel DEFINITION kernel (pb_sample_map_bilinear_u8, equal
-    to oracle.remap_bilinear to the bit) - single sources: no pixel beyond 1 LSB; double-fisheye sources: two eye samples of +-1 LSB
-    blended and truncated like the reference's can land 2 LSB off (measured: 9 pixels of 5.4 million), never more.  The float64-mode
+    to oracle.remap_bilinear to the bit) - single sources: no pixel beyond 1 LSB; double-fisheye sources: where BOTH eyes are sampled (the merge band,
+    and the corners of the eyes' squares beyond it, where the factors are both 1.0) the definition adds two samples it has rounded to
+    integers, each of ours may be the neighbouring integer, and the sum can land 2 LSB off - at the square of the one-eye rate (these
+    sixteen geometries: at most 1 pixel in 50 000; experiments/r6/two_lsb_probe.py), never more.  The float64-mode
     kernel of the same plan (MODE_FAITHFUL) stays within 1 LSB of the definition everywhere."""
     plan = H.pb_plan_private(case)
     info = plan.info()
