@@ -296,6 +296,41 @@ def _on(x):
     return on_device(device_index_of(x))
 
 
+class _LaunchGate:
+    """Launches of one plan (any number at a time) against the one rebuild of its tables a plan made for the reference's sampler may see -
+    the opt-in bilinear mode's first use, on whichever thread of the host's plan cache that happens.  The C ABI's rule for
+    pb_plan_prepare on a prepared plan is the caller's: no launch of the plan in flight or started during the call."""
+
+    __slots__ = ("_cv", "_inside", "_closed")
+
+    def __init__(self):
+        self._cv = threading.Condition(threading.Lock())
+        self._inside, self._closed = 0, False
+
+    def enter(self) -> None:
+        with self._cv:
+            while self._closed:
+                self._cv.wait()
+            self._inside += 1
+
+    def leave(self) -> None:
+        with self._cv:
+            self._inside -= 1
+            if self._closed and not self._inside:
+                self._cv.notify_all()
+
+    def close(self) -> None:
+        with self._cv:
+            self._closed = True
+            while self._inside:
+                self._cv.wait()
+
+    def open(self) -> None:
+        with self._cv:
+            self._closed = False
+            self._cv.notify_all()
+
+
 class Plan:
     """Owner of one pb_plan (dst projection, rotations, src projection)."""
 
@@ -316,6 +351,7 @@ class Plan:
         self.dst, self.src, self.n_rot = dst, src, rots.shape[0]
         self.double_src = src.kind == KIND_DOUBLE
         self._bilinear, self._deferred, self._bil_lock = bool(bilinear), bool(defer), threading.Lock()
+        self._gate = None if (bilinear and not defer) else _LaunchGate()  # (None: the tables are final)
 
     @classmethod
     def _adopt(cls, handle, dst: pb_proj, src: pb_proj, n_rot: int) -> "Plan":
@@ -324,23 +360,44 @@ class Plan:
         self.dst, self.src, self.n_rot = dst, src, n_rot
         self.double_src = src.kind == KIND_DOUBLE
         self._bilinear, self._deferred, self._bil_lock = True, False, threading.Lock()  # (a restored plan rebuilds the mode's tables with everything else)
+        self._gate = None
         return self
+
+    def _rebuild(self, flags: int, budget: int) -> None:
+        """pb_plan_prepare with this plan's launches held off: those inside the library leave first, the device drains (the tables the
+        call rewrites may be in use by launches already queued, on any stream), new ones wait at the gate."""
+        g = self._gate
+        if g is not None:
+            g.close()
+        try:
+            lib = load()
+            if g is not None and not self._deferred:  # (a prepared plan: its tables may be in use by launches already queued, on any stream)
+                check(lib.pb_device_sync())
+            check(lib.pb_plan_prepare(self._h, flags, int(budget)))
+        finally:
+            if g is not None:
+                g.open()
 
     def prepare(self, tune: bool = False, budget: int = 0) -> None:
         """Builds the fast path of a deferred plan on the current device (or re-applies ``budget``)."""
-        check(load().pb_plan_prepare(self._h, (PLAN_TUNE if tune else 0) | (PLAN_BILINEAR if self._bilinear else 0), int(budget)))
-        self._deferred = False
+        with self._bil_lock:
+            self._rebuild((PLAN_TUNE if tune else 0) | (PLAN_BILINEAR if self._bilinear else 0), budget)
+            self._deferred = False
+            if self._bilinear:
+                self._gate = None
 
     def ensure_bilinear(self) -> None:
-        """The opt-in bilinear mode's tables, built once when the mode is first used (synchronous; no launch of this plan may be in
-        flight on another stream, as for ``set_window_budget``).  A deferred plan stays deferred - its launches run the float64
-        kernels of either mode - and remembers the wish for ``prepare()``."""
+        """The opt-in bilinear mode's tables, built once when the mode is first used (synchronous).  Launches of this plan made through
+        this object on other threads wait while the tables are built; launches through the raw ``handle`` follow the C ABI's rule
+        (none in flight, as for ``set_window_budget``).  A deferred plan stays deferred - its launches run the float64 kernels of
+        either mode - and remembers the wish for ``prepare()``."""
         if self._bilinear:
             return
         with self._bil_lock:
             if not self._bilinear:
                 if not self._deferred:
-                    check(load().pb_plan_prepare(self._h, PLAN_BILINEAR, 0))
+                    self._rebuild(PLAN_BILINEAR, 0)
+                    self._gate = None
                 self._bilinear = True
 
     def set_window_budget(self, budget: int) -> None:
@@ -429,7 +486,19 @@ class Plan:
         if interpolation != "nearest":
             self.ensure_bilinear()
         fn = load().pb_remap_u8 if interpolation == "nearest" else load().pb_remap_bilinear_u8
-        check(fn(self._h, src_ptr, dst_ptr, int(n_frames), int(src_stride), int(dst_stride), current_stream() if stream is None else stream))
+        self._gated(fn, self._h, src_ptr, dst_ptr, int(n_frames), int(src_stride), int(dst_stride), current_stream() if stream is None else stream)
+
+    def _gated(self, fn, *args) -> None:
+        """One library call that launches this plan's kernels: through the gate while the plan's tables may still be rebuilt."""
+        g = self._gate
+        if g is None:
+            check(fn(*args))
+            return
+        g.enter()
+        try:
+            check(fn(*args))
+        finally:
+            g.leave()
 
     def remap(self, src, out=None, interpolation: str = "nearest"):
         """src: uint8 device array (h, w, 3) or (N, h, w, 3) -> (H, W, 3) / (N, H, W, 3), of src's kind.
@@ -490,7 +559,7 @@ class Plan:
         sp = (C.c_void_p * n)(*[int(s.data_ptr()) for s in srcs])
         dp = (C.c_void_p * n)(*[int(o.data_ptr()) for o in outs])
         with _on(srcs[0]):
-            check(load().pb_remap_u8v(self._h, sp, dp, n, current_stream() if stream is None else stream))
+            self._gated(load().pb_remap_u8v, self._h, sp, dp, n, current_stream() if stream is None else stream)
         return outs
 
     def index_map(self, weights: bool = False, device=None):
@@ -501,7 +570,7 @@ class Plan:
         idx = empty(shape, np.int32, device=device)
         w = empty((2, H, W), np.float64, like=idx) if (weights and self.double_src) else None
         with _on(idx):
-            check(load().pb_index_map_i32(self._h, idx.data_ptr(), w.data_ptr() if w is not None else None, current_stream()))
+            self._gated(load().pb_index_map_i32, self._h, idx.data_ptr(), w.data_ptr() if w is not None else None, current_stream())
         return (idx, w) if weights else idx
 
 

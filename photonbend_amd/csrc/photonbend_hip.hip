@@ -1103,9 +1103,10 @@ static int pb_plan_prepare_full(pb_plan* pl, unsigned flags, int win_budget) {
             int rc = pb_build_bilinear_list(pl);
             if (rc == PB_OK) rc = pb_build_bilinear_launch(pl);
             // pb_build_bilinear_launch leaves the tile tables' flags under the MODE's budget: the nearest mode's classification is written
-            // back (one small kernel).  Its launch table is NOT rebuilt - nothing it holds has changed - so nearest launches of this
-            // plan on other threads keep a valid table throughout (the Python host builds the mode's tables at its first use, on
-            // whichever thread that happens).
+            // back (one small kernel).  Its launch table is NOT rebuilt - nothing it holds has changed, and no device memory a launch may
+            // hold a pointer to is freed here.  The tile tables do pass through the other classification on the way, and a double-fisheye
+            // plan's nearest kernel reads them: hence the header's rule - no launch of the plan in flight (the Python host, which builds
+            // the mode's tables at its first use on whichever thread that happens, holds its own launches off: _native.py _LaunchGate).
             const int rc2 = win_budget > 0 ? pb_apply_budget(pl, win_budget) : pb_classify_under_budget(pl, pl->P.win_budget, nullptr);
             if (rc != PB_OK) return rc;
             if (rc2 != PB_OK) return rc2;

@@ -84,6 +84,37 @@ def test_plan_cache_survives_concurrent_callers():
     proj._PLAN_CACHE.clear()
 
 
+def test_launch_gate_holds_launches_off_a_rebuild():
+    """_native._LaunchGate: any number of launches inside at once; close() waits for them to leave and keeps new ones out until open()."""
+    import time
+
+    gate = nat._LaunchGate()
+    log, inside = [], threading.Event()
+
+    def launch(k, hold):
+        gate.enter()
+        log.append(("in", k))
+        inside.set()
+        time.sleep(hold)
+        log.append(("out", k))
+        gate.leave()
+
+    a = threading.Thread(target=launch, args=(0, 0.2))
+    a.start()
+    inside.wait(5)
+    gate.enter()  # (a second launch beside the first)
+    gate.leave()
+    closer = threading.Thread(target=lambda: (gate.close(), log.append(("closed",)), time.sleep(0.1), log.append(("opening",)), gate.open()))
+    closer.start()
+    time.sleep(0.05)
+    b = threading.Thread(target=launch, args=(1, 0.0))
+    b.start()
+    for t in (a, closer, b):
+        t.join(5)
+        assert not t.is_alive()
+    assert log == [("in", 0), ("out", 0), ("closed",), ("opening",), ("in", 1), ("out", 1)]
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
@@ -165,6 +196,47 @@ def test_bilinear_tables_are_built_at_the_modes_first_use(case):
     assert torch.equal(late.remap(frame, interpolation="bilinear"), f64)
     late.prepare()
     assert late.info()["bilinear_float64_tiles"] == 0 and torch.equal(late.remap(frame, interpolation="bilinear"), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [Case("api_race_pano", cam(1536, 1536, "equidistant", 360, inscribed(1536)), pano(1024, 2048)),
+                                  Case("api_race_double", pano(1024, 2048), dbl(960, 1920, "equidistant", 195), [(3, 90, -7)], mask=2)], ids=lambda c: c.name)
+def test_nearest_launches_run_on_while_another_thread_builds_the_bilinear_tables(case):
+    """A plan of the host's cache is shared by threads, and the opt-in mode's tables are built at the mode's first use on whichever thread
+    that happens: the build leaves the nearest mode's launch table in place (nothing it holds changes), so launches of the reference's
+    sampler on other threads run on through it - same bytes before, during and after."""
+    d, rots, s = _projs(case)
+    frame = nat.synth_frame(case.src[1], case.src[2], frame=4, circle_mask=case.mask)
+    plan = nat.Plan(d, rots, s)
+    want = plan.remap(frame)
+    want_bil = nat.Plan(d, rots, s, bilinear=True).remap(frame, interpolation="bilinear")
+    torch.cuda.synchronize()
+    started, errors, bad = threading.Event(), [], []
+
+    def nearest_loop():
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out = torch.empty_like(want)
+                for k in range(150):
+                    plan.remap(frame, out=out)
+                    if k == 10:
+                        started.set()
+                    torch.cuda.current_stream().synchronize()
+                    if not torch.equal(out, want):
+                        bad.append(k)
+        except Exception as ex:  # pragma: no cover
+            errors.append(ex)
+        finally:
+            started.set()
+
+    t = threading.Thread(target=nearest_loop)
+    t.start()
+    started.wait(60)
+    got_bil = plan.remap(frame, interpolation="bilinear")  # (builds the tables: plan.ensure_bilinear)
+    t.join(120)
+    assert not t.is_alive() and not errors and not bad, (errors, bad[:5])
+    assert plan.info()["bilinear_float64_tiles"] == 0 and torch.equal(got_bil, want_bil)
+    assert torch.equal(plan.remap(frame), want)
 
 
 @pytest.mark.gpu
