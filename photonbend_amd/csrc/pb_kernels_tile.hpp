@@ -961,15 +961,24 @@ __device__ __forceinline__ float pb_tile_cost(const PbTileEntry& e, const bool b
 // Plan creation: the cost of every super-tile for the launch order (fixed point, 1/1024: integer sums are order-independent).
 // A wave's measured life (experiments/diag_trace.py): 3 us on a black tile, 4.2 + 0.4 per KiB of window on a window tile,
 // 9.5 + 0.03 per source column on a direct-gather tile - here relative to a direct-gather tile of ordinary width.
+// forward / n_units: the class counters the budget pass in front of this kernel has left on the device (4 words) travel behind the costs
+// (unit_cost[n_units ..]), so that ONE copy brings both to the host (a round trip is 25 us of a 0.5 ms plan).
 __global__ void pb_unit_cost_kernel(const PbTileEntry* __restrict__ table, unsigned n_tiles, unsigned tiles_x, unsigned unit_tiles,
                                     unsigned units_x, unsigned* __restrict__ unit_cost, const PbTileEntry* __restrict__ table_r = nullptr,
-                                    unsigned unit_tiles_y = 0, int bil = 0) {
+                                    unsigned unit_tiles_y = 0, int bil = 0, const unsigned* __restrict__ forward = nullptr, unsigned n_units = 0) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (forward && t < 4u) unit_cost[n_units + t] = forward[t];
     if (t >= n_tiles) return;
     float c = pb_tile_cost(table[t], bil != 0);
     if (table_r) c += pb_tile_cost(table_r[t], bil != 0) - 0.3f;  // double-fisheye source: both eyes' work (a one-eye tile costs its live eye's)
     const unsigned ty = t / tiles_x, tx = t - ty * tiles_x;
     atomicAdd(&unit_cost[(ty / (unit_tiles_y ? unit_tiles_y : unit_tiles)) * units_x + tx / unit_tiles], (unsigned)(c * 1024.0f + 0.5f));
+}
+// The parameter block as the launches read it, stored from the kernel's own arguments: no host copy, no round trip.
+__global__ void pb_store_params_kernel(const PbParams P, PbParams* __restrict__ out) {
+    const unsigned* in = reinterpret_cast<const unsigned*>(&P);
+    unsigned* o = reinterpret_cast<unsigned*>(out);
+    for (unsigned k = threadIdx.x; k < sizeof(PbParams) / 4u; k += blockDim.x) o[k] = in[k];
 }
 __global__ void pb_save_flags_kernel(const PbTileEntry* __restrict__ table, int32_t* __restrict__ saved, unsigned n_tiles) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;

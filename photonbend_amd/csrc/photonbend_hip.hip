@@ -106,6 +106,32 @@ static int pb_knob(const char* name, int dflt) {
 static inline int pb_knob(const char*, int dflt) { return dflt; }
 #endif
 
+// -DPB_ABLATION only: PB_PLAN_STAGES=1 prints where a plan preparation's host time goes (experiments/r6/plan_stages.py): PB_STAGE("name")
+// stamps the host clock when the code reaches it, pb_stage_report prints the intervals.  Nothing in the product build.
+#ifdef PB_ABLATION
+#include <vector>
+static std::vector<std::pair<const char*, double>> g_stages;
+static void pb_stage_mark(const char* name) {
+    static const int on = pb_knob("PB_PLAN_STAGES", 0);
+    if (!on) return;
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    g_stages.emplace_back(name, ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6);
+}
+static void pb_stage_report() {
+    if (g_stages.size() > 1) {
+        fprintf(stderr, "[plan stages]");
+        for (size_t k = 1; k < g_stages.size(); ++k) fprintf(stderr, " %s %.0f", g_stages[k].first, 1e3 * (g_stages[k].second - g_stages[k - 1].second));
+        fprintf(stderr, " | total %.0f us\n", 1e3 * (g_stages.back().second - g_stages.front().second));
+    }
+    g_stages.clear();
+}
+#define PB_STAGE(name) pb_stage_mark(name)
+#else
+#define PB_STAGE(name) ((void)0)
+static inline void pb_stage_report() {}
+#endif
+
 // -DPB_ABLATION only: PB_FAIL_LTABLE_ALLOC=n makes the n-th launch-table allocation of the process fail (tests of the error path)
 static bool pb_test_alloc_fails() {
 #ifdef PB_ABLATION
@@ -136,6 +162,10 @@ static int pb_fail(int code, const std::string& msg) {
 // (experiments/r4/plan_api.sh).  They come from a per-device cache instead: a freed block is kept (up to 32 MiB in blocks of up to 4 MiB)
 // and handed to the next request it fits.  Safe because every user works on the NULL stream, which orders a block's next kernel behind its
 // last one device-wide, and because each site releases its block only after a synchronising copy or hipDeviceSynchronize.
+// Round 6: a plan's OWN tables (tile tables, fix lists, launch tables, parameter block) come from the same cache - a warm c2 plan made
+// eight hipMallocs (~40 us of its 0.45 ms) and its destruction up to ten hipFrees (~350 us).  Launches read those tables on the caller's
+// streams, which the NULL stream does not order: pb_plan_destroy and the budget change wait for the device ONCE before they hand blocks
+// back (what every one of their hipFrees did before).
 namespace {
 struct PbTmpCache {
     struct Block { int device; size_t bytes; void* ptr; };
@@ -189,6 +219,24 @@ static void pb_tmp_free(void* ptr) {
         }
     }
     (void)hipFree(ptr);
+}
+// Waits for `device` (< 0: the current one): a plan's launches may still be reading its tables on the caller's streams when a block goes
+// back to the cache - what the hipFree of rounds 1-5 did by itself, once per table.
+static void pb_wait_device(int device) {
+    int cur = -1;
+    if (device < 0 || hipGetDevice(&cur) != hipSuccess || cur == device) {
+        (void)hipDeviceSynchronize();
+        return;
+    }
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    (void)hipSetDevice(cur);
+}
+// one table of a plan back to the cache (nullptr: nothing, and no wait)
+static void pb_table_release(int device, void* ptr) {
+    if (!ptr) return;
+    pb_wait_device(device);
+    pb_tmp_free(ptr);
 }
 
 static inline unsigned pb_blocks(unsigned long long items);
@@ -412,6 +460,13 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
     do {
         if (P.dst.kind != PB_KIND_PANO) {
             hipLaunchKernelGGL(pb_threshold_kernel, dim3(1), dim3(2), 0, 0, P, scratch);
+            // (the bisection is one lane's chain of ~60 dependent square roots, 25-35 us: a single source's tile tables are allocated meanwhile)
+            if (P.src.kind != PB_KIND_DOUBLE && pb_fast_possible(P)) {
+                const unsigned nt0 = pb_num_tiles(P);
+                if (pb_tmp_alloc((void**)&pl->table, (size_t)nt0 * sizeof(PbTileEntry)) != hipSuccess ||
+                    pb_tmp_alloc((void**)&pl->fail_tiles, (size_t)nt0 * sizeof(int32_t)) != hipSuccess ||
+                    pb_tmp_alloc((void**)&pl->fix_px, (size_t)nt0 * PB_TILE_FAIL_LIMIT * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            }
             long long thr[4];
             if (hipMemcpy(thr, scratch, sizeof(thr), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
             P.inv_lo[0] = thr[0]; P.inv_hi[0] = thr[1];
@@ -433,10 +488,10 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             if (!pb_fast_possible_dims(P)) break;
             const unsigned ntiles = pb_num_tiles(P);
             const unsigned cap = 2u * ntiles * PB_TILE_FAIL_LIMIT;
-            if (hipMalloc((void**)&pl->table, (size_t)ntiles * sizeof(PbTileEntry)) != hipSuccess ||
-                hipMalloc((void**)&pl->table_r, (size_t)ntiles * sizeof(PbTileEntry)) != hipSuccess ||
-                hipMalloc((void**)&pl->fail_tiles, (size_t)2 * ntiles * sizeof(int32_t)) != hipSuccess ||
-                hipMalloc((void**)&pl->fix_px, (size_t)cap * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            if (pb_tmp_alloc((void**)&pl->table, (size_t)ntiles * sizeof(PbTileEntry)) != hipSuccess ||
+                pb_tmp_alloc((void**)&pl->table_r, (size_t)ntiles * sizeof(PbTileEntry)) != hipSuccess ||
+                pb_tmp_alloc((void**)&pl->fail_tiles, (size_t)2 * ntiles * sizeof(int32_t)) != hipSuccess ||
+                pb_tmp_alloc((void**)&pl->fix_px, (size_t)cap * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
             unsigned* counters = reinterpret_cast<unsigned*>(scratch + 4);
             if (hipMemsetAsync(counters, 0, 12 * sizeof(unsigned), 0) != hipSuccess) { rc = PB_ERR_HIP; break; }
             const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
@@ -457,7 +512,7 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             if (hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
             pl->n_lat_tiles = res[8] < lat_capacity ? res[8] : lat_capacity;
             if (pl->n_lat_tiles) {
-                if (hipMalloc((void**)&pl->lat_tab, (size_t)pl->n_lat_tiles * PB_LAT_TILE_DOUBLES * sizeof(double)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+                if (pb_tmp_alloc((void**)&pl->lat_tab, (size_t)pl->n_lat_tiles * PB_LAT_TILE_DOUBLES * sizeof(double)) != hipSuccess) { rc = PB_ERR_HIP; break; }
                 hipLaunchKernelGGL(pb_double_lat_kernel, grid, block, 0, 0, P, pl->table, pl->lat_tab);
                 if (hipDeviceSynchronize() != hipSuccess) { rc = PB_ERR_HIP; break; }
             }
@@ -465,8 +520,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                 const unsigned nf = res[1], np = res[0] > cap ? cap : res[0];
                 // a geometry the models mostly cannot follow is not worth gigabytes of stored taps: faithful kernel
                 if ((size_t)nf * PB_TILE * PB_TILE * sizeof(PbDoubleFix) > ((size_t)1 << 30)) break;
-                if (hipMalloc((void**)&pl->dbl_tile_fix, (size_t)(nf ? nf : 1) * PB_TILE * PB_TILE * sizeof(PbDoubleFix)) != hipSuccess ||
-                    hipMalloc((void**)&pl->dbl_px_fix, (size_t)(np ? np : 1) * sizeof(PbDoubleFix)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+                if (pb_tmp_alloc((void**)&pl->dbl_tile_fix, (size_t)(nf ? nf : 1) * PB_TILE * PB_TILE * sizeof(PbDoubleFix)) != hipSuccess ||
+                    pb_tmp_alloc((void**)&pl->dbl_px_fix, (size_t)(np ? np : 1) * sizeof(PbDoubleFix)) != hipSuccess) { rc = PB_ERR_HIP; break; }
                 const unsigned blocks = 4u * nf + (np + PB_BLOCK - 1) / PB_BLOCK;
                 if (blocks) {
                     hipLaunchKernelGGL(pb_double_tables_kernel, dim3(blocks), dim3(PB_BLOCK), 0, 0, P, pl->table_r, pl->fail_tiles, (int)nf, pl->fix_px,
@@ -486,12 +541,15 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
             pl->dbl_ready = 1;
             break;
         }
+        PB_STAGE("thresholds");
         if (!pb_fast_possible(P)) break;
         const unsigned ntiles = pb_num_tiles(P);
         const unsigned cap = ntiles * PB_TILE_FAIL_LIMIT;
-        if (hipMalloc((void**)&pl->table, (size_t)ntiles * sizeof(PbTileEntry)) != hipSuccess ||
-            hipMalloc((void**)&pl->fail_tiles, (size_t)ntiles * sizeof(int32_t)) != hipSuccess ||
-            hipMalloc((void**)&pl->fix_px, (size_t)cap * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+        if (!pl->table &&  // (not allocated beside the threshold kernel above)
+            (pb_tmp_alloc((void**)&pl->table, (size_t)ntiles * sizeof(PbTileEntry)) != hipSuccess ||
+             pb_tmp_alloc((void**)&pl->fail_tiles, (size_t)ntiles * sizeof(int32_t)) != hipSuccess ||
+             pb_tmp_alloc((void**)&pl->fix_px, (size_t)cap * sizeof(int32_t)) != hipSuccess)) { rc = PB_ERR_HIP; break; }
+        PB_STAGE("malloc3");
         unsigned* counters = reinterpret_cast<unsigned*>(scratch + 4);
         if (hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), 0) != hipSuccess) { rc = PB_ERR_HIP; break; }
         const dim3 grid(pb_hot_blocks(P)), block(64 * PB_TILE_WAVES);
@@ -511,9 +569,11 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                 pb_tmp_free(col_sc);
             }
         }
+        PB_STAGE("enqueue+colsync");
         hipLaunchKernelGGL(pb_count_flags_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, 0, pl->table, ntiles, counters);
         unsigned res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost) != hipSuccess) { rc = PB_ERR_HIP; break; }
+        PB_STAGE("certify-readback");
         pl->n_lean_tiles = res[4];
         pl->n_black_tiles = res[5];
         pl->n_direct_tiles = res[6];
@@ -523,8 +583,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         pl->n_tiles = ntiles;
         {   // exact-index tables for the windowed hot kernel
             const unsigned nf = pl->n_fail_tiles, np = pl->n_fix_px;
-            if (hipMalloc((void**)&pl->idx_tab, (size_t)(nf ? nf : 1) * PB_TILE * PB_TILE * sizeof(int32_t)) != hipSuccess ||
-                hipMalloc((void**)&pl->fix_idx, (size_t)(np ? np : 1) * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            if (pb_tmp_alloc((void**)&pl->idx_tab, (size_t)(nf ? nf : 1) * PB_TILE * PB_TILE * sizeof(int32_t)) != hipSuccess ||
+                pb_tmp_alloc((void**)&pl->fix_idx, (size_t)(np ? np : 1) * sizeof(int32_t)) != hipSuccess) { rc = PB_ERR_HIP; break; }
             const unsigned blocks = 4u * nf + (np + PB_BLOCK - 1) / PB_BLOCK;
             if (blocks) {
                 if (P.src.kind == PB_KIND_PANO)
@@ -533,26 +593,33 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
                 else
                     hipLaunchKernelGGL(pb_fix_tables_kernel<PB_KIND_CAMERA>, dim3(blocks), dim3(PB_BLOCK), 0, 0, P, pl->table, pl->fail_tiles, (int)nf,
                                        pl->fix_px, (int)np, pl->idx_tab, pl->fix_idx);
-                if (hipDeviceSynchronize() != hipSuccess) { rc = PB_ERR_HIP; break; }
+                // (not waited for: the budget pass and the launch-order pass queue up behind it, and their readback reports a failure)
+                if (hipGetLastError() != hipSuccess) { rc = PB_ERR_HIP; break; }
             }
         }
+        PB_STAGE("fix-tables");
         if (pl->bil_wanted && pb_build_bilinear_list(pl) != PB_OK) { rc = PB_ERR_HIP; break; }
         pl->fast_ready = 1;
     } while (0);
     if (rc != PB_OK) {
         g_err = std::string("plan preparation on device failed: ") + hipGetErrorString(hipGetLastError());
-        (void)hipFree(pl->table); (void)hipFree(pl->fail_tiles); (void)hipFree(pl->fix_px); (void)hipFree(pl->idx_tab); (void)hipFree(pl->fix_idx);
+        (void)hipDeviceSynchronize();
+        pb_tmp_free(pl->table); pb_tmp_free(pl->fail_tiles); pb_tmp_free(pl->fix_px); pb_tmp_free(pl->idx_tab); pb_tmp_free(pl->fix_idx);
         pl->idx_tab = nullptr; pl->fix_idx = nullptr;
-        (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols); (void)hipFree(pl->table_r); (void)hipFree(pl->lat_tab);
-        (void)hipFree(pl->dbl_tile_fix); (void)hipFree(pl->dbl_px_fix); (void)hipFree(pl->bil_tiles); (void)hipFree(pl->bil_xy); (void)hipFree(pl->bil_fix_xy);
+        (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols); pb_tmp_free(pl->table_r); pb_tmp_free(pl->lat_tab);
+        pb_tmp_free(pl->dbl_tile_fix); pb_tmp_free(pl->dbl_px_fix); (void)hipFree(pl->bil_tiles); (void)hipFree(pl->bil_xy); (void)hipFree(pl->bil_fix_xy);
         pl->dbl_tile_fix = nullptr; pl->dbl_px_fix = nullptr; pl->bil_tiles = nullptr; pl->n_bil_tiles = 0;
         pl->bil_xy = pl->bil_fix_xy = nullptr; pl->n_bil_slots = 0;
         pb_sep_release(pl);
         pl->table_r = nullptr; pl->lat_tab = nullptr; pl->sep_ready = 0; pl->dbl_ready = 0;
         pl->table = nullptr; pl->fail_tiles = nullptr; pl->fix_px = nullptr; pl->sep_rows = nullptr; pl->sep_cols = nullptr;
     }
-    (void)hipDeviceSynchronize();  // (preparation is synchronous; the scratch block goes back to the cache idle)
+    PB_STAGE("bil-list");
+    // (the scratch block's next user is ordered behind these kernels by the NULL stream; pb_plan_prepare_full's budget pass ends the
+    //  preparation with the wait - a failed one waits here, its tables have just been freed)
+    if (rc != PB_OK || !(pl->fast_ready || pl->dbl_ready)) (void)hipDeviceSynchronize();
     pb_tmp_free(scratch);
+    PB_STAGE("final-sync");
     return rc;
 }
 
@@ -643,7 +710,9 @@ static int pb_clamp_budget(int budget) {
 // failed and direct-gather tiles): then the super-tiles go heaviest first, dealt round-robin (c3 37.9 -> 35.1 us).  Double-fisheye
 // plans walk top to bottom and let columns of super-tiles change XCD when one XCD runs ahead (the policy is spelled out where it
 // is applied, below).  -DPB_ABLATION builds: PB_ORDER=1 forces top-to-bottom.  Synchronous.
-static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
+// class_dev / class_out: the budget pass's counters still on the device (pb_classify_under_budget keep_dev) and where their first two
+// words go - fetched with the cost pass's readback when there is one, by themselves otherwise.
+static int pb_build_launch_table(pb_plan* pl, const bool bil = false, const unsigned* class_dev = nullptr, unsigned* class_out = nullptr) {
     PbParams& P = pl->P;
     PbTileEntry*& out_table = bil ? pl->ltable_bil : pl->ltable;
     unsigned& out_groups = bil ? pl->launch_groups_bil : pl->launch_groups;
@@ -677,22 +746,29 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
         bool row_walk = true;  // seq is a sequence of whole rows
         const int walk = (order_mode >= 1 && order_mode <= 3) ? order_mode : pl->walk;  // (PB_ORDER=1 / 2 / 3, diagnostic build: force the plain walk / rows outwards / heaviest first)
         if (walk != 1 && sgy >= 4 && (ns >= 128u || walk != 0)) {  // (fewer than 16 super-tiles per XCD: too coarse to reorder - a 3072x2048 output measured 3-4 % slower)
-            std::vector<unsigned> fixed(ns, 0u);
+            std::vector<unsigned> fixed(ns + 4u, 0u);
             unsigned* cost_dev = nullptr;
-            if (pb_tmp_alloc((void**)&cost_dev, ns * sizeof(unsigned)) != hipSuccess) {
-                (void)hipFree(out_table);  // (the old table may be classified under another budget)
+            if (pb_tmp_alloc((void**)&cost_dev, (ns + 4u) * sizeof(unsigned)) != hipSuccess) {
+                pb_table_release(pl->device, out_table);  // (the old table may be classified under another budget)
                 out_table = nullptr;
                 out_groups = 0;
                 return pb_fail(PB_ERR_HIP, "launch table: out of device memory");
             }
             (void)hipMemsetAsync(cost_dev, 0, ns * sizeof(unsigned), 0);
             hipLaunchKernelGGL(pb_unit_cost_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->n_tiles, tiles_x, 2u * U, sgx, cost_dev,
-                               pl->dbl_ready ? pl->table_r : nullptr, 2u * UY, bil ? 1 : 0);
-            const hipError_t ce = hipMemcpy(fixed.data(), cost_dev, ns * sizeof(unsigned), hipMemcpyDeviceToHost);
+                               pl->dbl_ready ? pl->table_r : nullptr, 2u * UY, bil ? 1 : 0, class_dev, ns);
+            PB_STAGE("lt-host0");
+            const hipError_t ce = hipMemcpy(fixed.data(), cost_dev, (ns + (class_dev ? 4u : 0u)) * sizeof(unsigned), hipMemcpyDeviceToHost);
+            if (class_dev && class_out && ce == hipSuccess) {
+                class_out[0] = fixed[ns];
+                class_out[1] = fixed[ns + 1];
+                class_dev = nullptr;  // (delivered)
+            }
+            PB_STAGE("lt-cost-readback");
             if (ce != hipSuccess) (void)hipDeviceSynchronize();
             pb_tmp_free(cost_dev);
             if (ce != hipSuccess) {
-                (void)hipFree(out_table);
+                pb_table_release(pl->device, out_table);
                 out_table = nullptr;
                 out_groups = 0;
                 return pb_fail(PB_ERR_HIP, std::string("launch table: ") + hipGetErrorString(ce));
@@ -783,15 +859,23 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
     // the new table is built aside and replaces the plan's only when it is complete: a failure leaves the plan WITHOUT a
     // launch table (ltable == nullptr, launch_groups == 0 - its launches then take the direct-gather kernels), never with a
     // half-written one or one classified under another budget
-    (void)hipFree(out_table);
+    pb_table_release(pl->device, out_table);
     out_table = nullptr;
     out_groups = 0;
     PbTileEntry* fresh = nullptr;
     int* unit_dev = nullptr;
     hipError_t e = hipSuccess;
-    if (units) {
+    if (class_dev && class_out) {  // (no cost pass has brought the budget pass's class counters along)
+        unsigned r4[4] = {0, 0, 0, 0};
+        e = hipMemcpy(r4, class_dev, sizeof(r4), hipMemcpyDeviceToHost);
+        class_out[0] = r4[0];
+        class_out[1] = r4[1];
+    }
+    if (units && e == hipSuccess) {
         e = pb_tmp_alloc((void**)&unit_dev, unit_of.size() * sizeof(int));
+        PB_STAGE("lt-host-order");
         if (e == hipSuccess) e = hipMemcpy(unit_dev, unit_of.data(), unit_of.size() * sizeof(int), hipMemcpyHostToDevice);
+        PB_STAGE("lt-unit-upload");
     }
     if (bil && pl->dbl_ready) {
         // the PAIR layout (pb_kernels_tile.hpp): a two-eye tile takes two slots of a pair workgroup, so the XCDs' lists grow by what
@@ -806,7 +890,7 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
         }
         const unsigned per_xcd = *std::max_element(totals, totals + 8), pair_groups = 8u * per_xcd;
         if (e == hipSuccess && pair_groups == 0) e = hipErrorInvalidValue;  // (a plan without tiles does not get here)
-        if (e == hipSuccess) e = hipMalloc((void**)&fresh, (size_t)pair_groups * 4u * sizeof(PbTileEntry));
+        if (e == hipSuccess) e = pb_tmp_alloc((void**)&fresh, (size_t)pair_groups * 4u * sizeof(PbTileEntry));
         if (e == hipSuccess) {
             hipLaunchKernelGGL(pb_skip_fill_kernel, dim3(pair_groups), dim3(256), 0, 0, fresh, 4u * pair_groups);
             hipLaunchKernelGGL(pb_pair_table_kernel, dim3(n_groups), dim3(64), 0, 0, P, pl->table, pl->table_r, fresh, unit_dev, units_per_xcd, n_groups, (int)U, (int)UY,
@@ -817,16 +901,18 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
         n_groups = pair_groups;
     } else {
         const unsigned n_slots = 4u * n_groups;
-        if (e == hipSuccess) e = (!bil && pb_test_alloc_fails()) ? hipErrorOutOfMemory : hipMalloc((void**)&fresh, (size_t)n_slots * sizeof(PbTileEntry));  // (the test hook counts the nearest mode's tables)
+        if (e == hipSuccess) e = (!bil && pb_test_alloc_fails()) ? hipErrorOutOfMemory : pb_tmp_alloc((void**)&fresh, (size_t)n_slots * sizeof(PbTileEntry));  // (the test hook counts the nearest mode's tables)
         if (e == hipSuccess) {
+            PB_STAGE("lt-malloc");
             hipLaunchKernelGGL(pb_launch_table_kernel, dim3(n_groups), dim3(256), 0, 0, P, pl->table, fresh, unit_dev, units_per_xcd, n_slots, (int)U,
                                pl->dbl_ready ? pl->table_r : nullptr, (int)UY);
             e = hipDeviceSynchronize();
+            PB_STAGE("lt-kernel-sync");
         }
     }
     pb_tmp_free(unit_dev);
     if (e != hipSuccess) {
-        (void)hipFree(fresh);
+        pb_table_release(pl->device, fresh);
         (void)hipGetLastError();
         return pb_fail(PB_ERR_HIP, std::string("launch table: ") + hipGetErrorString(e));
     }
@@ -837,24 +923,29 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false) {
 
 // keeps the certified flags (once) and writes the flags under `budget` into the tile tables; counts = {LEAN, DIRECT} tiles (nullptr: not
 // wanted - then the call does not wait for the device).
-static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2]) {
+// keep_dev: the class counters stay on the device in that block (4 words, zeroed here) for the caller to fetch with something else.
+static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2], unsigned* keep_dev = nullptr) {
     const unsigned nt = pl->n_tiles;
     const dim3 g((nt + 255) / 256), b(256);
     if (!pl->saved_l) {
-        PB_HIP(hipMalloc((void**)&pl->saved_l, (size_t)nt * sizeof(int32_t)));
+        PB_HIP(pb_tmp_alloc((void**)&pl->saved_l, (size_t)nt * sizeof(int32_t)));
         hipLaunchKernelGGL(pb_save_flags_kernel, g, b, 0, 0, pl->table, pl->saved_l, nt);
         if (pl->dbl_ready) {
-            PB_HIP(hipMalloc((void**)&pl->saved_r, (size_t)nt * sizeof(int32_t)));
+            PB_HIP(pb_tmp_alloc((void**)&pl->saved_r, (size_t)nt * sizeof(int32_t)));
             hipLaunchKernelGGL(pb_save_flags_kernel, g, b, 0, 0, pl->table_r, pl->saved_r, nt);
         }
     }
-    unsigned* counters = nullptr;
-    PB_HIP(pb_tmp_alloc((void**)&counters, 4 * sizeof(unsigned)));
+    unsigned* counters = keep_dev;
+    if (!counters) PB_HIP(pb_tmp_alloc((void**)&counters, 4 * sizeof(unsigned)));
     (void)hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
     if (pl->dbl_ready)
         hipLaunchKernelGGL(pb_budget_double_kernel, g, b, 0, 0, pl->table, pl->table_r, pl->saved_l, pl->saved_r, nt, budget, counters);
     else
         hipLaunchKernelGGL(pb_budget_kernel, g, b, 0, 0, pl->table, pl->saved_l, nt, budget, counters);
+    if (keep_dev) {
+        PB_HIP(hipGetLastError());
+        return PB_OK;
+    }
     if (!counts) {  // (nobody reads the class counts of this pass: no round trip - the block's next user is ordered behind the kernel by the stream)
         pb_tmp_free(counters);
         PB_HIP(hipGetLastError());
@@ -881,7 +972,7 @@ static int pb_classify_under_budget(pb_plan* pl, int budget, unsigned counts[2])
 //  // measured on MI355X (experiments/r4/budget_bil.sh): c1 28.7 us at 7 KiB, 25.2 at 12; c2 68.9 / 62.0; c5 109.8 / 103.4; c3 58.3 / 58.9
 static int pb_build_bilinear_launch(pb_plan* pl) {
     if (!(pl->fast_ready || pl->dbl_ready)) return PB_OK;
-    (void)hipFree(pl->ltable_bil);
+    pb_table_release(pl->device, pl->ltable_bil);
     pl->ltable_bil = nullptr;
     pl->launch_groups_bil = 0;
     pl->bil_budget = pb_clamp_budget(PB_BIL_WIN_BUDGET);
@@ -935,7 +1026,7 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     if (e != hipSuccess) (void)hipDeviceSynchronize();
     pb_tmp_free(counters);
     if (e != hipSuccess || res[1] != 0u) {
-        (void)hipFree(pl->ltable_bil);
+        pb_table_release(pl->device, pl->ltable_bil);
         pl->ltable_bil = nullptr;
         pl->launch_groups_bil = 0;
         return pb_fail(PB_ERR_HIP, e != hipSuccess ? std::string("bilinear LDS pool: ") + hipGetErrorString(e) : std::string("bilinear LDS pool: a workgroup does not fit"));
@@ -945,7 +1036,7 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
                                pl->bil_fix_xy, pl->dbl_tile_fix, pl->dbl_px_fix};
         if ((!pl->bil_dbl_tables && hipMalloc((void**)&pl->bil_dbl_tables, sizeof(PbDblTables)) != hipSuccess) ||
             hipMemcpy(pl->bil_dbl_tables, &T, sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(pl->ltable_bil);
+            pb_table_release(pl->device, pl->ltable_bil);
             pl->ltable_bil = nullptr;
             pl->launch_groups_bil = 0;
             return pb_fail(PB_ERR_HIP, "bilinear launch: out of device memory");
@@ -965,21 +1056,36 @@ static int pb_apply_budget(pb_plan* pl, int budget) {
     // leave the old launch table, classified under the old budget, next to the new budget)
     PbParams Q = P;
     Q.win_budget = budget;
-    if (!pl->P_dev) PB_HIP(hipMalloc((void**)&pl->P_dev, sizeof(PbParams)));
-    unsigned counts[2];
-    int rc = pb_classify_under_budget(pl, budget, counts);
-    if (rc == PB_OK && hipMemcpy(pl->P_dev, &Q, sizeof(PbParams), hipMemcpyHostToDevice) != hipSuccess) rc = pb_fail(PB_ERR_HIP, "parameter block upload failed");
+    if (!pl->P_dev) PB_HIP(pb_tmp_alloc((void**)&pl->P_dev, sizeof(PbParams)));
+    // Nothing here waits for the device by itself (a round trip is 12-25 us of a 0.5 ms plan): the class counters of the budget pass stay
+    // on the device and come back with the launch-order pass's costs, the parameter block is stored by a kernel from its own arguments.
+    unsigned counts[2] = {pl->n_lean_tiles, pl->n_direct_tiles};
+    unsigned* class_dev = nullptr;
+    PB_HIP(pb_tmp_alloc((void**)&class_dev, 4 * sizeof(unsigned)));
+    PB_STAGE("ab-pdev-malloc");
+    int rc = pb_classify_under_budget(pl, budget, nullptr, class_dev);
+    PB_STAGE("ab-classify");
+    if (rc == PB_OK) {
+        hipLaunchKernelGGL(pb_store_params_kernel, dim3(1), dim3(64), 0, 0, Q, pl->P_dev);
+        if (hipGetLastError() != hipSuccess) rc = pb_fail(PB_ERR_HIP, "parameter block upload failed");
+    }
+    PB_STAGE("ab-pdev-upload");
     if (rc != PB_OK) {
         // the table may be half reclassified: no launch table at all (launches take the direct-gather kernels, which read no budget)
-        (void)hipFree(pl->ltable);
+        (void)hipDeviceSynchronize();  // (the counter block goes back idle)
+        pb_tmp_free(pl->ltable);
+        pb_tmp_free(class_dev);
         pl->ltable = nullptr;
         pl->launch_groups = 0;
         return rc;
     }
     P.win_budget = budget;
+    rc = pb_build_launch_table(pl, false, class_dev, counts);
+    if (rc != PB_OK) (void)hipDeviceSynchronize();
+    pb_tmp_free(class_dev);  // (pb_build_launch_table has waited for the device)
     pl->n_lean_tiles = counts[0];
     pl->n_direct_tiles = counts[1];
-    return pb_build_launch_table(pl);
+    return rc;
 }
 
 // OPT-IN (PB_PLAN_TUNE): picks the budget by measurement - four candidates x a few launches on scratch frames
@@ -1116,6 +1222,7 @@ static int pb_plan_prepare_full(pb_plan* pl, unsigned flags, int win_budget) {
         if (win_budget > 0) return pb_apply_budget(pl, win_budget);
         return PB_OK;
     }
+    PB_STAGE("begin");
     const double t0 = pb_now_ms();
     int rc = pb_plan_prepare_on_device(pl);
     if (rc != PB_OK) {
@@ -1127,9 +1234,12 @@ static int pb_plan_prepare_full(pb_plan* pl, unsigned flags, int win_budget) {
     if (win_budget <= 0 && pb_knob("PB_WIN_BUDGET", 0) > 0) budget = pb_knob("PB_WIN_BUDGET", 0);
     if (pl->bil_wanted) rc = pb_build_bilinear_launch(pl);
     if (rc != PB_OK) return rc;
+    PB_STAGE("bil-launch");
     rc = pb_apply_budget(pl, budget);
     if (rc != PB_OK) return rc;
     PB_HIP(hipDeviceSynchronize());
+    PB_STAGE("apply-budget-end");
+    pb_stage_report();
     pl->prepare_ms = pb_now_ms() - t0;
     if ((flags & PB_PLAN_TUNE) && win_budget <= 0) {
         const double t1 = pb_now_ms();
@@ -1247,27 +1357,29 @@ int pb_plan_timing(const pb_plan* plan, double* prepare_ms, double* tune_ms) {
 
 void pb_plan_destroy(pb_plan* plan) {
     if (!plan) return;
-    (void)hipFree(plan->table);
-    (void)hipFree(plan->fail_tiles);
-    (void)hipFree(plan->fix_px);
-    (void)hipFree(plan->idx_tab);
-    (void)hipFree(plan->fix_idx);
+    // ONE wait (launches of the plan may still be in flight on the caller's streams), then every table back to the cache
+    if (plan->table || plan->table_r || plan->ltable || plan->P_dev || plan->sep_rows) pb_wait_device(plan->device);
+    pb_tmp_free(plan->table);
+    pb_tmp_free(plan->fail_tiles);
+    pb_tmp_free(plan->fix_px);
+    pb_tmp_free(plan->idx_tab);
+    pb_tmp_free(plan->fix_idx);
     pb_sep_release(plan);
-    (void)hipFree(plan->sep_rows);
-    (void)hipFree(plan->sep_cols);
-    (void)hipFree(plan->table_r);
-    (void)hipFree(plan->lat_tab);
-    (void)hipFree(plan->dbl_tile_fix);
-    (void)hipFree(plan->dbl_px_fix);
-    (void)hipFree(plan->saved_l);
-    (void)hipFree(plan->saved_r);
-    (void)hipFree(plan->ltable);
-    (void)hipFree(plan->ltable_bil);
-    (void)hipFree(plan->bil_dbl_tables);
-    (void)hipFree(plan->P_dev);
-    (void)hipFree(plan->bil_tiles);
-    (void)hipFree(plan->bil_xy);
-    (void)hipFree(plan->bil_fix_xy);
+    pb_tmp_free(plan->sep_rows);
+    pb_tmp_free(plan->sep_cols);
+    pb_tmp_free(plan->table_r);
+    pb_tmp_free(plan->lat_tab);
+    pb_tmp_free(plan->dbl_tile_fix);
+    pb_tmp_free(plan->dbl_px_fix);
+    pb_tmp_free(plan->saved_l);
+    pb_tmp_free(plan->saved_r);
+    pb_tmp_free(plan->ltable);
+    pb_tmp_free(plan->ltable_bil);
+    pb_tmp_free(plan->bil_dbl_tables);
+    pb_tmp_free(plan->P_dev);
+    pb_tmp_free(plan->bil_tiles);
+    pb_tmp_free(plan->bil_xy);
+    pb_tmp_free(plan->bil_fix_xy);
     delete plan;
 }
 
@@ -2020,7 +2132,7 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
     const uint8_t* q = in + sizeof(PbBlobHeader) + sizeof(PbParams);
     for (int i = 0; i < 13 && rc == PB_OK; ++i) {
         if (!sec[i].bytes) continue;
-        if (hipMalloc(sec[i].ptr, sec[i].bytes) != hipSuccess || hipMemcpy(*sec[i].ptr, q, sec[i].bytes, hipMemcpyHostToDevice) != hipSuccess)
+        if (pb_tmp_alloc(sec[i].ptr, sec[i].bytes) != hipSuccess || hipMemcpy(*sec[i].ptr, q, sec[i].bytes, hipMemcpyHostToDevice) != hipSuccess)
             rc = PB_ERR_HIP;
         q += sec[i].bytes;
     }
@@ -2029,7 +2141,7 @@ int pb_plan_deserialize(const void* buf, size_t size, pb_plan** out) {
         pb_plan_destroy(pl);
         return rc;
     }
-    if (hipMalloc((void**)&pl->P_dev, sizeof(PbParams)) != hipSuccess || hipMemcpy(pl->P_dev, &pl->P, sizeof(PbParams), hipMemcpyHostToDevice) != hipSuccess) {
+    if (pb_tmp_alloc((void**)&pl->P_dev, sizeof(PbParams)) != hipSuccess || hipMemcpy(pl->P_dev, &pl->P, sizeof(PbParams), hipMemcpyHostToDevice) != hipSuccess) {
         pb_plan_destroy(pl);
         return pb_fail(PB_ERR_HIP, "plan upload failed: parameter block");
     }
