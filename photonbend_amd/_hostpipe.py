@@ -40,6 +40,7 @@ class HostPipe:
         self.stream = Stream()
         self._stage = []  # [pinned uint8 ndarray, Event or None]
         self._dev = OrderedDict()  # (slot, nbytes) -> DeviceArray
+        self._ring = {}  # nbytes -> idle DeviceArrays of remap_frames
         self._k = 0
 
     # -- device buffers kept between calls (hipMalloc of a 100 MB frame costs about a millisecond) ------------------------
@@ -52,6 +53,21 @@ class HostPipe:
             buf = self._dev[key] = DeviceArray((nbytes,), np.uint8)
         self._dev.move_to_end(key)
         return buf
+
+    # -- the streaming pipeline's rotating input buffers: checked out for one remap_frames call, kept for the next (three hipMallocs and
+    #    hipFrees of 100 MB were 1.5 ms of every call - a tenth of a millisecond per frame of a 16-frame batch)
+    def take_ring(self, nbytes: int, count: int) -> list:
+        idle = self._ring.setdefault(nbytes, [])
+        out = [idle.pop() for _ in range(min(count, len(idle)))]
+        while len(out) < count:
+            out.append(DeviceArray((nbytes,), np.uint8))
+        return out
+
+    def give_ring(self, nbytes: int, bufs: list) -> None:
+        idle = self._ring.setdefault(nbytes, [])
+        idle.extend(bufs[: max(0, 4 - len(idle))])  # (at most four per size stay)
+        for key in [k for k in self._ring if k != nbytes][1:]:  # (and two sizes)
+            del self._ring[key]
 
     def _staging(self):
         """The next page-locked staging chunk, free of its previous DMA."""
@@ -133,42 +149,54 @@ def remap_frames(plan: nat.Plan, frames: Iterable[np.ndarray], depth: int = 3, i
     sh = (plan.src.height, plan.src.width, 3)
     dh = (plan.dst.height, plan.dst.width, 3)
     n_in = int(np.prod(sh))
-    d_in = [DeviceArray((n_in,), np.uint8) for _ in range(depth)]
+    d_in = pipe.take_ring(n_in, depth)
     s_up, s_run = Stream(), Stream()
     uploaded = [Event() for _ in range(depth)]
     computed = [Event() for _ in range(depth)]
     results = [None] * depth
+    sources = [None] * depth  # a sequence's frames whose DMA may still be reading them
     pending: list = []  # slots whose kernel has been queued, oldest first
 
     def drain_one():
         slot = pending.pop(0)
-        computed[slot].sync()  # (the kernel has completed: its stores into the host array are visible)
-        out, results[slot] = results[slot], None
+        computed[slot].sync()  # (the kernel has completed: its stores into the host array are visible, the upload before it is through)
+        out, results[slot], sources[slot] = results[slot], None, None
         return out
 
     ahead = frames if isinstance(frames, (list, tuple)) else None
     k = 0
-    for frame in frames:
-        a = np.asarray(frame)
-        if a.dtype != np.uint8 or tuple(a.shape) != sh:
-            raise ValueError(f"frames must be uint8 {sh}, got {a.dtype} {tuple(a.shape)}")
-        slot = k % depth
-        if len(pending) == depth:  # the slot about to be reused still holds an undelivered result
+    try:
+        for frame in frames:
+            a = np.asarray(frame)
+            if a.dtype != np.uint8 or tuple(a.shape) != sh:
+                raise ValueError(f"frames must be uint8 {sh}, got {a.dtype} {tuple(a.shape)}")
+            slot = k % depth  # (free: the previous turn delivered its result, below)
+            direct = pipe.upload(a, d_in[slot], s_up)
+            uploaded[slot].record(s_up)
+            s_run.wait(uploaded[slot])
+            out = results[slot] = PINNED.ndarray(dh, np.uint8)
+            plan.launch(d_in[slot].data_ptr(), out.ctypes.data, 1, s_run.handle, interpolation)
+            computed[slot].record(s_run)
+            pending.append(slot)
+            if direct and ahead is not None:
+                # frames that already exist (a list, a tuple): nothing waits for this DMA - the next frame's is queued behind it at once;
+                # the frame is held until its kernel has run.  The NEXT frame is page-locked meanwhile (0.2-0.35 ms off the critical path).
+                sources[slot] = a
+                if k + 1 < len(ahead) and isinstance(ahead[k + 1], np.ndarray):
+                    REGISTERED.is_registered(ahead[k + 1])
+            # everything that does not need the next frame happens HERE, while this frame's DMA runs: the oldest result is handed over (the
+            # caller's turn with it included) and frees the slot the next frame takes.  What was left between the end of one upload and the
+            # start of the next - the link idle - used to hold all of this: 0.15-0.2 ms of a 2.25 ms frame.
+            if len(pending) == depth:
+                yield drain_one()
+            if direct and ahead is None:
+                # an iterator may refill the buffer the DMA is reading as soon as it is asked for the next frame: the DMA must be through
+                uploaded[slot].sync()
+            k += 1
+        while pending:
             yield drain_one()
-        # (the slot's previous remap has finished: its result was delivered, or is being waited for above)
-        direct = pipe.upload(a, d_in[slot], s_up)
-        uploaded[slot].record(s_up)
-        s_run.wait(uploaded[slot])
-        out = results[slot] = PINNED.ndarray(dh, np.uint8)
-        plan.launch(d_in[slot].data_ptr(), out.ctypes.data, 1, s_run.handle, interpolation)
-        computed[slot].record(s_run)
-        pending.append(slot)
-        if direct:
-            # frames that already exist (a list, a tuple): page-lock the NEXT one while this one's DMA runs (0.2-0.35 ms off the critical
-            # path; an iterator is never looked ahead into - it may refill the buffer the DMA is reading)
-            if ahead is not None and k + 1 < len(ahead) and isinstance(ahead[k + 1], np.ndarray):
-                REGISTERED.is_registered(ahead[k + 1])
-            uploaded[slot].sync()  # the DMA reads the caller's own buffer: it must be through before the caller refills it
-        k += 1
-    while pending:
-        yield drain_one()
+    finally:
+        # (a caller that stops early: nothing of the pipeline may still be reading its frames or writing the results it was not given)
+        s_up.sync()
+        s_run.sync()
+        pipe.give_ring(n_in, d_in)

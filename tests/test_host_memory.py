@@ -301,6 +301,29 @@ def test_streamed_results_outlive_the_generator_and_slots_are_not_overwritten(pi
     assert len({o.ctypes.data for o in kept}) == 9  # nine live results, nine distinct page-locked blocks
 
 
+def test_the_pipelines_device_ring_is_kept_between_calls_and_a_caller_may_stop_early(pipe_env):
+    """Round 6: remap_frames checks its rotating device input buffers out of the thread's pipe and returns them (three hipMallocs and
+    hipFrees of 100 MB per call otherwise); two pipelines alive at once never share a buffer; a caller that stops iterating leaves
+    nothing in flight (the generator's exit waits for both streams) and the ring goes back."""
+    lib, hp = pipe_env
+    frames = [np.full((16, 16, 3), k, np.uint8) for k in range(6)]
+    plan = FakePlan(16, 16, lib)
+    assert [int(o[0, 0, 0]) for o in hp.remap_frames(plan, frames, depth=3)] == list(range(6))
+    ring = len(lib.live_dev)
+    assert ring == 3
+    assert [int(o[0, 0, 0]) for o in hp.remap_frames(plan, frames, depth=3)] == list(range(6))
+    assert len(lib.live_dev) == ring  # the same three buffers served the second call
+    g1, g2 = hp.remap_frames(plan, frames, depth=2), hp.remap_frames(plan, list(reversed(frames)), depth=2)
+    got = [(int(next(g1)[0, 0, 0]), int(next(g2)[0, 0, 0])) for _ in range(3)]
+    assert got == [(0, 5), (1, 4), (2, 3)]
+    assert len(lib.live_dev) == ring + 1  # 2 + 2 buffers checked out, three of them from the idle ring
+    g1.close()  # stopped early
+    g2.close()
+    assert len(lib.live_dev) <= 4  # at most four idle buffers of a size are kept
+    assert [int(o[0, 0, 0]) for o in hp.remap_frames(plan, frames, depth=3)] == list(range(6))
+    gc.collect()
+
+
 def test_streaming_rejects_frames_of_the_wrong_shape_or_type(pipe_env):
     lib, hp = pipe_env
     plan = FakePlan(16, 16, lib)
