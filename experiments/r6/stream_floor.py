@@ -41,10 +41,11 @@ run(6)
 for label, kw in (("dependent, rotating outputs, no host sync", {}), ("... host waits for each upload (iterator semantics)", {"sync_each": True}),
                   ("... one output buffer", {"same_out": True}), ("independent (kernel does not wait for the upload)", {"dep": False})):
     print("%-60s %.3f ms / frame" % (label, min(run(16, **kw) for _ in range(3))), flush=True)
-frames = [h.reshape(case.src[1], case.src[2], 3) for h in hin]
-seq = [frames[k % D] for k in range(16)]
+rng = np.random.default_rng(5)
+ring = [rng.integers(0, 256, size=(case.src[1], case.src[2], 3), dtype=np.uint8) for _ in range(4)]  # the caller's own buffers: page-locked in place when first seen
+seq = [ring[k % 4] for k in range(16)]
 list(batch.remap_frames(plan, seq))
-for label, mk in (("batch.remap_frames, list of page-locked frames", lambda: seq), ("batch.remap_frames, iterator over the same", lambda: iter(seq))):
+for label, mk in (("batch.remap_frames, list over a ring of 4 caller buffers", lambda: seq), ("batch.remap_frames, iterator over the same", lambda: iter(seq))):
     ts = []
     for _ in range(3):
         t0 = time.perf_counter(); n = sum(1 for _ in batch.remap_frames(plan, mk())); ts.append((time.perf_counter() - t0) / n * 1e3)
