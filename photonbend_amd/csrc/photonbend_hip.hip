@@ -1263,7 +1263,18 @@ int pb_init(int device) {
     PB_HIP(hipSetDevice(device));
     return PB_OK;
 }
-int pb_shutdown(void) { return PB_OK; }
+int pb_shutdown(void) {
+    // the idle blocks of the plan-preparation cache (at most 32 MiB) go back to the driver; live plans keep theirs
+    std::vector<void*> idle;
+    {
+        std::lock_guard<std::mutex> g(g_tmp.lock);
+        for (const auto& b : g_tmp.idle) idle.push_back(b.ptr);
+        g_tmp.idle.clear();
+        g_tmp.held = 0;
+    }
+    for (void* p : idle) (void)hipFree(p);
+    return PB_OK;
+}
 
 int pb_device_name(char* buf, size_t buflen) {
     if (!buf || !buflen) return pb_fail(PB_ERR_INVALID, "null buffer");

@@ -240,6 +240,30 @@ def test_nearest_launches_run_on_while_another_thread_builds_the_bilinear_tables
 
 
 @pytest.mark.gpu
+def test_destroyed_plans_hand_their_tables_to_the_next_and_shutdown_returns_them():
+    """Round 6: a plan's tables come from the library's block cache and go back to it when the plan is destroyed (one device wait instead
+    of a hipFree - itself a device wait - per table); pb_shutdown returns the idle blocks to the driver.  Whatever block a table lands
+    in, the bytes are the same - also while an earlier plan of the same geometry is still alive and launching."""
+    case = Case("api_cache", cam(1536, 1536, "equidistant", 360, inscribed(1536)), pano(1024, 2048), [(5, -10, 20)])
+    d, rots, s = _projs(case)
+    frame = nat.synth_frame(case.src[1], case.src[2], frame=6, circle_mask=case.mask)
+    keeper = nat.Plan(d, rots, s)
+    want = keeper.remap(frame).clone()
+    want_bil = keeper.remap(frame, interpolation="bilinear").clone()
+    for k in range(4):
+        p = nat.Plan(d, rots, s, bilinear=bool(k & 1))
+        assert torch.equal(p.remap(frame), want) and torch.equal(keeper.remap(frame), want)
+        assert torch.equal(p.remap(frame, interpolation="bilinear"), want_bil)
+        del p
+    free_cached = torch.cuda.mem_get_info()[0]
+    assert nat.load().pb_shutdown() == 0
+    assert torch.cuda.mem_get_info()[0] >= free_cached
+    assert torch.equal(keeper.remap(frame), want)  # live plans keep their tables
+    p = nat.Plan(d, rots, s)
+    assert torch.equal(p.remap(frame), want)
+
+
+@pytest.mark.gpu
 def test_tune_is_opt_in_and_changes_no_byte():
     case = Case("tune", cam(1536, 1536, "equidistant", 360, inscribed(1536)), pano(1024, 2048))
     d, rots, s = _projs(case)
