@@ -1050,30 +1050,41 @@ __global__ __launch_bounds__(PB_BLOCK) void pb_fix_kernel(const PbParams P, cons
 }
 
 // ---- plan creation -------------------------------------------------------------------
-// Bisection for the destination-validity thresholds with the exact predicate.
-__global__ void pb_threshold_kernel(const PbParams P, long long* __restrict__ out) {
-    const int side = threadIdx.x;  // 0: left / single, 1: right eye of a double destination
-    if (side > 1) return;
+// The first n in [lo, hi) where a monotone predicate (false ... false true ... true) holds, hi if nowhere: 64 probes per step, one per
+// lane, instead of a bisection's one (3e7 candidates: 5 steps of one predicate's latency instead of 25 - the predicate is a chain of a
+// float64 square root and an arcsine, and a plan's preparation waits for this kernel: 25-35 us -> ~10).
+template <typename PRED>
+__device__ __forceinline__ long long pb_first_true_64(long long lo, long long hi, const int lane, PRED pred) {
+    while (lo < hi) {
+        const long long step = (hi - lo + 63) / 64;        // >= 1; the last lane's probe is hi - 1 or beyond
+        const long long p = lo + step * (lane + 1) - 1;
+        const bool t = (p < hi) ? pred(p) : true;            // (beyond the interval: counts as true)
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(t);
+        if (m == 0) return hi;                               // every probe false, hi - 1 among them
+        const int first = __builtin_ctzll(m);
+        const long long pf = lo + step * (first + 1) - 1;    // the first true probe; the one before it is false
+        lo += step * first;
+        hi = pf < hi ? pf : hi;                              // (at most step - 1 candidates left)
+    }
+    return lo;
+}
+// The destination-validity thresholds with the exact predicate: wave 0 the left / single image, wave 1 the right eye of a double destination.
+__global__ __launch_bounds__(128) void pb_threshold_kernel(const PbParams P, long long* __restrict__ out) {
+    const int side = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long wc = (P.dst.kind == PB_KIND_DOUBLE) ? P.dst_half_w : P.dst.width;
     const long long nmax = (wc - 1) * (wc - 1) + (long long)(P.dst.height - 1) * (P.dst.height - 1);
     // first n4 where the lens inverse leaves its domain (asin argument > 1); nmax + 1 if never
-    long long lo = 0, hi = nmax + 1;
-    while (lo < hi) {
-        const long long mid = lo + (hi - lo) / 2;
+    const long long n_dom = pb_first_true_64(0, nmax + 1, lane, [&](long long n) {
         bool outside;
-        pb_dst_inv_pred(P, mid, side != 0, &outside);
-        if (outside) hi = mid; else lo = mid + 1;
-    }
-    const long long n_dom = lo;
+        pb_dst_inv_pred(P, n, side != 0, &outside);
+        return outside;
+    });
     // first n4 in [0, n_dom) where the pixel is invalid (monotone inside the domain)
-    lo = 0;
-    hi = n_dom;
-    while (lo < hi) {
-        const long long mid = lo + (hi - lo) / 2;
-        if (pb_dst_inv_pred(P, mid, side != 0, nullptr)) hi = mid; else lo = mid + 1;
+    const long long lo = pb_first_true_64(0, n_dom, lane, [&](long long n) { return pb_dst_inv_pred(P, n, side != 0, nullptr); });
+    if (lane == 0) {
+        out[2 * side + 0] = lo;      // invalid  <=>  lo <= n4 < n_dom
+        out[2 * side + 1] = n_dom;
     }
-    out[2 * side + 0] = lo;      // invalid  <=>  lo <= n4 < n_dom
-    out[2 * side + 1] = n_dom;
 }
 
 // One wave per tile: 25 faithful node evaluations -> monomial coefficients (float64) ->

@@ -459,8 +459,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
     int rc = PB_OK;
     do {
         if (P.dst.kind != PB_KIND_PANO) {
-            hipLaunchKernelGGL(pb_threshold_kernel, dim3(1), dim3(2), 0, 0, P, scratch);
-            // (the bisection is one lane's chain of ~60 dependent square roots, 25-35 us: a single source's tile tables are allocated meanwhile)
+            hipLaunchKernelGGL(pb_threshold_kernel, dim3(1), dim3(128), 0, 0, P, scratch);
+            // (a chain of ~10 dependent square roots and arcsines, and the kernel's launch: a single source's tile tables are allocated meanwhile)
             if (P.src.kind != PB_KIND_DOUBLE && pb_fast_possible(P)) {
                 const unsigned nt0 = pb_num_tiles(P);
                 if (pb_tmp_alloc((void**)&pl->table, (size_t)nt0 * sizeof(PbTileEntry)) != hipSuccess ||
