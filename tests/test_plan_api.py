@@ -264,6 +264,42 @@ def test_destroyed_plans_hand_their_tables_to_the_next_and_shutdown_returns_them
 
 
 @pytest.mark.gpu
+def test_plans_made_used_and_destroyed_on_four_threads_at_once():
+    """The block cache under concurrent preparation and destruction: four threads each make, use (both samplers) and drop plans of three
+    geometries in turn, tables of one thread's dead plans serving another's new ones - every result equals the single-threaded one."""
+    cases = [CASES[0], CASES[2], Case("api_mt_cam", pano(512, 1024), cam(640, 640, "equidistant", 360, inscribed(640)))]
+    setups = []
+    for c in cases:
+        d, rots, s = _projs(c)
+        frame = nat.synth_frame(c.src[1], c.src[2], frame=1, circle_mask=c.mask)
+        p = nat.Plan(d, rots, s)
+        setups.append((d, rots, s, frame, p.remap(frame).clone(), p.remap(frame, interpolation="bilinear").clone()))
+        del p
+    torch.cuda.synchronize()
+    errors, bad = [], []
+
+    def worker(t):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for k in range(12):
+                    d, rots, s, frame, want, want_bil = setups[(k + t) % len(setups)]
+                    p = nat.Plan(d, rots, s, bilinear=bool((k + t) & 1))
+                    a = p.remap(frame)
+                    b = p.remap(frame, interpolation="bilinear") if k % 3 == 0 else None
+                    torch.cuda.current_stream().synchronize()
+                    if not torch.equal(a, want) or (b is not None and not torch.equal(b, want_bil)):
+                        bad.append((t, k))
+                    del p
+        except Exception as ex:  # pragma: no cover
+            errors.append(ex)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join(180) for t in ts]
+    assert not any(t.is_alive() for t in ts) and not errors and not bad, (errors, bad[:5])
+
+
+@pytest.mark.gpu
 def test_tune_is_opt_in_and_changes_no_byte():
     case = Case("tune", cam(1536, 1536, "equidistant", 360, inscribed(1536)), pano(1024, 2048))
     d, rots, s = _projs(case)
