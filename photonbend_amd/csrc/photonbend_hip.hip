@@ -987,8 +987,8 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     unsigned* counters = nullptr;
     const unsigned ng = pl->launch_groups_bil;
     unsigned res[2] = {0u, 0u};
-    hipError_t e = pb_tmp_alloc((void**)&counters, 4 * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 4 * sizeof(unsigned), 0);
+    hipError_t e = pb_tmp_alloc((void**)&counters, 8 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 8 * sizeof(unsigned), 0);
     if (e == hipSuccess && !pb_bil_off(1))  // direct-gather slots that can be served as two half windows
     {
         hipLaunchKernelGGL(pb_bilinear_halves_kernel, dim3(ng), dim3(256), 0, 0, pl->ltable_bil, 4u * ng, pl->bil_budget, pl->P.src.height, pl->P.src.width,
@@ -1001,14 +1001,18 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
         // (the one-eye slots of a virtual workgroup dealt to its two halves so that their LDS needs balance: largest with smallest)
         hipLaunchKernelGGL(pb_bilinear_balance_kernel, dim3(ng), dim3(64), 0, 0, pl->ltable_bil, ng);
         const struct { int waves; unsigned bytes; } tiers[3] = {{2, PB_BIL_POOL_SMALL / 2u}, {4, PB_BIL_POOL_SMALL}, {2, (163840u / 7u) & ~15u}};
+        // the three dry passes back to back, ONE read-back (a round trip is ~25 us; a plan that takes the third tier made three)
+        unsigned dry[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        e = hipMemsetAsync(counters, 0, 6 * sizeof(unsigned), 0);
         for (int t = 0; t < 3 && e == hipSuccess; ++t) {
             if (tiers[t].bytes >= (unsigned)tiers[t].waves * budget32) continue;
-            e = hipMemsetAsync(counters, 0, 2 * sizeof(unsigned), 0);
-            if (e != hipSuccess) break;
-            hipLaunchKernelGGL(pb_bilinear_pool_kernel, dim3((ng * (4u / (unsigned)tiers[t].waves) + 127) / 128), dim3(128), 0, 0, pl->ltable_bil, ng, tiers[t].bytes, 1, counters,
-                               tiers[t].waves);
-            e = hipMemcpy(res, counters, sizeof(res), hipMemcpyDeviceToHost);
-            if (e == hipSuccess && res[1] == 0u && res[0] * PB_BIL_POOL_RULE <= pl->n_tiles) {
+            hipLaunchKernelGGL(pb_bilinear_pool_kernel, dim3((ng * (4u / (unsigned)tiers[t].waves) + 127) / 128), dim3(128), 0, 0, pl->ltable_bil, ng, tiers[t].bytes, 1,
+                               counters + 2 * t, tiers[t].waves);
+        }
+        if (e == hipSuccess) e = hipMemcpy(dry, counters, sizeof(dry), hipMemcpyDeviceToHost);
+        for (int t = 0; t < 3 && e == hipSuccess; ++t) {
+            if (tiers[t].bytes >= (unsigned)tiers[t].waves * budget32) continue;
+            if (dry[2 * t + 1] == 0u && dry[2 * t] * PB_BIL_POOL_RULE <= pl->n_tiles) {
                 waves = tiers[t].waves;
                 pool = tiers[t].bytes;
                 break;
