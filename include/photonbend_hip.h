@@ -88,7 +88,7 @@ int pb_abi_version(void);
 int pb_math_flavour(void);
 const char* pb_last_error(void); /* thread-local, valid until the next failing call */
 int pb_init(int device);         /* hipSetDevice + sanity checks (gfx950 expected) */
-int pb_shutdown(void);           /* returns the idle blocks of the plan-preparation cache (<= 32 MiB of device memory) to the driver; plans stay valid */
+int pb_shutdown(void);           /* returns the idle blocks of the plan-preparation cache (<= 96 MiB of device memory) to the driver; plans stay valid */
 int pb_device_name(char* buf, size_t buflen);
 
 /* ---- the fused hot path ------------------------------------------------ */

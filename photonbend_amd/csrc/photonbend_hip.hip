@@ -159,7 +159,7 @@ static int pb_fail(int code, const std::string& msg) {
 
 // Small device buffers that live for a few launches of plan preparation (counters, per-unit costs, a column table): a hipFree costs ~35 us
 // on this stack (it synchronises the device) and a plan used to make nine - a third of a millisecond of a 1.3 ms preparation
-// (experiments/r4/plan_api.sh).  They come from a per-device cache instead: a freed block is kept (up to 32 MiB in blocks of up to 4 MiB)
+// (experiments/r4/plan_api.sh).  They come from a per-device cache instead: a freed block is kept (up to 96 MiB in blocks of up to 16 MiB: the tables of a 33-Mpx plan)
 // and handed to the next request it fits.  Safe because every user works on the NULL stream, which orders a block's next kernel behind its
 // last one device-wide, and because each site releases its block only after a synchronising copy or hipDeviceSynchronize.
 // Round 6: a plan's OWN tables (tile tables, fix lists, launch tables, parameter block) come from the same cache - a warm c2 plan made
@@ -211,7 +211,7 @@ static void pb_tmp_free(void* ptr) {
         if (it != g_tmp.live.end()) {
             const std::pair<int, size_t> info = it->second;
             g_tmp.live.erase(it);
-            if (info.second <= ((size_t)4 << 20) && g_tmp.held + info.second <= ((size_t)32 << 20)) {
+            if (info.second <= ((size_t)16 << 20) && g_tmp.held + info.second <= ((size_t)96 << 20)) {
                 g_tmp.idle.push_back({info.first, info.second, ptr});
                 g_tmp.held += info.second;
                 return;
@@ -1268,7 +1268,7 @@ int pb_init(int device) {
     return PB_OK;
 }
 int pb_shutdown(void) {
-    // the idle blocks of the plan-preparation cache (at most 32 MiB) go back to the driver; live plans keep theirs
+    // the idle blocks of the plan-preparation cache (at most 96 MiB) go back to the driver; live plans keep theirs
     std::vector<void*> idle;
     {
         std::lock_guard<std::mutex> g(g_tmp.lock);
