@@ -980,6 +980,15 @@ __global__ void pb_store_params_kernel(const PbParams P, PbParams* __restrict__ 
     unsigned* o = reinterpret_cast<unsigned*>(out);
     for (unsigned k = threadIdx.x; k < sizeof(PbParams) / 4u; k += blockDim.x) o[k] = in[k];
 }
+// A short host array into device memory from the kernel's own arguments, 256 words per launch: the launch order's unit list (a few hundred
+// entries) without the synchronous staged copy a pageable hipMemcpy is (~12 us).
+struct PbWordChunk {
+    int v[256];
+};
+__global__ void pb_store_words_kernel(const PbWordChunk c, int* __restrict__ out, int n) {
+    const int k = threadIdx.x;
+    if (k < n) out[k] = c.v[k];
+}
 __global__ void pb_save_flags_kernel(const PbTileEntry* __restrict__ table, int32_t* __restrict__ saved, unsigned n_tiles) {
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < n_tiles) saved[t] = table[t].flags;

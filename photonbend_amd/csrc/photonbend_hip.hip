@@ -875,7 +875,19 @@ static int pb_build_launch_table(pb_plan* pl, const bool bil = false, const unsi
     if (units && e == hipSuccess) {
         e = pb_tmp_alloc((void**)&unit_dev, unit_of.size() * sizeof(int));
         PB_STAGE("lt-host-order");
-        if (e == hipSuccess) e = hipMemcpy(unit_dev, unit_of.data(), unit_of.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            if (unit_of.size() <= 1024) {  // (up to four launches that nothing waits for)
+                for (size_t o = 0; o < unit_of.size(); o += 256) {
+                    PbWordChunk c;
+                    const size_t n = std::min<size_t>(256, unit_of.size() - o);
+                    memcpy(c.v, unit_of.data() + o, n * sizeof(int));
+                    hipLaunchKernelGGL(pb_store_words_kernel, dim3(1), dim3(256), 0, 0, c, unit_dev + o, (int)n);
+                }
+                e = hipGetLastError();
+            } else {
+                e = hipMemcpy(unit_dev, unit_of.data(), unit_of.size() * sizeof(int), hipMemcpyHostToDevice);
+            }
+        }
         PB_STAGE("lt-unit-upload");
     }
     if (bil && pl->dbl_ready) {
