@@ -377,6 +377,15 @@ static bool pb_fast_possible(const PbParams& P) {
 // the bilinear mode's plan state (pb_kernels_bilinear.hpp): which tiles the models cannot serve, their slots in the exact coordinate
 // table, the table itself and the fix list's coordinates - all from the faithful float64 chain, once per plan; derived state, not
 // serialized (rebuilt from the tile tables).  Synchronous.
+// A double-fisheye source whose field of view is within one degree above 180: the reference keeps blending for half a degree past the merge
+// band's end with the band's own slope (projection.py:416-418, :440-444), so the factor there reaches -0.5 deg / (fov - 180 deg) - minus
+// 45 at 180.011 degrees - and multiplies whatever an eye's sample is off by.  The tile kernels' eye samples may be the neighbouring integer
+// (1 LSB); with a band of a degree or more the factor stays within [-0.5, 1] and the sum within 2 LSB; below that the mode
+// runs its per-pixel float64 kernels, whose eye samples are the definition's.  (Exactly 180 degrees: the factor is infinite or NaN and
+// the cast gives 0 whatever the sample - no restriction.)
+static bool pb_bilinear_tiles_allowed(const PbParams& P) {
+    return !(P.src.kind == PB_KIND_DOUBLE && P.mrg_range > 0.0 && P.mrg_range < 0.999 * (PB_PI / 180.0));  // (181 degrees itself: tiles)
+}
 static int pb_build_bilinear_list(pb_plan* pl) {
     const PbParams& P = pl->P;
     unsigned* cnt = nullptr;
@@ -386,6 +395,7 @@ static int pb_build_bilinear_list(pb_plan* pl) {
     pl->bil_tiles = nullptr;
     pl->bil_xy = pl->bil_fix_xy = nullptr;
     pl->n_bil_tiles = pl->n_bil_slots = 0;
+    if (!pb_bilinear_tiles_allowed(P)) return PB_OK;  // (no tables: pb_remap_bilinear_u8 takes the float64 kernels)
     PB_HIP(pb_tmp_alloc((void**)&cnt, 2 * sizeof(unsigned)));
     hipError_t e = hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned), 0);
     if (e == hipSuccess) e = hipMalloc((void**)&pl->bil_tiles, (size_t)(pl->n_tiles ? pl->n_tiles : 1) * sizeof(int32_t));
@@ -988,6 +998,7 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     pb_table_release(pl->device, pl->ltable_bil);
     pl->ltable_bil = nullptr;
     pl->launch_groups_bil = 0;
+    if (!pb_bilinear_tiles_allowed(pl->P)) return PB_OK;
     pl->bil_budget = pb_clamp_budget(PB_BIL_WIN_BUDGET);
     int rc = pb_classify_under_budget(pl, pl->bil_budget, nullptr);
     if (rc == PB_OK) rc = pb_build_launch_table(pl, true);

@@ -243,6 +243,31 @@ def test_bilinear_tiles_on_noise_frames(case):
     assert int((dist(f64, want) > 1).sum()) == 0
 
 
+@pytest.mark.parametrize("fov, tiles_expected", [(180.05, False), (180.6, False), (181.0, True), (180.0, True), (195.0, True)])
+def test_a_stitch_with_a_merge_band_under_one_degree_runs_the_float64_kernels(fov, tiles_expected):
+    """The reference keeps blending for half a degree past the merge band's end with the band's own slope (projection.py:416-418, :440-444):
+    the factor there reaches -0.5 / (fov - 180), which multiplies whatever an eye's sample is off by (a 180.01-degree stitch: x 45; found
+    by the round's fuzz: 42 LSB).  With a band of a degree or more the factor stays within [-0.5, 1] and two +-1 samples stay within 2 LSB;
+    under a degree the plan builds no bilinear tile tables and the mode runs its per-pixel float64 kernels - within 1 LSB of the
+    definition like everywhere.  (Exactly 180: the factor is infinite, the cast gives 0 whatever the sample.)"""
+    case = Case(f"narrow_{fov}", pano(300, 600), dbl(440, 880, "equidistant", fov), [(20, -35, 10)])
+    plan = H.pb_plan_private(case)
+    info = plan.info()
+    assert (info["bilinear_float64_tiles"] == 0) == tiles_expected and (tiles_expected or info["bilinear_float64_tiles"] == info["tiles"])
+    assert (plan.bilinear_launch_shape()["workgroups"] > 0) == tiles_expected
+    frame = nat.synth_frame(case.src[1], case.src[2], frame=3)
+    src, cmap = H.pb_chain(case, frame)
+    want = nat.sample_map_bilinear(src._proj("src"), cmap.device_tensor(), frame, 3, np.uint8).reshape(case.dst[1], case.dst[2], 3).to(torch.int16)
+    got = plan.remap(frame, interpolation="bilinear").to(torch.int16)
+    d = (got - want).abs()
+    d = torch.minimum(d, 256 - d).amax(dim=2)
+    assert int((d > (2 if tiles_expected else 1)).sum()) == 0, f"{int((d > 1).sum())} pixels beyond 1 LSB, max {int(d.max())}"
+    plan.set_mode(nat.MODE_FAITHFUL)  # (the reference's sampler is untouched by any of this: tile kernels == float64 kernel)
+    near64 = plan.remap(frame)
+    plan.set_mode(nat.MODE_AUTO)
+    assert torch.equal(plan.remap(frame), near64)
+
+
 _TINY = [
     Case("tiny_pano_2x4", cam(33, 35, "equidistant", 180), pano(2, 4)),
     Case("tiny_pano_3x6", cam(40, 40, "equidistant", 360, inscribed(40)), pano(3, 6)),
