@@ -134,7 +134,7 @@ void pb_plan_destroy(pb_plan* plan);
  * PB_PLAN_BILINEAR (pb_plan_prepare, synchronous, no launch of the plan in flight) builds it later.  pb_remap_bilinear_u8 on a plan
  * without it is still correct - it runs the mode's per-pixel float64 kernels, several times slower - and pb_plan_bilinear_float64_tiles
  * says so (every tile).  A deferred plan (PB_PLAN_DEFER) remembers either choice for its preparation.  Default (neither flag): as before.
- * A double-fisheye source whose field of view lies within one degree above 180 never gets the tables: the reference's blend factor
+ * A double-fisheye source whose field of view lies within one degree of 180 (180 itself excepted) never gets the tables: the reference's blend factor
  * past the end of so narrow a merge band (projection.py:440-444) multiplies any sampler's rounding; the mode's float64 kernels serve it. */
 #define PB_PLAN_NO_BILINEAR 16u
 #define PB_PLAN_BILINEAR 32u

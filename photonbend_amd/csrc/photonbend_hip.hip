@@ -377,14 +377,15 @@ static bool pb_fast_possible(const PbParams& P) {
 // the bilinear mode's plan state (pb_kernels_bilinear.hpp): which tiles the models cannot serve, their slots in the exact coordinate
 // table, the table itself and the fix list's coordinates - all from the faithful float64 chain, once per plan; derived state, not
 // serialized (rebuilt from the tile tables).  Synchronous.
-// A double-fisheye source whose field of view is within one degree above 180: the reference keeps blending for half a degree past the merge
+// A double-fisheye source whose field of view is within one degree of 180 (not 180 itself): the reference keeps blending for half a degree past the merge
 // band's end with the band's own slope (projection.py:416-418, :440-444), so the factor there reaches -0.5 deg / (fov - 180 deg) - minus
 // 45 at 180.011 degrees - and multiplies whatever an eye's sample is off by.  The tile kernels' eye samples may be the neighbouring integer
 // (1 LSB); with a band of a degree or more the factor stays within [-0.5, 1] and the sum within 2 LSB; below that the mode
 // runs its per-pixel float64 kernels, whose eye samples are the definition's.  (Exactly 180 degrees: the factor is infinite or NaN and
 // the cast gives 0 whatever the sample - no restriction.)
 static bool pb_bilinear_tiles_allowed(const PbParams& P) {
-    return !(P.src.kind == PB_KIND_DOUBLE && P.mrg_range > 0.0 && P.mrg_range < 0.999 * (PB_PI / 180.0));  // (181 degrees itself: tiles)
+    // (below 180 degrees the band turns inside out; it exists down to 179.5 degrees, with factors from 1 up to 0.5 deg / (180 deg - fov))
+    return !(P.src.kind == PB_KIND_DOUBLE && P.mrg_range != 0.0 && fabs(P.mrg_range) < 0.999 * (PB_PI / 180.0));  // (181 / 179 degrees themselves: tiles)
 }
 static int pb_build_bilinear_list(pb_plan* pl) {
     const PbParams& P = pl->P;

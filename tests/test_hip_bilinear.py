@@ -243,7 +243,7 @@ def test_bilinear_tiles_on_noise_frames(case):
     assert int((dist(f64, want) > 1).sum()) == 0
 
 
-@pytest.mark.parametrize("fov, tiles_expected", [(180.05, False), (180.6, False), (181.0, True), (180.0, True), (195.0, True)])
+@pytest.mark.parametrize("fov, tiles_expected", [(180.05, False), (180.6, False), (179.8, False), (181.0, True), (180.0, True), (195.0, True), (170.0, True)])
 def test_a_stitch_with_a_merge_band_under_one_degree_runs_the_float64_kernels(fov, tiles_expected):
     """The reference keeps blending for half a degree past the merge band's end with the band's own slope (projection.py:416-418, :440-444):
     the factor there reaches -0.5 / (fov - 180), which multiplies whatever an eye's sample is off by (a 180.01-degree stitch: x 45; found
