@@ -883,6 +883,10 @@ def main():
     local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    from photonbend_amd.utils import numa
+
+    cpus_as_found = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    numa_cpus = numa.pin_to_device(local)  # (the rank runs - and first-touches its host buffers - on its GPU's NUMA node: host_path's upload DMA)
     coll_device = device if backend == "nccl" else torch.device("cpu")
     force_dist = os.environ.get("PB_FORCE_DIST") == "1"  # a group of ONE rank: the RCCL broadcast really runs on a 1-GPU box
     if world > 1 or force_dist:
@@ -1123,6 +1127,7 @@ def main():
             line["flavours"] = flavours_block("c3")
             try:
                 line["host_path"] = host_path(cfg, d, rots, s)
+                line["host_path"]["cpus_after_numa_pin"] = numa_cpus  # (0: affinity left as found - one node, or already inside the GPU's)
             except Exception as exc:  # a measurement extra: never fail the line over it
                 line["host_path"] = {"error": repr(exc)}
     # ---- north_star's multi-GPU workloads, at ANY rank count: c4 = 64 frames per GPU, c5 = 32 per GPU, sharded
@@ -1182,6 +1187,8 @@ def main():
             sharded["collective"] = "one broadcast of the 90-double parameter block per workload (RCCL when the backend is nccl); no pixel crosses a link"
             line["sharded"] = sharded
         if world == 1 and not args.no_cpu_baseline and not bilinear:  # (the CPU leg times the reference's nearest sampler)
+            if numa_cpus and cpus_as_found:
+                os.sched_setaffinity(0, cpus_as_found)  # (the CPU legs run where the host would have put them: the pin is the GPU path's)
             line["cpu_baseline"] = cpu_baseline(cfg, mpx_per_frame)
             extra = cpu_baseline_all_cores(args.config, mpx_per_frame)
             if extra:

@@ -204,7 +204,8 @@ class _Registrations:
 
     FIRST_SIGHT_BYTES = 32 << 20
 
-    def __init__(self, max_count: int = 8, max_bytes: int = 4 << 30):
+    def __init__(self, max_count: int = 48, max_bytes: int = 4 << 30):  # (an eviction's release contends with the pipeline's own HIP calls - 0.4-0.5 ms
+        # stalls of event.record / stream.wait measured while one ran: a batch of a few dozen never-seen frames should not evict; the bytes bound holds)
         self._seen = OrderedDict()  # (addr, nbytes) -> sightings
         self._reg = OrderedDict()   # addr -> (nbytes, weakref to owner)
         self._late = {}             # addr -> owner: evicted, its release is queued on the worker thread
