@@ -886,7 +886,7 @@ def main():
     from photonbend_amd.utils import numa
 
     cpus_as_found = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
-    numa_cpus = numa.pin_to_device(local)  # (the rank runs - and first-touches its host buffers - on its GPU's NUMA node: host_path's upload DMA)
+    numa_cpus = 0 if os.environ.get("PB_BENCH_NO_NUMA_PIN") == "1" else numa.pin_to_device(local)  # (the rank runs - and first-touches its host buffers - on its GPU's NUMA node: host_path's upload DMA)
     coll_device = device if backend == "nccl" else torch.device("cpu")
     force_dist = os.environ.get("PB_FORCE_DIST") == "1"  # a group of ONE rank: the RCCL broadcast really runs on a 1-GPU box
     if world > 1 or force_dist:
