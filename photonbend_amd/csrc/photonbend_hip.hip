@@ -390,16 +390,16 @@ static bool pb_bilinear_tiles_allowed(const PbParams& P) {
 static int pb_build_bilinear_list(pb_plan* pl) {
     const PbParams& P = pl->P;
     unsigned* cnt = nullptr;
-    (void)hipFree(pl->bil_tiles);
-    (void)hipFree(pl->bil_xy);
-    (void)hipFree(pl->bil_fix_xy);
+    pb_table_release(pl->device, pl->bil_tiles);
+    pb_table_release(pl->device, pl->bil_xy);
+    pb_table_release(pl->device, pl->bil_fix_xy);
     pl->bil_tiles = nullptr;
     pl->bil_xy = pl->bil_fix_xy = nullptr;
     pl->n_bil_tiles = pl->n_bil_slots = 0;
     if (!pb_bilinear_tiles_allowed(P)) return PB_OK;  // (no tables: pb_remap_bilinear_u8 takes the float64 kernels)
     PB_HIP(pb_tmp_alloc((void**)&cnt, 2 * sizeof(unsigned)));
     hipError_t e = hipMemsetAsync(cnt, 0, 2 * sizeof(unsigned), 0);
-    if (e == hipSuccess) e = hipMalloc((void**)&pl->bil_tiles, (size_t)(pl->n_tiles ? pl->n_tiles : 1) * sizeof(int32_t));
+    if (e == hipSuccess) e = pb_tmp_alloc((void**)&pl->bil_tiles, (size_t)(pl->n_tiles ? pl->n_tiles : 1) * sizeof(int32_t));
     unsigned res[2] = {0u, 0u};
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pb_bilinear_tile_list_kernel, dim3((pl->n_tiles + 255) / 256), dim3(256), 0, 0, pl->table, pl->table_r, pl->n_tiles, P.src_eye_w,
@@ -416,8 +416,8 @@ static int pb_build_bilinear_list(pb_plan* pl) {
                         (size_t)res[1] * PB_TILE * PB_TILE * sizeof(PbBilCoord) <= ((size_t)1 << 30);
     if (tables) {
         const unsigned np = pl->n_fix_px, stride = dbl ? 2u : 1u;
-        e = hipMalloc((void**)&pl->bil_xy, (size_t)(res[1] ? res[1] : 1u) * PB_TILE * PB_TILE * sizeof(PbBilCoord));
-        if (e == hipSuccess) e = hipMalloc((void**)&pl->bil_fix_xy, (size_t)(np ? np : 1u) * stride * sizeof(PbBilCoord));
+        e = pb_tmp_alloc((void**)&pl->bil_xy, (size_t)(res[1] ? res[1] : 1u) * PB_TILE * PB_TILE * sizeof(PbBilCoord));
+        if (e == hipSuccess) e = pb_tmp_alloc((void**)&pl->bil_fix_xy, (size_t)(np ? np : 1u) * stride * sizeof(PbBilCoord));
         if (e == hipSuccess) {
             const dim3 grid(4u * pl->n_tiles), block(PB_BLOCK), fgrid((np + PB_BLOCK - 1) / PB_BLOCK);
             if (dbl) {
@@ -441,13 +441,13 @@ static int pb_build_bilinear_list(pb_plan* pl) {
             if (dbl)
                 hipLaunchKernelGGL(pb_bilinear_orient_kernel, dim3(pl->n_tiles), dim3(256), 0, 0, pl->table_r, pl->bil_xy, P.src.height, P.src.width, P.src_eye_w,
                                    P.src.width, pb_knob("PB_BIL_OFF", 0), pl->saved_r);
-            e = hipDeviceSynchronize();
+            e = hipGetLastError();  // (not waited for: the launch builder's read-backs follow on the same stream and report a failure)
         }
     }
     if (e != hipSuccess) {
-        (void)hipFree(pl->bil_tiles);
-        (void)hipFree(pl->bil_xy);
-        (void)hipFree(pl->bil_fix_xy);
+        pb_table_release(pl->device, pl->bil_tiles);
+        pb_table_release(pl->device, pl->bil_xy);
+        pb_table_release(pl->device, pl->bil_fix_xy);
         pl->bil_tiles = nullptr;
         pl->bil_xy = pl->bil_fix_xy = nullptr;
         return pb_fail(PB_ERR_HIP, std::string("bilinear tables: ") + hipGetErrorString(e));
@@ -486,8 +486,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         P.thresholds_ready = 1;
         if (P.src.kind == PB_KIND_DOUBLE && P.dst.kind == PB_KIND_PANO && P.n_rot == 0) {
             // separable path: the row / column tables (their taps are checked against the faithful ones when first needed: pb_sep_verified)
-            if (hipMalloc((void**)&pl->sep_rows, (size_t)P.dst.height * sizeof(PbSepRow)) != hipSuccess ||
-                hipMalloc((void**)&pl->sep_cols, (size_t)P.dst.width * sizeof(PbSepCol)) != hipSuccess) { rc = PB_ERR_HIP; break; }
+            if (pb_tmp_alloc((void**)&pl->sep_rows, (size_t)P.dst.height * sizeof(PbSepRow)) != hipSuccess ||
+                pb_tmp_alloc((void**)&pl->sep_cols, (size_t)P.dst.width * sizeof(PbSepCol)) != hipSuccess) { rc = PB_ERR_HIP; break; }
             hipLaunchKernelGGL(pb_sep_tables_kernel, dim3(pb_blocks((unsigned long long)P.dst.height + P.dst.width)), dim3(PB_BLOCK), 0, 0,
                                P, pl->sep_rows, pl->sep_cols);
             pl->sep_ready = 1;
@@ -618,8 +618,8 @@ static int pb_plan_prepare_on_device(pb_plan* pl) {
         (void)hipDeviceSynchronize();
         pb_tmp_free(pl->table); pb_tmp_free(pl->fail_tiles); pb_tmp_free(pl->fix_px); pb_tmp_free(pl->idx_tab); pb_tmp_free(pl->fix_idx);
         pl->idx_tab = nullptr; pl->fix_idx = nullptr;
-        (void)hipFree(pl->sep_rows); (void)hipFree(pl->sep_cols); pb_tmp_free(pl->table_r); pb_tmp_free(pl->lat_tab);
-        pb_tmp_free(pl->dbl_tile_fix); pb_tmp_free(pl->dbl_px_fix); (void)hipFree(pl->bil_tiles); (void)hipFree(pl->bil_xy); (void)hipFree(pl->bil_fix_xy);
+        pb_tmp_free(pl->sep_rows); pb_tmp_free(pl->sep_cols); pb_tmp_free(pl->table_r); pb_tmp_free(pl->lat_tab);
+        pb_tmp_free(pl->dbl_tile_fix); pb_tmp_free(pl->dbl_px_fix); pb_table_release(pl->device, pl->bil_tiles); pb_table_release(pl->device, pl->bil_xy); pb_table_release(pl->device, pl->bil_fix_xy);
         pl->dbl_tile_fix = nullptr; pl->dbl_px_fix = nullptr; pl->bil_tiles = nullptr; pl->n_bil_tiles = 0;
         pl->bil_xy = pl->bil_fix_xy = nullptr; pl->n_bil_slots = 0;
         pb_sep_release(pl);
@@ -1063,7 +1063,7 @@ static int pb_build_bilinear_launch(pb_plan* pl) {
     if (pl->dbl_ready) {
         const PbDblTables T = {pl->P.mrg_min, pl->P.mrg_max_safe, pl->P.mrg_max, pl->P.mrg_range, pl->sep_ready ? pl->sep_rows : nullptr, pl->lat_tab, pl->fix_px,
                                pl->bil_fix_xy, pl->dbl_tile_fix, pl->dbl_px_fix};
-        if ((!pl->bil_dbl_tables && hipMalloc((void**)&pl->bil_dbl_tables, sizeof(PbDblTables)) != hipSuccess) ||
+        if ((!pl->bil_dbl_tables && pb_tmp_alloc((void**)&pl->bil_dbl_tables, sizeof(PbDblTables)) != hipSuccess) ||
             hipMemcpy(pl->bil_dbl_tables, &T, sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
             pb_table_release(pl->device, pl->ltable_bil);
             pl->ltable_bil = nullptr;
